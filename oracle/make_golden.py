@@ -1,0 +1,135 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz from the UNMODIFIED reference.
+
+Run in the build container (needs /root/reference):   python -m oracle.make_golden
+
+For each case: parameters are drawn with oracle.vlp_oracle.init_params(seed) (reproducible from the
+seed alone, so the multi-MB weights never need to be committed), loaded into the reference's own
+BertForPreTrainingLossMask (strict state_dict load => also pins checkpoint key names), a seeded
+synthetic batch (vlp_amd.synthetic) is pushed through the reference forward + backward, and the
+reference's outputs are stored: losses, MLM / VQA logits (captured by forward hooks on
+`cls.predictions` / `ans_classifier`, modeling.py:1102,1139 -- the reference never returns logits),
+a strided sample of every layer's hidden states, per-parameter gradient L2 norms and strided samples
+of selected gradients, and the parameters after one reference BertAdam.step().
+A fingerprint of the generated parameters/batch is stored too so a consumer can tell an RNG-stream
+mismatch from a parity failure.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import ref_loader, vlp_oracle as O          # noqa: E402
+from vlp_amd import synthetic as S                      # noqa: E402
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+CASES = {
+    # name: (model kwargs, batch kwargs)
+    "img2txt_L123_2l": (dict(vocab_size=1024, layers=2, tasks="img2txt", seed=11),
+                        dict(batch_size=2, max_len_b=20, vocab_size=1024, max_pred=3, s2s_prob=0.5, seed=101)),
+    "img2txt_L167_2l": (dict(vocab_size=1024, layers=2, tasks="img2txt", seed=12),
+                        dict(batch_size=3, max_len_b=64, vocab_size=1024, max_pred=3, s2s_prob=1.0, seed=102)),
+    "vqa2_L123_2l": (dict(vocab_size=1024, layers=2, tasks="vqa2", seed=13),
+                     dict(batch_size=2, max_len_b=20, vocab_size=1024, max_pred=1, tasks="vqa2", seed=103)),
+    "img2txt_L167_12l": (dict(vocab_size=2048, layers=12, tasks="img2txt", seed=14),
+                         dict(batch_size=2, max_len_b=64, vocab_size=2048, max_pred=3, s2s_prob=0.75, seed=104)),
+}
+
+GRAD_SAMPLES = [
+    "bert.embeddings.word_embeddings.weight", "bert.embeddings.position_embeddings.weight",
+    "bert.embeddings.token_type_embeddings.weight", "bert.embeddings.LayerNorm.weight",
+    "bert.encoder.layer.0.attention.self.query.weight", "bert.encoder.layer.0.attention.self.value.bias",
+    "bert.encoder.layer.1.intermediate.dense.weight", "bert.encoder.layer.1.output.LayerNorm.bias",
+    "vis_embed.0.weight", "vis_embed.2.bias", "vis_pe_embed.0.weight",
+    "cls.predictions.transform.dense.weight", "cls.predictions.bias", "ans_classifier.2.weight",
+]
+
+
+def sample(t, n=4096):
+    """Deterministic strided sample of a tensor (flattened)."""
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n].float().numpy().copy()
+
+
+def fingerprint(p, batch):
+    keys = sorted(p.keys())
+    fp = [float(p[k].double().abs().sum()) for k in keys[:8]]
+    fp += [float(batch.img.double().sum()), float(batch.vis_pe.double().abs().sum()),
+           float(batch.input_ids.sum()), float(batch.input_mask.sum())]
+    return np.asarray(fp, dtype=np.float64)
+
+
+def run_reference_case(mk, bk):
+    ref = ref_loader.load_reference()
+    tasks = mk["tasks"]
+    p = O.init_params(vocab_size=mk["vocab_size"], layers=mk["layers"], tasks=tasks, seed=mk["seed"])
+    model = ref_loader.build_reference_model(dict(vocab_size=mk["vocab_size"], num_hidden_layers=mk["layers"]),
+                                             tasks=tasks, seed=0)
+    sd = dict(p)
+    sd["cls.predictions.decoder.weight"] = p["bert.embeddings.word_embeddings.weight"]
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    model.eval()
+    batch = S.make_batch(**bk)
+    cap = {}
+    model.cls.predictions.register_forward_hook(lambda m, i, o: cap.__setitem__("mlm_logits", o.detach()))
+    if tasks == "vqa2":
+        model.ans_classifier.register_forward_hook(lambda m, i, o: cap.__setitem__("vqa_logits", o.detach()))
+    hid = []
+    model.bert.embeddings.register_forward_hook(lambda m, i, o: hid.append(o.detach()))
+    for lyr in model.bert.encoder.layer:
+        lyr.register_forward_hook(lambda m, i, o: hid.append(o.detach()))
+    losses = model(batch.img, batch.vis_pe, batch.input_ids, batch.segment_ids, batch.input_mask,
+                   batch.lm_label_ids, batch.ans_labels, batch.is_next, masked_pos=batch.masked_pos,
+                   masked_weights=batch.masked_weights, task_idx=batch.task_idx,
+                   vis_masked_pos=batch.vis_masked_pos, mask_image_regions=False, drop_worst_ratio=0)
+    loss = losses[0] + losses[1] + losses[2]          # run_img2txt_dist.py:531
+    loss.sum().backward()
+    out = {"fingerprint": fingerprint(p, batch),
+           "loss_shapes": np.asarray([l.dim() for l in losses]),
+           "losses": np.asarray([float(l.detach().sum()) for l in losses], dtype=np.float64)}
+    for k, v in cap.items():
+        out[k] = v.float().numpy()
+    for i, h in enumerate(hid):
+        out["hidden_%d" % i] = sample(h)
+    names, norms = [], []
+    for n, q in model.named_parameters():
+        names.append(n)
+        norms.append(-1.0 if q.grad is None else float(q.grad.double().norm()))
+        if n in GRAD_SAMPLES and q.grad is not None:
+            out["grad::" + n] = sample(q.grad)
+    out["param_names"] = np.asarray(names)
+    out["grad_norms"] = np.asarray(norms, dtype=np.float64)
+    # one reference BertAdam step (optimization.py:112-182) with the train script's param groups
+    # (run_img2txt_dist.py:394-401,422-426)
+    no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
+    named = list(model.named_parameters())
+    groups = [{"params": [q for n, q in named if not any(nd in n for nd in no_decay)], "weight_decay": 0.01},
+              {"params": [q for n, q in named if any(nd in n for nd in no_decay)], "weight_decay": 0.0}]
+    opt = ref.optimization.BertAdam(groups, lr=1e-2, warmup=0.1, schedule="warmup_linear", t_total=20)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        opt.step()          # step 0 of a warmup schedule has lr 0 ...
+        opt.step()          # ... so take two steps with the same gradients
+    for n, q in named:
+        if n in GRAD_SAMPLES:
+            out["adam::" + n] = sample(q.detach() - p[n])      # the update, not the weight
+    return out
+
+
+def main():
+    torch.set_num_threads(8)
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    for name, (mk, bk) in CASES.items():
+        out = run_reference_case(mk, bk)
+        path = os.path.join(GOLDEN_DIR, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("%s: losses=%s  -> %s (%.1f KB)" % (name, out["losses"], path, os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    main()

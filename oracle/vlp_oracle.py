@@ -1,0 +1,438 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement (the *oracle*) of the reference's hot path.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this file; the product (``vlp_amd/``) never does and fails loudly without its HIP library.
+
+What it restates: the unified encoder-decoder forward of LuoweiZhou/VLP
+(``pytorch_pretrained_bert/modeling.py``), its losses, and the optimizer arithmetic
+(``pytorch_pretrained_bert/optimization.py`` + apex FusedAdam/FP16_Optimizer as called from
+``vlp/run_img2txt_dist.py:411-420,571-585``).  Every function cites the reference lines it follows.
+It is a *functional* restatement over a plain ``{state_dict key: tensor}`` dict (the reference's
+checkpoint key names), written with elementary torch CPU ops in the dtype of the parameters
+(fp32 for ground truth, fp64 for tight kernel checks).  Backward is obtained by torch autograd
+over these elementary ops (the path is floating point, so a torch reference is the yardstick).
+
+PINNING (see tests/test_oracle_vs_reference.py and oracle/make_golden.py):
+  * forward / losses / gradients / BertAdam: pinned against the reference's own modeling.py and
+    optimization.py executed unmodified in the build container (oracle/ref_loader.py), and against
+    the committed fixtures in tests/golden/ generated from that reference.
+  * apex arithmetic (FusedLayerNorm, FusedAdam, FP16_Optimizer @1603407): apex is not under
+    /root/reference and is not installable offline -> **parity unpinned** for `fused_adam_step`
+    and `LossScaler`; they restate apex's published algorithm from the call sites
+    (run_img2txt_dist.py:411-420, optimization_fp16.py:7-80).  LayerNorm follows the in-repo
+    python fallback (modeling.py:179-192), which is what runs when apex is absent.
+  * Unlike the reference (modeling.py:231 asserts len_vis_input == 100) the restatement accepts any
+    region count so BASELINE.json's 8-region plumbing config can be checked.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------------------------
+# elementary ops
+# ----------------------------------------------------------------------------------------------
+def gelu(x):
+    """modeling.py:62-67 (exact erf form)."""
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def layer_norm(x, weight, bias, eps=1e-5):
+    """modeling.py:188-192 (TF style: eps inside the sqrt; biased variance)."""
+    u = x.mean(-1, keepdim=True)
+    s = (x - u).pow(2).mean(-1, keepdim=True)
+    x = (x - u) / torch.sqrt(s + eps)
+    return weight * x + bias
+
+
+def linear(x, w, b=None):
+    y = x.matmul(w.t())
+    return y if b is None else y + b
+
+
+def extended_attention_mask(attention_mask, dtype):
+    """modeling.py:807-833: [B,L,L] (or [B,L]) 0/1 -> additive [B,1,L,L] with 0 / -10000."""
+    if attention_mask.dim() == 2:
+        ext = attention_mask.unsqueeze(1).unsqueeze(2)
+    elif attention_mask.dim() == 3:
+        ext = attention_mask.unsqueeze(1)
+    else:
+        raise NotImplementedError
+    ext = ext.to(dtype=dtype)
+    return (1.0 - ext) * -10000.0
+
+
+# ----------------------------------------------------------------------------------------------
+# model
+# ----------------------------------------------------------------------------------------------
+def vis_embed(p, vis_feats):
+    """modeling.py:1003-1007,1035: ReLU(Linear(2048,768)(ReLU(Linear(2048,2048)(x)))) (dropout p=0)."""
+    h = torch.relu(linear(vis_feats, p["vis_embed.0.weight"], p["vis_embed.0.bias"]))
+    return torch.relu(linear(h, p["vis_embed.2.weight"], p["vis_embed.2.bias"]))
+
+
+def vis_pe_embed(p, vis_pe):
+    """modeling.py:1016-1018,1036."""
+    return torch.relu(linear(vis_pe, p["vis_pe_embed.0.weight"], p["vis_pe_embed.0.bias"]))
+
+
+def embeddings(p, vis_feats_h, vis_pe_h, input_ids, token_type_ids, len_vis_input, position_ids=None,
+               vis_input=True):
+    """modeling.py:217-241: rows 1..Nv of the word stream are the projected region features and rows
+    1..Nv of the position stream are the projected box/class encodings."""
+    B, L = input_ids.shape
+    if position_ids is None:
+        position_ids = torch.arange(L, dtype=torch.long).unsqueeze(0).expand_as(input_ids)
+    words = p["bert.embeddings.word_embeddings.weight"][input_ids]
+    pos = p["bert.embeddings.position_embeddings.weight"][position_ids]
+    if vis_input:
+        Nv = len_vis_input
+        words = torch.cat((words[:, :1], vis_feats_h, words[:, Nv + 1:]), dim=1)
+        pos = torch.cat((pos[:, :1], vis_pe_h, pos[:, Nv + 1:]), dim=1)
+    typ = p["bert.embeddings.token_type_embeddings.weight"][token_type_ids]
+    pre = words + pos + typ
+    out = layer_norm(pre, p["bert.embeddings.LayerNorm.weight"], p["bert.embeddings.LayerNorm.bias"])
+    return out, pre
+
+
+def self_attention(p, pre, x, ext_mask, num_heads, history=None, cap=None):
+    """modeling.py:268-303.  `pre` = 'bert.encoder.layer.{i}.attention.self.'"""
+    B, Lq, H = x.shape
+    d = H // num_heads
+    kv_in = x if history is None else torch.cat((history, x), dim=1)
+    q = linear(x, p[pre + "query.weight"], p[pre + "query.bias"])
+    k = linear(kv_in, p[pre + "key.weight"], p[pre + "key.bias"])
+    v = linear(kv_in, p[pre + "value.weight"], p[pre + "value.bias"])
+
+    def heads(t):  # transpose_for_scores :262-266
+        return t.view(t.shape[0], t.shape[1], num_heads, d).permute(0, 2, 1, 3)
+
+    q, k, v = heads(q), heads(k), heads(v)
+    scores = q.matmul(k.transpose(-1, -2)) / math.sqrt(d)
+    scores = scores + ext_mask
+    probs = torch.softmax(scores, dim=-1)
+    ctx = probs.matmul(v).permute(0, 2, 1, 3).contiguous().view(B, Lq, H)
+    if cap is not None:
+        cap["probs"] = probs
+    return ctx
+
+
+def bert_layer(p, i, x, ext_mask, num_heads, history=None, cap=None):
+    """modeling.py:306-372 (BertSelfOutput, BertIntermediate, BertOutput, BertLayer)."""
+    L = "bert.encoder.layer.%d." % i
+    ctx = self_attention(p, L + "attention.self.", x, ext_mask, num_heads, history, cap)
+    a = linear(ctx, p[L + "attention.output.dense.weight"], p[L + "attention.output.dense.bias"])
+    a = layer_norm(a + x, p[L + "attention.output.LayerNorm.weight"], p[L + "attention.output.LayerNorm.bias"])
+    g = gelu(linear(a, p[L + "intermediate.dense.weight"], p[L + "intermediate.dense.bias"]))
+    o = linear(g, p[L + "output.dense.weight"], p[L + "output.dense.bias"])
+    o = layer_norm(o + a, p[L + "output.LayerNorm.weight"], p[L + "output.LayerNorm.bias"])
+    if cap is not None:
+        cap.update(ctx=ctx, attn_out=a, inter=g)
+    return o
+
+
+def num_layers_of(p):
+    n = 0
+    while ("bert.encoder.layer.%d.output.dense.weight" % n) in p:
+        n += 1
+    return n
+
+
+def encoder(p, x, ext_mask, num_heads, num_layers=None):
+    """modeling.py:382-402 (no-history path).  Returns the list of all layer outputs."""
+    outs = []
+    for i in range(num_layers if num_layers is not None else num_layers_of(p)):
+        x = bert_layer(p, i, x, ext_mask, num_heads)
+        outs.append(x)
+    return outs
+
+
+def pooler(p, h):
+    """modeling.py:411-417."""
+    return torch.tanh(linear(h[:, 0], p["bert.pooler.dense.weight"], p["bert.pooler.dense.bias"]))
+
+
+def lm_head(p, h):
+    """modeling.py:431-435, 465-482 (relax_projection off): LN(gelu(dense(x))) . E^T + bias (tied)."""
+    t = gelu(linear(h, p["cls.predictions.transform.dense.weight"], p["cls.predictions.transform.dense.bias"]))
+    t = layer_norm(t, p["cls.predictions.transform.LayerNorm.weight"], p["cls.predictions.transform.LayerNorm.bias"])
+    return linear(t, p["bert.embeddings.word_embeddings.weight"]) + p["cls.predictions.bias"]
+
+
+def gather_seq_out_by_pos(seq, pos):
+    """modeling.py:1068-1069."""
+    return torch.gather(seq, 1, pos.unsqueeze(2).expand(-1, -1, seq.size(-1)))
+
+
+def loss_mask_and_normalize(loss, mask, drop_worst_ratio):
+    """modeling.py:1083-1093."""
+    mask = mask.type_as(loss)
+    loss = loss * mask
+    keep_loss, keep_ind = torch.topk(loss.sum(-1), int(loss.size(0) * (1 - drop_worst_ratio)), largest=False)
+    denominator = torch.sum(mask.sum(-1)[keep_ind]) + 1e-5
+    return (keep_loss / denominator).sum()
+
+
+def vqa_head(p, h, len_vis_input):
+    """modeling.py:1027-1030,1044-1045,1138-1139."""
+    e = h[:, 0] * h[:, len_vis_input + 1]
+    z = torch.relu(linear(e, p["ans_classifier.0.weight"], p["ans_classifier.0.bias"]))
+    return linear(z, p["ans_classifier.2.weight"], p["ans_classifier.2.bias"])
+
+
+def forward_pretraining_loss_mask(p, batch, num_heads=12, len_vis_input=100, tasks="img2txt",
+                                  drop_worst_ratio=0.0, vqa_inference=False, capture=False):
+    """modeling.py:1033-1143 (BertForPreTrainingLossMask.forward; mask_image_regions off, dropout 0).
+
+    Returns a dict: losses (`mlm_loss`, `vis_pretext_loss`, `vqa_loss` shaped like the reference's
+    3-tuple) plus the parity capture points `mlm_logits` / `vqa_logits` / `hidden` (list)."""
+    dt = p["bert.embeddings.word_embeddings.weight"].dtype
+    out = {}
+    vf = vis_embed(p, batch.img.to(dt))
+    vp = vis_pe_embed(p, batch.vis_pe.to(dt))
+    ext = extended_attention_mask(batch.input_mask, dt)
+    emb, emb_pre = embeddings(p, vf, vp, batch.input_ids, batch.segment_ids, len_vis_input)
+    hs = encoder(p, emb, ext, num_heads)
+    seq = hs[-1]
+    if capture:
+        out.update(vis_feats=vf, vis_pe=vp, emb=emb, emb_pre=emb_pre, hidden=hs)
+    out["sequence_output"] = seq
+
+    if vqa_inference:
+        logits = vqa_head(p, seq, len_vis_input)
+        out["vqa_logits"] = logits
+        out["ans_idx"] = torch.max(logits[:, 1:], -1)[1] + 1     # :1046
+        return out
+
+    zero1 = seq.new_zeros(1)
+    if batch.masked_pos.numel() == 0:
+        mlm_loss = zero1.clone()                                   # :1096-1098
+    else:
+        sel = gather_seq_out_by_pos(seq, batch.masked_pos)
+        logits = lm_head(p, sel)
+        out["mlm_logits"] = logits
+        ce = F.cross_entropy(logits.transpose(1, 2).float(), batch.lm_label_ids, reduction="none")   # :1108
+        mlm_loss = loss_mask_and_normalize(ce.float(), batch.masked_weights, drop_worst_ratio)
+    vis_pretext_loss = zero1.clone()                               # :1133
+    if tasks == "vqa2":
+        logits = vqa_head(p, seq, len_vis_input)
+        out["vqa_logits"] = logits
+        vqa_loss = F.binary_cross_entropy_with_logits(logits, batch.ans_labels.to(dt)) * batch.ans_labels.size(1)
+        out.update(mlm_loss=zero1.clone(), vis_pretext_loss=vis_pretext_loss, vqa_loss=vqa_loss)   # :1141
+    else:
+        out.update(mlm_loss=mlm_loss, vis_pretext_loss=vis_pretext_loss, vqa_loss=zero1.clone())  # :1143
+    out["loss"] = out["mlm_loss"] + out["vis_pretext_loss"] + out["vqa_loss"]   # run_img2txt_dist.py:531
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# incremental decoding (reference "next" row N1; restated for later rounds)
+# ----------------------------------------------------------------------------------------------
+def greedy_decode(p, batch_img, batch_vis_pe, input_ids, token_type_ids, position_ids, attention_mask,
+                  mask_word_id, num_heads=12, len_vis_input=100):
+    """modeling.py:1189-1253 (sample_mode='greedy', beam size 1) with the hidden-state history
+    caches of BertModelIncr/BertEncoder (:856-875, :386-394)."""
+    dt = p["bert.embeddings.word_embeddings.weight"].dtype
+    vf, vp = vis_embed(p, batch_img.to(dt)), vis_pe_embed(p, batch_vis_pe.to(dt))
+    nl = num_layers_of(p)
+    in_len, out_len = input_ids.shape[1], token_type_ids.shape[1]
+    out_ids, out_probs = [], []
+    prev_emb, prev_layers = None, None
+    curr_ids = input_ids
+    mask_ids = input_ids[:, :1] * 0 + mask_word_id
+    next_pos = in_len
+    while next_pos < out_len:
+        cl = curr_ids.shape[1]
+        st = next_pos - cl
+        x_ids = torch.cat((curr_ids, mask_ids), dim=1)
+        tt = token_type_ids[:, st:next_pos + 1]
+        am = attention_mask[:, st:next_pos + 1, :next_pos + 1]
+        pid = position_ids[:, st:next_pos + 1]
+        ext = extended_attention_mask(am, dt)
+        emb, _ = embeddings(p, vf, vp, x_ids, tt, len_vis_input, position_ids=pid, vis_input=(prev_layers is None))
+        x, hist, new_layers = emb, prev_emb, []
+        for i in range(nl):
+            x = bert_layer(p, i, x, ext, num_heads, history=hist)
+            new_layers.append(x)
+            if prev_layers is not None:
+                hist = prev_layers[i]
+        logits = lm_head(p, new_layers[-1][:, -1:, :])
+        mp, mi = torch.max(logits, dim=-1)
+        out_ids.append(mi)
+        out_probs.append(mp)
+        prev_emb = emb[:, :-1] if prev_emb is None else torch.cat((prev_emb, emb[:, :-1]), dim=1)
+        if prev_layers is None:
+            prev_layers = [t[:, :-1] for t in new_layers]
+        else:
+            prev_layers = [torch.cat((a, b[:, :-1]), dim=1) for a, b in zip(prev_layers, new_layers)]
+        curr_ids = mi
+        next_pos += 1
+    return torch.cat(out_ids, dim=1), torch.cat(out_probs, dim=1)
+
+
+# ----------------------------------------------------------------------------------------------
+# optimizers
+# ----------------------------------------------------------------------------------------------
+def warmup_linear(x, warmup=0.002):
+    """optimization.py:45-48."""
+    if x < warmup:
+        return x / warmup
+    return max((x - 1.) / (warmup - 1.), 0)
+
+
+def warmup_constant(x, warmup=0.002):
+    """optimization.py:39-42."""
+    return x / warmup if x < warmup else 1.0
+
+
+def warmup_cosine(x, warmup=0.002):
+    """optimization.py:33-36."""
+    if x < warmup:
+        return x / warmup
+    return 0.5 * (1.0 + math.cos(math.pi * x))
+
+
+SCHEDULES = {"warmup_cosine": warmup_cosine, "warmup_constant": warmup_constant, "warmup_linear": warmup_linear}
+
+
+def bert_adam_step(p, g, m, v, step, lr, warmup=-1, t_total=-1, schedule="warmup_linear", b1=0.9, b2=0.999,
+                   e=1e-6, weight_decay=0.01, max_grad_norm=1.0):
+    """optimization.py:112-182 for ONE parameter tensor; updates p, m, v in place, returns step+1.
+    Note the clip is per parameter tensor (:146-147, clip_grad_norm_ on the single tensor: coefficient
+    max_norm / (norm + 1e-6), applied only when < 1) and there is no bias correction (:177-180)."""
+    g = g.clone()
+    if max_grad_norm > 0:
+        norm = g.norm(2)
+        coef = max_grad_norm / (norm + 1e-6)
+        if coef < 1:
+            g.mul_(coef)
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    update = m / (v.sqrt() + e)
+    if weight_decay > 0.0:
+        update = update + weight_decay * p
+    lr_s = lr * SCHEDULES[schedule](step / t_total, warmup) if t_total != -1 else lr
+    p.add_(-lr_s * update)
+    return step + 1
+
+
+def fused_adam_step(p32, g16_scaled, m, v, lr, grad_norm_scaled, scale, b1=0.9, b2=0.999, eps=1e-8,
+                    weight_decay=0.0, max_grad_norm=1.0, step=1, bias_correction=False,
+                    eps_inside_sqrt=False):
+    """apex FusedAdam.step + fused_adam_cuda kernel as configured at run_img2txt_dist.py:411-414
+    (bias_correction=False, max_grad_norm=1.0, eps 1e-8) for ONE param group whose gradient is the
+    flat fp16 tensor `g16_scaled` (still multiplied by the loss scale) with L2 norm
+    `grad_norm_scaled`.  **parity unpinned** (apex @1603407 is not in /root/reference):
+        clip = (norm/scale + 1e-6) / max_grad_norm ; combined_scale = scale * max(clip, 1)
+        g = g16/combined_scale ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2
+        denom = sqrt(v + eps) if eps_inside_sqrt else sqrt(v) + eps
+        p -= step_size * (m/denom + decay*p) ; p16 = half(p)
+    Returns the fp16 copy of the updated master weights."""
+    combined = scale
+    if max_grad_norm > 0:
+        clip = ((grad_norm_scaled / scale) + 1e-6) / max_grad_norm
+        if clip > 1:
+            combined = clip * scale
+    if bias_correction:
+        step_size = lr * math.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+    else:
+        step_size = lr
+    g = g16_scaled.float() / combined
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).add_(g * g, alpha=1 - b2)
+    denom = torch.sqrt(v + eps) if eps_inside_sqrt else torch.sqrt(v) + eps
+    p32.sub_(step_size * (m / denom + weight_decay * p32))
+    return p32.half()
+
+
+class LossScaler(object):
+    """apex FP16_Optimizer (the FusedAdam-only variant) dynamic loss-scale bookkeeping, as wrapped
+    by optimization_fp16.py:7-80 (state_dict fields :28-37).  **parity unpinned** (apex absent):
+    init scale 2**16, x2 every `scale_window`=1000 clean iterations, /2 (floor 1) on overflow."""
+
+    def __init__(self, dynamic=True, static_loss_scale=1.0, init_scale=2 ** 16, scale_factor=2, scale_window=1000):
+        self.dynamic = dynamic
+        self.cur_scale = init_scale if dynamic else static_loss_scale
+        self.cur_iter = 0
+        self.last_overflow_iter = -1
+        self.scale_factor = scale_factor
+        self.scale_window = scale_window
+
+    def update(self, overflow):
+        if self.dynamic:
+            if overflow:
+                self.cur_scale = max(self.cur_scale / self.scale_factor, 1)
+                self.last_overflow_iter = self.cur_iter
+            elif (self.cur_iter - self.last_overflow_iter) % self.scale_window == 0:
+                self.cur_scale *= self.scale_factor
+        self.cur_iter += 1
+
+
+# ----------------------------------------------------------------------------------------------
+# helpers for tests / bench
+# ----------------------------------------------------------------------------------------------
+def params_from_state_dict(sd, dtype=torch.float32, requires_grad=False):
+    """Clone a reference-keyed state_dict into oracle parameters.  The tied decoder weight
+    (cls.predictions.decoder.weight, modeling.py:445-448) is dropped: lm_head() reads the word
+    embedding table directly so autograd accumulates both uses into one gradient."""
+    p = {}
+    for k, t in sd.items():
+        if k == "cls.predictions.decoder.weight":
+            continue
+        t = t.detach().to(dtype).clone()
+        if requires_grad:
+            t.requires_grad_(True)
+        p[k] = t
+    return p
+
+
+def init_params(vocab_size=28996, hidden=768, layers=12, inter=3072, max_pos=512, type_vocab=6,
+                tasks="img2txt", feat_dim=2048, pe_dim=1607, num_answers=3129, seed=0, std=0.02,
+                dtype=torch.float32):
+    """Random parameters with the reference's shapes and init law (modeling.py:539-551:
+    N(0, initializer_range) weights, zero biases, unit LayerNorm), keyed like its state_dict."""
+    g = torch.Generator().manual_seed(seed)
+
+    def w(*shape):
+        return (torch.randn(*shape, generator=g) * std).to(dtype)
+
+    def z(*shape):
+        return torch.zeros(*shape, dtype=dtype)
+
+    def o(*shape):
+        return torch.ones(*shape, dtype=dtype)
+
+    p = {}
+    p["bert.embeddings.word_embeddings.weight"] = w(vocab_size, hidden)
+    p["bert.embeddings.position_embeddings.weight"] = w(max_pos, hidden)
+    p["bert.embeddings.token_type_embeddings.weight"] = w(type_vocab, hidden)
+    p["bert.embeddings.LayerNorm.weight"], p["bert.embeddings.LayerNorm.bias"] = o(hidden), z(hidden)
+    for i in range(layers):
+        L = "bert.encoder.layer.%d." % i
+        for n in ("query", "key", "value"):
+            p[L + "attention.self.%s.weight" % n], p[L + "attention.self.%s.bias" % n] = w(hidden, hidden), z(hidden)
+        p[L + "attention.output.dense.weight"], p[L + "attention.output.dense.bias"] = w(hidden, hidden), z(hidden)
+        p[L + "attention.output.LayerNorm.weight"], p[L + "attention.output.LayerNorm.bias"] = o(hidden), z(hidden)
+        p[L + "intermediate.dense.weight"], p[L + "intermediate.dense.bias"] = w(inter, hidden), z(inter)
+        p[L + "output.dense.weight"], p[L + "output.dense.bias"] = w(hidden, inter), z(hidden)
+        p[L + "output.LayerNorm.weight"], p[L + "output.LayerNorm.bias"] = o(hidden), z(hidden)
+    p["bert.pooler.dense.weight"], p["bert.pooler.dense.bias"] = w(hidden, hidden), z(hidden)
+    p["cls.predictions.bias"] = z(vocab_size)
+    p["cls.predictions.transform.dense.weight"], p["cls.predictions.transform.dense.bias"] = w(hidden, hidden), z(hidden)
+    p["cls.predictions.transform.LayerNorm.weight"], p["cls.predictions.transform.LayerNorm.bias"] = o(hidden), z(hidden)
+    p["vis_embed.0.weight"], p["vis_embed.0.bias"] = w(feat_dim, feat_dim), w(feat_dim)
+    p["vis_embed.2.weight"], p["vis_embed.2.bias"] = w(hidden, feat_dim), z(hidden)
+    p["vis_pe_embed.0.weight"], p["vis_pe_embed.0.bias"] = w(hidden, pe_dim), z(hidden)
+    if tasks == "vqa2":
+        p["ans_classifier.0.weight"], p["ans_classifier.0.bias"] = w(hidden * 2, hidden), z(hidden * 2)
+        p["ans_classifier.2.weight"], p["ans_classifier.2.bias"] = w(num_answers, hidden * 2), z(num_answers)
+    return p
+
+
+def loss_and_grads(p, batch, **kw):
+    """Forward + autograd backward of the summed loss (run_img2txt_dist.py:531,575).  `p` must hold
+    leaf tensors with requires_grad.  Returns (out dict, {key: grad or None})."""
+    out = forward_pretraining_loss_mask(p, batch, **kw)
+    out["loss"].sum().backward()
+    return out, {k: t.grad for k, t in p.items()}
