@@ -1,0 +1,318 @@
+/* libvlp_hip.so -- C ABI of the MI355X (gfx950) hot path of LuoweiZhou/VLP.
+ *
+ * The reference has no FFI/plugin layer: its seam is the Python class API of
+ * pytorch_pretrained_bert/modeling.py + optimization*.py, underneath which apex / cuBLAS / torch
+ * CUDA kernels run.  This header is the boundary a maintainer would bind (ctypes stub in
+ * INTEGRATION.md) to replace those third-party kernels.  Each entry point cites the reference call
+ * site(s) it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain C linkage, POD argument structs, raw DEVICE pointers, no torch types;
+ *   - all floating tensors are IEEE fp16 ("half") unless a field says f32; accumulation is fp32;
+ *   - the caller owns every buffer (the library never allocates or frees device memory); scratch is
+ *     passed in and sized by the matching *_workspace_bytes() query;
+ *   - `stream` is a hipStream_t; launches are asynchronous, no entry point synchronises the device;
+ *   - re-entrant and thread-safe (backward runs on autograd worker threads);
+ *   - return value: VLP_OK (0) or a negative vlp_status; vlp_last_error_string() returns the
+ *     thread-local message of the last failure.  Nothing throws or aborts across the ABI.
+ *   - dropout masks are a pure function of (seed, rng_stream, element index), so backward entry
+ *     points regenerate them from the same triple instead of reading a stored mask.
+ */
+#ifndef VLP_HIP_H
+#define VLP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VLP_ABI_VERSION 1
+
+typedef enum {
+    VLP_OK = 0,
+    VLP_ERR_BAD_ARG = -1,     /* shape / alignment / null pointer / unsupported configuration */
+    VLP_ERR_HIP = -2,         /* a HIP runtime call or kernel launch failed */
+    VLP_ERR_WORKSPACE = -3    /* workspace too small */
+} vlp_status;
+
+enum { VLP_ACT_NONE = 0, VLP_ACT_GELU = 1, VLP_ACT_RELU = 2, VLP_ACT_TANH = 3 };
+enum { VLP_MUL_NONE = 0, VLP_MUL_GELU_GRAD = 1, VLP_MUL_RELU_MASK = 2 };
+
+int vlp_version(void);
+const char* vlp_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Y[M,N] = epilogue( alpha * X[M,K] . W[N,K]^T )                      (fp16 in/out, fp32 accumulate)
+ * epilogue order:  + bias[n] -> (store preact) -> act -> * mul(mul_src) -> dropout -> + residual
+ * Replaces every nn.Linear forward on the path (modeling.py:270-272, 314, 341 + gelu :62-67, 354,
+ * 415, 432, 481, 1003-1005, 1016, 1027-1029) with its bias/activation/dropout/residual glue
+ * (:315-316, :355-356), and -- called with a transposed weight shadow as W -- the dgrad GEMMs of
+ * autograd's LinearBackward, with gelu'/relu' fused through mul_mode.
+ * Requirements: K % 64 == 0; ld* % 8 == 0; ldy (ldr, ldp, ldm) >= roundup8(N); 16-byte aligned bases.
+ * Columns in [N, roundup8(N)) of Y / preact are written as 0.
+ */
+typedef struct {
+    const void* X; int64_t ldx;          /* [M,K] */
+    const void* W; int64_t ldw;          /* [N,K] */
+    void* Y; int64_t ldy;                /* [M,N] */
+    const void* bias;                    /* [N] or NULL */
+    const void* residual; int64_t ldr;   /* [M,N] or NULL */
+    void* preact; int64_t ldp;           /* [M,N] or NULL: value after bias, before act (fp16) */
+    const void* mul_src; int64_t ldm;    /* [M,N] operand of mul_mode or NULL */
+    int32_t M, N, K;
+    int32_t act;                         /* VLP_ACT_* */
+    int32_t mul_mode;                    /* VLP_MUL_*: GELU_GRAD multiplies by gelu'(mul_src), RELU_MASK by (mul_src > 0) */
+    float alpha;
+    float dropout_p; uint64_t seed; uint32_t rng_stream;
+    int32_t variant;                     /* 0 = register-staged tiles, 1 = LDS-DMA (global_load_lds) */
+} vlp_gemm_nt_args;
+int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * dW[N,K] (+)= A[M,N]^T . B[M,K]          (wgrad: A = dY, B = layer input; contraction over rows M)
+ * Replaces autograd's weight-gradient GEMMs for every nn.Linear above.
+ * beta = 0 overwrites C, beta = 1 accumulates into it (gradient accumulation,
+ * run_img2txt_dist.py:566-576).  Requirements: N % 8 == 0 is NOT required (rows n >= N are skipped)
+ * but lda >= roundup8(N); K % 8 == 0; ld* % 8 == 0; 16-byte aligned bases.
+ * workspace: vlp_gemm_tn_workspace_bytes(M,N,K) bytes of scratch (fp32 split-M partial slabs).
+ */
+typedef struct {
+    const void* A; int64_t lda;          /* [M,N] */
+    const void* B; int64_t ldb;          /* [M,K] */
+    void* C; int64_t ldc;                /* [N,K] */
+    int32_t M, N, K;
+    int32_t beta;                        /* 0 or 1 */
+    void* workspace; int64_t workspace_bytes;
+    int32_t variant;                     /* 0 = ds_read_u16 fragment gathers, 1 = ds_read_b64_tr_b16 */
+    int32_t splits;                      /* 0 = choose automatically */
+} vlp_gemm_tn_args;
+int64_t vlp_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K);
+int vlp_gemm_tn(const vlp_gemm_tn_args* a, void* stream);
+
+/* out[n] (+)= sum_m A[m,n]  -- bias gradients (autograd SumBackward of the broadcast bias add). */
+typedef struct {
+    const void* A; int64_t lda; int32_t M, N;
+    void* out;                           /* [N] fp16 */
+    int32_t beta;
+    void* workspace; int64_t workspace_bytes;   /* vlp_colsum_workspace_bytes(M,N) */
+} vlp_colsum_args;
+int64_t vlp_colsum_workspace_bytes(int32_t M, int32_t N);
+int vlp_colsum(const vlp_colsum_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused masked-softmax attention.  qkv is the packed projection [B, L, 3*H] (q | k | v, head h at
+ * column h*64 of each third); mask is the byte mask [B, L, Lp] produced by vlp_mask_pack
+ * (1 = attend, 0 = masked -> additive -10000 exactly like modeling.py:807-833, 2 = padding); Lp = roundup32(L).
+ * Forward replaces modeling.py:279-302 (transpose_for_scores, QK^T/sqrt(d), +mask, softmax, dropout,
+ * PV, permute+contiguous); backward replaces the autograd of those ops.  head_dim must be 64,
+ * L <= 256.  lse [B, heads, L] f32 is the per-row log-sum-exp saved for backward.
+ */
+typedef struct {
+    const void* qkv; int64_t ld_qkv;     /* [B*L, 3H] */
+    const uint8_t* mask;                 /* [B, L, Lp] */
+    void* ctx; int64_t ld_ctx;           /* [B*L, H] out */
+    float* lse;                          /* [B, heads, L] out */
+    int32_t B, L, heads;
+    float scale;                         /* 1/sqrt(head_dim) */
+    float dropout_p; uint64_t seed; uint32_t rng_stream;
+} vlp_attn_fwd_args;
+int vlp_attn_fwd(const vlp_attn_fwd_args* a, void* stream);
+
+typedef struct {
+    const void* qkv; int64_t ld_qkv;
+    const uint8_t* mask;
+    const void* ctx; int64_t ld_ctx;     /* forward output */
+    const void* dctx; int64_t ld_dctx;   /* [B*L, H] gradient of ctx */
+    const float* lse;
+    void* dqkv; int64_t ld_dqkv;         /* [B*L, 3H] out: dq | dk | dv */
+    float* delta;                        /* [B, heads, L] f32 scratch */
+    int32_t B, L, heads;
+    float scale;
+    float dropout_p; uint64_t seed; uint32_t rng_stream;
+} vlp_attn_bwd_args;
+int vlp_attn_bwd(const vlp_attn_bwd_args* a, void* stream);
+
+/* int64 [B,L,L] 0/1 (seq2seq_loader.py:292-304) -> uint8 [B,L,Lp]: 1 attend, 0 masked, 2 for the padding
+ * columns >= L (excluded from the softmax). */
+int vlp_mask_pack(const int64_t* mask, uint8_t* out, int32_t B, int32_t L, int32_t Lp, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm, TF style (eps inside sqrt, biased variance, fp32 statistics): modeling.py:174-192 /
+ * apex FusedLayerNorm.  y = dropout( gamma * (x - mean) * rstd + beta ).  H % 8 == 0, H <= 4096.
+ */
+typedef struct {
+    const void* x; int64_t ldx;          /* [M,H] */
+    const void* gamma; const void* beta; /* [H] */
+    void* y; int64_t ldy;                /* [M,H] */
+    float* mean; float* rstd;            /* [M] out (may be NULL for inference) */
+    int32_t M, H; float eps;
+    float dropout_p; uint64_t seed; uint32_t rng_stream;
+} vlp_layernorm_fwd_args;
+int vlp_layernorm_fwd(const vlp_layernorm_fwd_args* a, void* stream);
+
+/* dx = LN'(x)·(drop(dy)); dgamma/dbeta (+)= column sums.  If dy_drop_p > 0 the incoming dy is first
+ * multiplied by the forward's output-dropout mask.  If out_drop_p > 0 a second output
+ * dx_drop = dx * mask(out_seed, out_stream) is written (the gradient that flows into the dropout
+ * that FED the pre-LN sum: modeling.py:315-316, 355-356).
+ */
+typedef struct {
+    const void* dy; int64_t lddy;
+    const void* x; int64_t ldx;
+    const void* gamma;
+    const float* mean; const float* rstd;
+    void* dx; int64_t lddx;
+    void* dx_drop; int64_t lddxd;        /* optional */
+    void* dgamma; void* dbeta;           /* [H] fp16 */
+    int32_t M, H; int32_t beta;          /* beta: accumulate into dgamma/dbeta */
+    float dy_drop_p; uint64_t dy_seed; uint32_t dy_stream;
+    float out_drop_p; uint64_t out_seed; uint32_t out_stream;
+    void* workspace; int64_t workspace_bytes;   /* vlp_layernorm_bwd_workspace_bytes(H) */
+} vlp_layernorm_bwd_args;
+int64_t vlp_layernorm_bwd_workspace_bytes(int32_t H);
+int vlp_layernorm_bwd(const vlp_layernorm_bwd_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Embedding splice (modeling.py:217-236): pre[b,l,:] = word(l) + pos(l) + type[seg[b,l]] where for
+ * l in [1, Nv] word(l) = vis_h[b,l-1] and pos(l) = vispe_h[b,l-1] (projected region features / box
+ * encodings), else word = word_emb[input_ids[b,l]], pos = pos_emb[l].  (LayerNorm + dropout :239-240
+ * are done by vlp_layernorm_fwd on `pre`.)
+ */
+typedef struct {
+    const int64_t* input_ids; const int64_t* segment_ids;   /* [B,L] */
+    const void* word_emb; const void* pos_emb; const void* type_emb;   /* [V,H] [P,H] [T,H] */
+    const void* vis_h; const void* vispe_h;                 /* [B*Nv, H] */
+    void* pre;                                              /* [B*L, H] out */
+    int32_t B, L, Nv, H, vocab, type_vocab;
+} vlp_embed_fwd_args;
+int vlp_embed_fwd(const vlp_embed_fwd_args* a, void* stream);
+
+/* Backward of the splice: scatter-adds dpre into d_word_emb rows (fp16 packed atomics), d_pos_emb,
+ * d_type_emb, and writes the region-row gradients.  d_vis_h = dpre * relu'(vis_h) * dropmask(vis),
+ * d_vispe_h = dpre * relu'(vispe_h) * dropmask(vispe) (backward of ReLU+Dropout, modeling.py:1006-1007,
+ * 1017-1018).  acc32 is f32 scratch of 64 * 8 * H floats (type-table partial sums); type_vocab <= 8.
+ */
+typedef struct {
+    const void* dpre;                                       /* [B*L, H] */
+    const int64_t* input_ids; const int64_t* segment_ids;
+    const void* vis_h; const void* vispe_h;                 /* forward outputs (post ReLU+dropout) */
+    void* d_word_emb; void* d_pos_emb; void* d_type_emb;    /* accumulated into (+=) */
+    void* d_vis_h; void* d_vispe_h;                         /* [B*Nv, H] out */
+    float* acc32;
+    int32_t B, L, Nv, H, vocab, type_vocab;
+    float drop_p; uint64_t seed; uint32_t vis_stream; uint32_t vispe_stream;
+} vlp_embed_bwd_args;
+int vlp_embed_bwd(const vlp_embed_bwd_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * small data-movement helpers
+ */
+/* dst[r, 0:cols_dst] = (beta ? dst : 0) + cast_f16(src[r, 0:cols_src]) ; columns >= cols_src are 0.
+ * src_f32 != 0 reads fp32 input (features arrive as fp32 then .half(): run_img2txt_dist.py:466-468). */
+int vlp_copy2d(const void* src, int64_t lds, int32_t src_f32, void* dst, int64_t ldd, int32_t rows,
+               int32_t cols_src, int32_t cols_dst, int32_t beta, void* stream);
+/* dst[c, r] = src[r, c] for r < rows, c < cols; dst columns in [rows, ldd) of rows c < cols_pad are 0
+ * (weight shadows W^T for the dgrad GEMMs; zero padding keeps K % 64 == 0). */
+int vlp_transpose(const void* src, int64_t lds, void* dst, int64_t ldd, int32_t rows, int32_t cols,
+                  int32_t rows_pad, void* stream);
+/* out[i,:] = src[(i / P) * L + pos[i], :]   (gather_seq_out_by_pos, modeling.py:1068-1069) */
+int vlp_gather_rows(const void* src, int64_t lds, const int64_t* pos, void* out, int64_t ldo,
+                    int32_t B, int32_t P, int32_t L, int32_t H, void* stream);
+/* dst[(i / P) * L + pos[i], :] += src[i, :]   (backward of the gather; fp16 packed atomics) */
+int vlp_scatter_add_rows(const void* src, int64_t lds, const int64_t* pos, void* dst, int64_t ldd,
+                         int32_t B, int32_t P, int32_t L, int32_t H, void* stream);
+/* VQA fusion (modeling.py:1044,1138): out[b,:] = h[b,0,:] * h[b,Nv+1,:]; backward adds into dh rows. */
+int vlp_vqa_mul_fwd(const void* h, void* out, int32_t B, int32_t L, int32_t Nv, int32_t H, void* stream);
+int vlp_vqa_mul_bwd(const void* h, const void* dout, void* dh, int32_t B, int32_t L, int32_t Nv, int32_t H, void* stream);
+/* dz = dy * dropmask * (y > 0): backward of Linear->ReLU->Dropout given the layer OUTPUT y */
+int vlp_relu_dropout_bwd(const void* dy, const void* y, void* dz, int64_t n, int64_t ncols, float drop_p,
+                         uint64_t seed, uint32_t rng_stream, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Losses
+ * Masked-LM loss (modeling.py:1083-1111): per-row CE in fp32 over V logits, * masked_weights,
+ * per-sample sum, keep the int(B*(1-ratio)) smallest samples, / (sum of kept weights + 1e-5), sum.
+ * vlp_mlm_loss_fwd writes loss[0] (f32), per-row lse [B*P] and the per-row gradient coefficient
+ * coef[B*P] = keep * weight / denominator; vlp_mlm_loss_bwd writes
+ * dlogits[r, v] = grad_scale * coef[r] * (softmax(logits[r])[v] - [v == label[r]]) for v < V and 0 for
+ * V <= v < ld_dlogits.
+ */
+typedef struct {
+    const void* logits; int64_t ld_logits;    /* [B*P, V] fp16 */
+    const int64_t* labels;                    /* [B*P] */
+    const int64_t* weights;                   /* [B*P] masked_weights */
+    float* loss;                              /* [1] out */
+    float* lse; float* coef;                  /* [B*P] out */
+    float* row_loss;                          /* [B*P] scratch */
+    int32_t B, P, V;
+    float drop_worst_ratio;
+} vlp_mlm_loss_fwd_args;
+int vlp_mlm_loss_fwd(const vlp_mlm_loss_fwd_args* a, void* stream);
+typedef struct {
+    const void* logits; int64_t ld_logits;
+    const int64_t* labels;
+    const float* lse; const float* coef;
+    const float* grad_scale;                  /* [1] device scalar (upstream gradient x loss scale) */
+    void* dlogits; int64_t ld_dlogits;        /* [B*P, ld] fp16 out */
+    int32_t rows, V;
+} vlp_mlm_loss_bwd_args;
+int vlp_mlm_loss_bwd(const vlp_mlm_loss_bwd_args* a, void* stream);
+
+/* VQA loss (modeling.py:1030,1140): BCEWithLogits(mean) * num_answers. fwd -> loss[0] (loss must hold
+ * 257 floats: loss[1..257) is scratch);
+ * bwd -> dlogits = grad_scale * (sigmoid(x) - y) / B, zero for columns >= N. */
+int vlp_bce_loss_fwd(const void* logits, int64_t ld, const void* labels_f32, int64_t ldl, int32_t B, int32_t N,
+                     float* loss, void* stream);
+int vlp_bce_loss_bwd(const void* logits, int64_t ld, const void* labels_f32, int64_t ldl, int32_t B, int32_t N,
+                     const float* grad_scale, void* dlogits, int64_t ldd, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizers
+ * vlp_sumsq: out[0] = sum(g^2) in f32, out[1] = 1.0 if any element is inf/nan else 0 (the overflow
+ * check + grad norm of apex FP16_Optimizer._compute_grad_norm).  partial = f32 scratch [2048].
+ */
+int vlp_sumsq(const void* g_f16, int64_t n, float* out2, float* partial, void* stream);
+
+/* apex fused_adam_cuda.adam as called by FusedAdam.step (run_img2txt_dist.py:411-420):
+ *   g = g16 / (*combined_scale); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ *   denom = eps_inside_sqrt ? sqrt(v + eps) : sqrt(v) + eps;
+ *   p32 -= step_size * (m / denom + decay * p32); p16 = half(p32)
+ * hyper points to 3 device floats {combined_scale, step_size, skip}; when skip != 0 (overflow) the
+ * kernel leaves all state untouched -- so the loss-scale logic never forces a host sync.
+ */
+typedef struct {
+    float* p32; float* m; float* v;      /* master weights and moments [n] */
+    const void* g16;                     /* [n] fp16 gradients (still multiplied by the loss scale) */
+    void* p16;                           /* [n] fp16 model weights out */
+    int64_t n;
+    float b1, b2, eps, decay;
+    int32_t eps_inside_sqrt;
+    const float* hyper;                  /* device {combined_scale, step_size, skip} */
+} vlp_fused_adam_args;
+int vlp_fused_adam(const vlp_fused_adam_args* a, void* stream);
+/* device-side scalar logic of FP16_Optimizer.step + FusedAdam.step for one param group:
+ *   norm = sqrt(sumsq[0]); overflow = sumsq[1] (or any_overflow[0]);
+ *   clip = (norm/scale + 1e-6)/max_grad_norm; combined = scale * max(clip, 1); hyper = {combined, lr, overflow} */
+int vlp_adam_hyper(const float* sumsq2, const float* any_overflow, float loss_scale, float max_grad_norm,
+                   float step_size, float* hyper3, void* stream);
+
+/* BertAdam (optimization.py:112-182) over a flat fp32 master buffer made of `ntensors` tensors:
+ * per-tensor L2 clip to max_grad_norm (:146-147), no bias correction, decoupled decay, lr already
+ * scheduled by the host (warmup_linear :45-48).  seg_off[ntensors+1] (int64, device) are the tensor
+ * boundaries inside the flat buffers, norms is f32 scratch [ntensors].  g may be fp16 or fp32.
+ */
+typedef struct {
+    float* p32; float* m; float* v;
+    const void* g; int32_t g_is_f32;
+    void* p16;                           /* optional fp16 copy out (NULL for pure-fp32 use) */
+    const int64_t* seg_off; int32_t ntensors; int64_t n;
+    float* norms;
+    float lr, b1, b2, eps, decay, max_grad_norm;
+    float grad_scale;                    /* gradients are divided by this (loss scale), 1 for fp32 */
+} vlp_bert_adam_args;
+int vlp_bert_adam(const vlp_bert_adam_args* a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLP_HIP_H */

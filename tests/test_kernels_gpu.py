@@ -1,0 +1,492 @@
+"""GPU parity tests of every HIP kernel, called THROUGH THE C ABI (vlp_amd._lib -> libvlp_hip.so), against
+fp32/fp64 torch restatements of the same op (the path is floating point; tolerances are written next to
+each check).  Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+from vlp_amd import _lib as K          # noqa: E402
+from oracle import vlp_oracle as O      # noqa: E402   (checker only)
+
+DEV = torch.device("cuda:0")
+M32 = 0xFFFFFFFF
+
+
+# ---- python mirror of csrc/common.h's dropout hash (uint32 arithmetic on int64 tensors) -----------------
+def _mix32(x):
+    x = x & M32
+    x = x ^ (x >> 16); x = (x * 0x7feb352d) & M32
+    x = x ^ (x >> 15); x = (x * 0x846ca68b) & M32
+    x = x ^ (x >> 16)
+    return x
+
+
+def _mul64(a, b):
+    return (a * b) & 0xFFFFFFFFFFFFFFFF
+
+
+def drop_mult_ref(p, seed, stream, rows, cols, device=DEV):
+    """[len(rows), len(cols)] multiplier tensor (0 or 1/(1-p)) for elements (row, col)."""
+    if p <= 0:
+        return torch.ones(len(rows), len(cols), device=device)
+    s = (_mul64(seed, 0x9E3779B97F4A7C15) + _mul64(stream, 0xD1B54A32D192ED03) + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF
+    k0, k1 = s & M32, ((s >> 32) & M32) | 1
+    t = p * 4294967296.0
+    thresh = 0xFFFFFFFF if t >= 4294967295.0 else int(t)
+    rows = torch.as_tensor(rows, dtype=torch.int64, device=device)
+    cols = torch.as_tensor(cols, dtype=torch.int64, device=device)
+    rk = (_mix32((rows & M32) ^ k0) + _mix32(((rows >> 32) & M32) + k1)) & M32
+    h = _mix32((rk[:, None] + (cols[None, :] * 0x9E3779B9 & M32)) & M32)
+    return torch.where(h < thresh, torch.zeros((), device=device), torch.full((), 1.0 / (1.0 - p), device=device))
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+def h16(*shape, scale=1.0, gen=None):
+    return (torch.randn(*shape, device=DEV, generator=gen) * scale).half()
+
+
+@pytest.fixture
+def gen():
+    g = torch.Generator(device=DEV)
+    g.manual_seed(1234)
+    return g
+
+
+# =====================================================================================================
+# NT GEMM
+# =====================================================================================================
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (1000, 768, 768), (77, 1000, 192), (256, 2304, 768)])
+def test_gemm_nt_plain(variant, M, N, K, gen):
+    Kd = K
+    from vlp_amd import _lib as K   # the parametrize name shadows the module alias inside this test
+    x, w = h16(M, Kd, gen=gen), h16(N, Kd, scale=0.05, gen=gen)
+    ldy = (N + 7) // 8 * 8
+    y = torch.full((M, ldy), 7.0, device=DEV, dtype=torch.half)
+    K.gemm_nt(x, w, y, M, N, Kd, variant=variant)
+    ref = x.float() @ w.float().t()
+    # fp32 accumulate, one fp16 rounding of the result: 2^-11 relative + accumulation-order noise
+    assert rel(y[:, :N].float(), ref) < 1.5e-3, "variant %d" % variant
+    if ldy > N:
+        assert float(y[:, N:].abs().max()) == 0.0        # padding columns are written as zero
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_gemm_nt_asymmetric_identity(variant):
+    """A = I against an asymmetric B catches swapped row/col in the MFMA C-layout handling."""
+    M = N = Kd = 128
+    x = torch.eye(M, Kd, device=DEV).half()
+    w = (torch.arange(N, device=DEV)[:, None] * 0.01 + torch.arange(Kd, device=DEV)[None, :] * 1.0).half()
+    y = torch.zeros(M, N, device=DEV, dtype=torch.half)
+    K.gemm_nt(x, w, y, M, N, Kd, variant=variant)
+    assert torch.equal(y, w.t().contiguous())
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_gemm_nt_epilogues(variant, gen):
+    M, N, Kd = 200, 384, 256
+    x, w = h16(M, Kd, gen=gen), h16(N, Kd, scale=0.06, gen=gen)
+    bias, res = h16(N, gen=gen), h16(M, N, gen=gen)
+    lin = x.float() @ w.float().t() + bias.float()
+    # bias + gelu (+ pre-activation output)
+    y = torch.empty(M, N, device=DEV, dtype=torch.half)
+    z = torch.empty(M, N, device=DEV, dtype=torch.half)
+    K.gemm_nt(x, w, y, M, N, Kd, bias=bias, preact=z, act=K.ACT_GELU, variant=variant)
+    assert rel(z.float(), lin) < 1.5e-3
+    assert rel(y.float(), O.gelu(z.float())) < 1.5e-3          # gelu is applied to the fp16-rounded pre-activation
+    # relu, tanh
+    K.gemm_nt(x, w, y, M, N, Kd, bias=bias, act=K.ACT_RELU, variant=variant)
+    assert rel(y.float(), torch.relu(lin)) < 1.5e-3
+    K.gemm_nt(x, w, y, M, N, Kd, bias=bias, act=K.ACT_TANH, variant=variant)
+    assert rel(y.float(), torch.tanh(lin)) < 1.5e-3
+    # bias + residual, alpha
+    K.gemm_nt(x, w, y, M, N, Kd, bias=bias, residual=res, alpha=0.5, variant=variant)
+    assert rel(y.float(), 0.5 * (x.float() @ w.float().t()) + bias.float() + res.float()) < 1.5e-3
+    # multiplier epilogues (dgrad through gelu / relu)
+    src = h16(M, N, gen=gen)
+    K.gemm_nt(x, w, y, M, N, Kd, mul_src=src, mul_mode=K.MUL_GELU_GRAD, variant=variant)
+    s32 = src.float().requires_grad_(True)
+    O.gelu(s32).sum().backward()
+    assert rel(y.float(), (x.float() @ w.float().t()) * s32.grad) < 2e-3
+    K.gemm_nt(x, w, y, M, N, Kd, mul_src=src, mul_mode=K.MUL_RELU_MASK, variant=variant)
+    assert rel(y.float(), (x.float() @ w.float().t()) * (src.float() > 0)) < 1.5e-3
+    # dropout + residual: exact mask from the python mirror of the hash; element = (row m, col n)
+    p, seed, stream = 0.3, 99, 5
+    K.gemm_nt(x, w, y, M, N, Kd, bias=bias, residual=res, dropout_p=p, seed=seed, rng_stream=stream, variant=variant)
+    mult = drop_mult_ref(p, seed, stream, range(M), range(N))
+    assert rel(y.float(), lin * mult + res.float()) < 1.5e-3
+    frac = float((mult == 0).float().mean())
+    assert abs(frac - p) < 0.01
+
+
+def test_gemm_nt_rejects_bad_args():
+    x = torch.zeros(8, 100, device=DEV, dtype=torch.half)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        K.gemm_nt(x, x, x, 8, 8, 100)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        K.gemm_nt(x.cpu(), x, x, 8, 8, 64)
+
+
+# =====================================================================================================
+# TN GEMM (wgrad), colsum
+# =====================================================================================================
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("M,N,K,splits", [(64, 128, 128, 1), (1000, 256, 384, 1), (1000, 256, 384, 4), (192, 1000, 768, 1),
+                                          (2000, 768, 768, 0), (333, 72, 64, 2)])
+def test_gemm_tn(variant, M, N, K, splits, gen):
+    Kd = K
+    from vlp_amd import _lib as K
+    a, b = h16(M, (N + 7) // 8 * 8, scale=0.3, gen=gen), h16(M, Kd, scale=0.3, gen=gen)
+    c = h16(N, Kd, gen=gen)
+    ws = torch.empty(K_ws(M, N, Kd), device=DEV, dtype=torch.uint8)
+    ref = a[:, :N].float().t() @ b.float()
+    K.gemm_tn(a, b, c, M, N, Kd, beta=0, workspace=ws, variant=variant, splits=splits)
+    assert rel(c.float(), ref) < 1.5e-3, "variant %d" % variant
+    K.gemm_tn(a, b, c, M, N, Kd, beta=1, workspace=ws, variant=variant, splits=splits)
+    assert rel(c.float(), 2 * ref) < 2.5e-3
+
+
+def K_ws(M, N, Kd):
+    return K.gemm_tn_workspace_bytes(M, N, Kd)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_gemm_tn_asymmetric(variant):
+    """dY = I-like selector against an asymmetric X: dW[n,k] must equal X[n,k] for n < M."""
+    M, N, Kd = 128, 128, 128
+    a = torch.eye(M, N, device=DEV).half()
+    b = (torch.arange(M, device=DEV)[:, None] * 1.0 + torch.arange(Kd, device=DEV)[None, :] * 0.01).half()
+    c = torch.zeros(N, Kd, device=DEV, dtype=torch.half)
+    ws = torch.empty(K_ws(M, N, Kd), device=DEV, dtype=torch.uint8)
+    K.gemm_tn(a, b, c, M, N, Kd, workspace=ws, variant=variant, splits=1)
+    assert torch.equal(c, b)
+
+
+@pytest.mark.parametrize("M,N", [(10, 64), (1000, 768), (4097, 1000), (192, 28996)])
+def test_colsum(M, N, gen):
+    lda = (N + 7) // 8 * 8
+    a = h16(M, lda, gen=gen)
+    out = h16(N, gen=gen)
+    out0 = out.clone()
+    ws = torch.empty(K.colsum_workspace_bytes(M, N), device=DEV, dtype=torch.uint8)
+    K.colsum(a, out, M, N, beta=0, workspace=ws)
+    ref = a[:, :N].float().sum(0)
+    assert float((out.float() - ref).abs().max()) < 1e-3 * float(ref.abs().max()) + 1e-2
+    K.colsum(a, out0, M, N, beta=1, workspace=ws)
+    assert float((out0.float() - (ref + out0.float() * 0)).abs().max()) >= 0   # smoke: beta path runs
+
+
+# =====================================================================================================
+# attention
+# =====================================================================================================
+def _mask(B, L, Nv, gen_cpu):
+    from vlp_amd import synthetic as S
+    m = torch.zeros(B, L, L, dtype=torch.long)
+    for b in range(B):
+        n_b = int(torch.randint(1, L - Nv - 2, (1,), generator=gen_cpu))
+        m[b] = S.build_attention_mask(L, Nv, n_b, "s2s" if b % 2 == 0 else "bi")
+    return m
+
+
+def _attn_ref(qkv, mask, B, L, heads, mult=None):
+    H = heads * 64
+    x = qkv.double().view(B, L, 3, heads, 64)
+    q, k, v = (x[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    s = q @ k.transpose(-1, -2) / 8.0 + (1.0 - mask.double().to(qkv.device))[:, None] * -10000.0
+    p = torch.softmax(s, -1)
+    pd = p if mult is None else p * mult
+    return (pd @ v).permute(0, 2, 1, 3).reshape(B * L, H), p
+
+
+@pytest.mark.parametrize("B,L,Nv,heads", [(2, 43, 8, 2), (3, 123, 100, 12), (2, 167, 100, 12), (1, 256, 100, 4), (2, 64, 20, 1)])
+def test_attention_fwd_bwd(B, L, Nv, heads, gen):
+    gc = torch.Generator().manual_seed(5)
+    H = heads * 64
+    qkv = h16(B * L, 3 * H, scale=1.0, gen=gen)
+    mask = _mask(B, L, Nv, gc).to(DEV)
+    Lp = (L + 31) // 32 * 32
+    mb = torch.empty(B, L, Lp, device=DEV, dtype=torch.uint8)
+    K.mask_pack(mask, mb, B, L, Lp)
+    assert torch.equal(mb[:, :, :L].long(), mask) and (Lp == L or int(mb[:, :, L:].min()) == 2)
+    ctx = torch.zeros(B * L, H, device=DEV, dtype=torch.half)
+    lse = torch.zeros(B, heads, L, device=DEV)
+    K.attn_fwd(qkv, mb, ctx, lse, B, L, heads, 0.125)
+    q64 = qkv.double().requires_grad_(True)
+    ref, p = _attn_ref(q64, mask, B, L, heads)
+    # P and O are rounded to fp16 once each: ~1e-3 relative to max|O|
+    assert rel(ctx.float(), ref) < 2e-3
+    x = qkv.double().view(B, L, 3, heads, 64)
+    s = (x[:, :, 0].permute(0, 2, 1, 3) @ x[:, :, 1].permute(0, 2, 3, 1)) / 8.0 + (1.0 - mask.double())[:, None] * -10000.0
+    assert float((lse.double() - torch.logsumexp(s, -1)).abs().max()) < 1e-3
+    # backward
+    dctx = h16(B * L, H, gen=gen)
+    dqkv = torch.zeros(B * L, 3 * H, device=DEV, dtype=torch.half)
+    delta = torch.zeros(B, heads, L, device=DEV)
+    K.attn_bwd(qkv, mb, ctx, dctx, lse, dqkv, delta, B, L, heads, 0.125)
+    ref.backward(dctx.double())
+    g = q64.grad
+    for i, name in enumerate(("dq", "dk", "dv")):
+        a = dqkv.view(B * L, 3, H)[:, i].float()
+        r = g.view(B * L, 3, H)[:, i]
+        assert rel(a, r) < 4e-3, name
+
+
+def test_attention_dropout_exact_mask(gen):
+    B, L, Nv, heads, p, seed, stream = 2, 123, 100, 3, 0.25, 7, 11
+    H = heads * 64
+    gc = torch.Generator().manual_seed(6)
+    qkv = h16(B * L, 3 * H, gen=gen)
+    mask = _mask(B, L, Nv, gc).to(DEV)
+    Lp = (L + 31) // 32 * 32
+    mb = torch.empty(B, L, Lp, device=DEV, dtype=torch.uint8)
+    K.mask_pack(mask, mb, B, L, Lp)
+    ctx = torch.zeros(B * L, H, device=DEV, dtype=torch.half)
+    lse = torch.zeros(B, heads, L, device=DEV)
+    K.attn_fwd(qkv, mb, ctx, lse, B, L, heads, 0.125, dropout_p=p, seed=seed, rng_stream=stream)
+    # element = (row (b*heads + h)*L + q, col key)
+    mult = drop_mult_ref(p, seed, stream, range(B * heads * L), range(L)).view(B, heads, L, L).double()
+    q64 = qkv.double().requires_grad_(True)
+    ref, _ = _attn_ref(q64, mask, B, L, heads, mult)
+    assert rel(ctx.float(), ref) < 2e-3
+    dctx = h16(B * L, H, gen=gen)
+    dqkv = torch.zeros(B * L, 3 * H, device=DEV, dtype=torch.half)
+    delta = torch.zeros(B, heads, L, device=DEV)
+    K.attn_bwd(qkv, mb, ctx, dctx, lse, dqkv, delta, B, L, heads, 0.125, dropout_p=p, seed=seed, rng_stream=stream)
+    ref.backward(dctx.double())
+    assert rel(dqkv.float(), q64.grad) < 5e-3
+
+
+# =====================================================================================================
+# layernorm
+# =====================================================================================================
+@pytest.mark.parametrize("M,H", [(5, 768), (1000, 768), (300, 2048), (64, 64)])
+def test_layernorm_fwd_bwd(M, H, gen):
+    x, gamma, beta = h16(M, H, scale=2.0, gen=gen), (1 + 0.1 * torch.randn(H, device=DEV, generator=gen)).half(), h16(H, scale=0.1, gen=gen)
+    y = torch.empty_like(x)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    K.layernorm_fwd(x, gamma, beta, y, M, H, mean, rstd)
+    x64 = x.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = O.layer_norm(x64, g64, b64)
+    assert rel(y.float(), ref) < 1.5e-3
+    dy = h16(M, H, gen=gen)
+    dx, dg, db = torch.empty_like(x), torch.zeros(H, device=DEV, dtype=torch.half), torch.zeros(H, device=DEV, dtype=torch.half)
+    ws = torch.empty(K.layernorm_bwd_workspace_bytes(H), device=DEV, dtype=torch.uint8)
+    K.layernorm_bwd(dy, x, gamma, mean, rstd, dx, dg, db, M, H, ws)
+    ref.backward(dy.double())
+    assert rel(dx.float(), x64.grad) < 2e-3
+    assert rel(dg.float(), g64.grad) < 3e-3 and rel(db.float(), b64.grad) < 3e-3
+    K.layernorm_bwd(dy, x, gamma, mean, rstd, dx, dg, db, M, H, ws, beta=1)
+    assert rel(dg.float(), 2 * g64.grad) < 4e-3
+
+
+def test_layernorm_dropout_paths(gen):
+    M, H, p = 257, 768, 0.2
+    x, gamma, beta = h16(M, H, gen=gen), torch.ones(H, device=DEV).half(), torch.zeros(H, device=DEV).half()
+    y = torch.empty_like(x)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    K.layernorm_fwd(x, gamma, beta, y, M, H, mean, rstd, dropout_p=p, seed=3, rng_stream=9)
+    mult = drop_mult_ref(p, 3, 9, range(M), range(H))
+    ref = O.layer_norm(x.float(), gamma.float(), beta.float())
+    assert rel(y.float(), ref * mult) < 1.5e-3
+    # backward: incoming dy passes through the same mask; second output = dx * (another mask)
+    dy = h16(M, H, gen=gen)
+    dx, dxd = torch.empty_like(x), torch.empty_like(x)
+    dg, db = torch.zeros(H, device=DEV, dtype=torch.half), torch.zeros(H, device=DEV, dtype=torch.half)
+    ws = torch.empty(K.layernorm_bwd_workspace_bytes(H), device=DEV, dtype=torch.uint8)
+    K.layernorm_bwd(dy, x, gamma, mean, rstd, dx, dg, db, M, H, ws, dx_drop=dxd, dy_drop=(p, 3, 9), out_drop=(0.1, 4, 2))
+    x64 = x.double().requires_grad_(True)
+    (O.layer_norm(x64, gamma.double(), beta.double()) * mult.double()).backward(dy.double())
+    assert rel(dx.float(), x64.grad) < 2e-3
+    assert rel(dxd.float(), x64.grad * drop_mult_ref(0.1, 4, 2, range(M), range(H))) < 2e-3
+
+
+# =====================================================================================================
+# embeddings / data movement
+# =====================================================================================================
+def test_embed_fwd_bwd(gen):
+    B, L, Nv, H, V, T, P = 3, 43, 8, 768, 500, 6, 64
+    ids = torch.randint(0, V, (B, L), device=DEV, generator=gen)
+    ids[0, -3:] = 0
+    seg = torch.randint(0, T, (B, L), device=DEV, generator=gen)
+    word, pos, typ = h16(V, H, gen=gen), h16(P, H, gen=gen), h16(T, H, gen=gen)
+    vis, vpe = torch.relu(h16(B * Nv, H, gen=gen)), torch.relu(h16(B * Nv, H, gen=gen))
+    pre = torch.empty(B * L, H, device=DEV, dtype=torch.half)
+    K.embed_fwd(ids, seg, word, pos, typ, vis, vpe, pre, B, L, Nv, H)
+    p = {"bert.embeddings.word_embeddings.weight": word.double().requires_grad_(True),
+         "bert.embeddings.position_embeddings.weight": pos.double().requires_grad_(True),
+         "bert.embeddings.token_type_embeddings.weight": typ.double().requires_grad_(True),
+         "bert.embeddings.LayerNorm.weight": torch.ones(H, device=DEV).double(), "bert.embeddings.LayerNorm.bias": torch.zeros(H, device=DEV).double()}
+    v64, vp64 = vis.double().view(B, Nv, H).requires_grad_(True), vpe.double().view(B, Nv, H).requires_grad_(True)
+    # the oracle's arange for position ids lives on the CPU: build it on the device here
+    _, ref_pre = O.embeddings(p, v64, vp64, ids, seg, Nv, position_ids=torch.arange(L, device=DEV).unsqueeze(0).expand(B, L))
+    assert rel(pre.float(), ref_pre.reshape(B * L, H)) < 1e-3
+    dpre = h16(B * L, H, gen=gen)
+    dpre.view(B, L, H)[0, -3:] = 0      # padding rows carry exactly zero gradient
+    dw, dp_, dt = torch.zeros_like(word), torch.zeros_like(pos), torch.zeros_like(typ)
+    dv, dvp = torch.empty_like(vis), torch.empty_like(vpe)
+    acc = torch.empty(64 * 8 * H, device=DEV)
+    K.embed_bwd(dpre, ids, seg, vis, vpe, dw, dp_, dt, dv, dvp, acc, B, L, Nv, H, V, T)
+    ref_pre.backward(dpre.double().view(B, L, H))
+    assert rel(dw.float(), p["bert.embeddings.word_embeddings.weight"].grad) < 3e-3
+    assert rel(dp_.float(), p["bert.embeddings.position_embeddings.weight"].grad) < 3e-3
+    assert rel(dt.float(), p["bert.embeddings.token_type_embeddings.weight"].grad) < 3e-3
+    # region rows: gradient gated by (y > 0) (ReLU'; no dropout here)
+    assert rel(dv.float(), (v64.grad * (v64 > 0)).reshape(B * Nv, H)) < 1e-3
+    assert rel(dvp.float(), (vp64.grad * (vp64 > 0)).reshape(B * Nv, H)) < 1e-3
+
+
+def test_copy2d_transpose_gather_scatter(gen):
+    src = torch.randn(50, 1607, device=DEV, generator=gen)
+    dst = torch.full((50, 1664), 9.0, device=DEV, dtype=torch.half)
+    K.copy2d(src, 1607, True, dst, 1664, 50, 1607, 1664)
+    assert torch.equal(dst[:, :1607], src.half()) and float(dst[:, 1607:].abs().max()) == 0
+    s16 = src.half()
+    K.copy2d(s16, 1607, False, dst, 1664, 50, 1607, 1664, beta=1)
+    assert rel(dst[:, :1607].float(), 2 * src) < 1e-3
+    w = h16(300, 200, gen=gen)
+    wt = torch.full((200, 320), 5.0, device=DEV, dtype=torch.half)
+    K.transpose(w, 200, wt, 320, 300, 200, 320)
+    assert torch.equal(wt[:, :300], w.t()) and float(wt[:, 300:].abs().max()) == 0
+    B, P, L, H = 4, 3, 20, 64
+    h = h16(B * L, H, gen=gen)
+    pos = torch.randint(0, L, (B, P), device=DEV, generator=gen)
+    out = torch.empty(B * P, H, device=DEV, dtype=torch.half)
+    K.gather_rows(h, H, pos, out, H, B, P, L, H)
+    ref = torch.gather(h.view(B, L, H), 1, pos.unsqueeze(2).expand(-1, -1, H)).reshape(B * P, H)
+    assert torch.equal(out, ref)
+    dh = torch.zeros(B * L, H, device=DEV, dtype=torch.half)
+    K.scatter_add_rows(out, H, pos, dh, H, B, P, L, H)
+    ref_d = torch.zeros(B, L, H, device=DEV).scatter_add_(1, pos.unsqueeze(2).expand(-1, -1, H), out.view(B, P, H).float())
+    assert rel(dh.float(), ref_d.view(B * L, H)) < 2e-3
+
+
+def test_vqa_mul_and_relu_dropout_bwd(gen):
+    B, L, Nv, H = 5, 30, 10, 768
+    h = h16(B * L, H, gen=gen)
+    out = torch.empty(B, H, device=DEV, dtype=torch.half)
+    K.vqa_mul_fwd(h, out, B, L, Nv, H)
+    hv = h.view(B, L, H).float()
+    assert rel(out.float(), hv[:, 0] * hv[:, Nv + 1]) < 1e-3
+    dout = h16(B, H, gen=gen)
+    dh = torch.zeros(B * L, H, device=DEV, dtype=torch.half)
+    K.vqa_mul_bwd(h, dout, dh, B, L, Nv, H)
+    d = dh.view(B, L, H).float()
+    assert rel(d[:, 0], dout.float() * hv[:, Nv + 1]) < 1e-3 and rel(d[:, Nv + 1], dout.float() * hv[:, 0]) < 1e-3
+    assert float(d[:, 1:Nv + 1].abs().max()) == 0
+    y, dy = torch.relu(h16(40, 768, gen=gen)), h16(40, 768, gen=gen)
+    dz = torch.empty_like(y)
+    K.relu_dropout_bwd(dy, y, dz, y.numel(), 768, drop_p=0.3, seed=1, rng_stream=2)
+    ref = dy.float() * (y > 0) * drop_mult_ref(0.3, 1, 2, range(40), range(768))
+    assert rel(dz.float(), ref) < 1e-3
+
+
+# =====================================================================================================
+# losses
+# =====================================================================================================
+@pytest.mark.parametrize("ratio", [0.0, 0.3])
+def test_mlm_loss(ratio, gen):
+    B, P, V = 16, 3, 28996
+    ld = (V + 63) // 64 * 64
+    logits = torch.zeros(B * P, ld, device=DEV, dtype=torch.half)
+    logits[:, :V] = h16(B * P, V, scale=2.0, gen=gen)
+    labels = torch.randint(0, V, (B, P), device=DEV, generator=gen)
+    weights = (torch.rand(B, P, device=DEV, generator=gen) < 0.7).long()
+    weights[:, 0] = 1
+    loss, lse, coef, row = torch.zeros(1, device=DEV), torch.zeros(B * P, device=DEV), torch.zeros(B * P, device=DEV), torch.zeros(B * P, device=DEV)
+    K.mlm_loss_fwd(logits, ld, labels, weights, loss, lse, coef, row, B, P, V, drop_worst_ratio=ratio)
+    x = logits[:, :V].float().view(B, P, V).requires_grad_(True)
+    ce = torch.nn.functional.cross_entropy(x.transpose(1, 2), labels, reduction="none")
+    ref = O.loss_mask_and_normalize(ce, weights, ratio)
+    assert abs(float(loss) - float(ref)) < 1e-4 * abs(float(ref))
+    gs = torch.full((1,), 128.0, device=DEV)
+    dl = torch.full((B * P, ld), 3.0, device=DEV, dtype=torch.half)
+    K.mlm_loss_bwd(logits, ld, labels, lse, coef, gs, dl, ld, B * P, V)
+    (ref * 128.0).backward()
+    assert rel(dl[:, :V].float(), x.grad.view(B * P, V)) < 2e-3
+    assert float(dl[:, V:].abs().max()) == 0
+
+
+def test_bce_loss(gen):
+    B, N, ld = 7, 3129, 3136
+    logits = torch.zeros(B, ld, device=DEV, dtype=torch.half)
+    logits[:, :N] = h16(B, N, scale=3.0, gen=gen)
+    y = torch.rand(B, N, device=DEV, generator=gen)
+    loss = torch.zeros(257, device=DEV)
+    K.bce_loss_fwd(logits, ld, y, N, B, N, loss)
+    x = logits[:, :N].float().requires_grad_(True)
+    ref = torch.nn.functional.binary_cross_entropy_with_logits(x, y) * N
+    assert abs(float(loss[0]) - float(ref)) < 1e-4 * abs(float(ref))
+    gs = torch.full((1,), 64.0, device=DEV)
+    d = torch.full((B, ld), 2.0, device=DEV, dtype=torch.half)
+    K.bce_loss_bwd(logits, ld, y, N, B, N, gs, d, ld)
+    (ref * 64.0).backward()
+    assert rel(d[:, :N].float(), x.grad) < 2e-3 and float(d[:, N:].abs().max()) == 0
+
+
+# =====================================================================================================
+# optimizers
+# =====================================================================================================
+def test_fused_adam_and_norm(gen):
+    n = 8 * 12345
+    p32 = torch.randn(n, device=DEV, generator=gen) * 0.02
+    g16 = (torch.randn(n, device=DEV, generator=gen) * 300).half()      # "scaled" gradients
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    p16 = torch.empty(n, device=DEV, dtype=torch.half)
+    out2, part, hyper = torch.zeros(2, device=DEV), torch.zeros(2048, device=DEV), torch.zeros(3, device=DEV)
+    scale = 1024.0
+    rp, rm, rv = p32.cpu().clone(), m.cpu().clone(), v.cpu().clone()
+    for step in range(2):
+        K.sumsq(g16, n, out2, part)
+        K.adam_hyper(out2, None, scale, 1.0, 3e-5, hyper)
+        K.fused_adam(p32, m, v, g16, p16, n, hyper, decay=0.01)
+        norm = float(g16.float().norm())
+        assert abs(math.sqrt(float(out2[0])) - norm) < 1e-4 * norm and float(out2[1]) == 0
+        O.fused_adam_step(rp, g16.cpu(), rm, rv, lr=3e-5, grad_norm_scaled=norm, scale=scale, weight_decay=0.01)
+    assert rel(p32.cpu(), rp) < 1e-5 and rel(m.cpu(), rm) < 1e-4 and rel(v.cpu(), rv) < 1e-4
+    assert torch.equal(p16.cpu(), p32.cpu().half())
+    # overflow: state must stay untouched and the flag must be raised
+    g_bad = g16.clone()
+    g_bad[777] = float("inf")
+    before = p32.clone()
+    K.sumsq(g_bad, n, out2, part)
+    K.adam_hyper(out2, None, scale, 1.0, 3e-5, hyper)
+    K.fused_adam(p32, m, v, g_bad, p16, n, hyper)
+    assert float(out2[1]) == 1.0 and float(hyper[2]) == 1.0 and torch.equal(before, p32)
+
+
+@pytest.mark.parametrize("g_is_f32", [True, False])
+def test_bert_adam(g_is_f32, gen):
+    sizes = [768 * 64, 768, 3072, 5000, 8, 28996]
+    offs = [0]
+    for s in sizes:
+        offs.append(offs[-1] + s)
+    n = offs[-1]
+    seg = torch.tensor(offs, device=DEV, dtype=torch.int64)
+    p32 = torch.randn(n, device=DEV, generator=gen) * 0.02
+    g = torch.randn(n, device=DEV, generator=gen) * 0.05
+    g[offs[1]:offs[2]] *= 100          # one tensor far above the clip threshold
+    gk = g if g_is_f32 else g.half()
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    norms = torch.zeros(len(sizes), device=DEV)
+    p16 = torch.empty(n, device=DEV, dtype=torch.half)
+    rp = p32.cpu().clone()
+    rm, rv = torch.zeros(n), torch.zeros(n)
+    for step in range(2):
+        lr = 1e-3 * O.warmup_linear((step + 1) / 20, 0.1)
+        K.bert_adam(p32, m, v, gk, g_is_f32, p16, seg, len(sizes), n, norms, lr=lr, decay=0.01)
+        for i in range(len(sizes)):
+            sl = slice(offs[i], offs[i + 1])
+            O.bert_adam_step(rp[sl], gk.float().cpu()[sl], rm[sl], rv[sl], 0, lr=lr, weight_decay=0.01)
+    assert rel(p32.cpu(), rp) < 1e-5 and rel(m.cpu(), rm) < 1e-4
+    assert torch.equal(p16.cpu(), p32.cpu().half())

@@ -1,0 +1,349 @@
+"""ctypes binding of libvlp_hip.so (include/vlp_hip.h).
+
+The structures below mirror the header field for field.  Every wrapper takes torch tensors only to
+extract raw device pointers (`data_ptr()`) and the current HIP stream; the library itself has no
+torch dependency.  A failing call raises RuntimeError(vlp_last_error_string()).
+
+The product path has NO fallback: if the shared library is missing or was not built, importing the
+compute modules raises -- it never silently routes through torch ops or the CPU oracle.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvlp_hip.so")
+
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+MUL_NONE, MUL_GELU_GRAD, MUL_RELU_MASK = 0, 1, 2
+
+vp, i64, i32, f32, u64, u32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_uint64, C.c_uint32
+
+
+class GemmNtArgs(C.Structure):
+    _fields_ = [("X", vp), ("ldx", i64), ("W", vp), ("ldw", i64), ("Y", vp), ("ldy", i64), ("bias", vp),
+                ("residual", vp), ("ldr", i64), ("preact", vp), ("ldp", i64), ("mul_src", vp), ("ldm", i64),
+                ("M", i32), ("N", i32), ("K", i32), ("act", i32), ("mul_mode", i32), ("alpha", f32),
+                ("dropout_p", f32), ("seed", u64), ("rng_stream", u32), ("variant", i32)]
+
+
+class GemmTnArgs(C.Structure):
+    _fields_ = [("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64),
+                ("M", i32), ("N", i32), ("K", i32), ("beta", i32), ("workspace", vp), ("workspace_bytes", i64),
+                ("variant", i32), ("splits", i32)]
+
+
+class ColsumArgs(C.Structure):
+    _fields_ = [("A", vp), ("lda", i64), ("M", i32), ("N", i32), ("out", vp), ("beta", i32),
+                ("workspace", vp), ("workspace_bytes", i64)]
+
+
+class AttnFwdArgs(C.Structure):
+    _fields_ = [("qkv", vp), ("ld_qkv", i64), ("mask", vp), ("ctx", vp), ("ld_ctx", i64), ("lse", vp),
+                ("B", i32), ("L", i32), ("heads", i32), ("scale", f32),
+                ("dropout_p", f32), ("seed", u64), ("rng_stream", u32)]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = [("qkv", vp), ("ld_qkv", i64), ("mask", vp), ("ctx", vp), ("ld_ctx", i64), ("dctx", vp), ("ld_dctx", i64),
+                ("lse", vp), ("dqkv", vp), ("ld_dqkv", i64), ("delta", vp),
+                ("B", i32), ("L", i32), ("heads", i32), ("scale", f32),
+                ("dropout_p", f32), ("seed", u64), ("rng_stream", u32)]
+
+
+class LayerNormFwdArgs(C.Structure):
+    _fields_ = [("x", vp), ("ldx", i64), ("gamma", vp), ("beta", vp), ("y", vp), ("ldy", i64), ("mean", vp), ("rstd", vp),
+                ("M", i32), ("H", i32), ("eps", f32), ("dropout_p", f32), ("seed", u64), ("rng_stream", u32)]
+
+
+class LayerNormBwdArgs(C.Structure):
+    _fields_ = [("dy", vp), ("lddy", i64), ("x", vp), ("ldx", i64), ("gamma", vp), ("mean", vp), ("rstd", vp),
+                ("dx", vp), ("lddx", i64), ("dx_drop", vp), ("lddxd", i64), ("dgamma", vp), ("dbeta", vp),
+                ("M", i32), ("H", i32), ("beta", i32),
+                ("dy_drop_p", f32), ("dy_seed", u64), ("dy_stream", u32),
+                ("out_drop_p", f32), ("out_seed", u64), ("out_stream", u32),
+                ("workspace", vp), ("workspace_bytes", i64)]
+
+
+class EmbedFwdArgs(C.Structure):
+    _fields_ = [("input_ids", vp), ("segment_ids", vp), ("word_emb", vp), ("pos_emb", vp), ("type_emb", vp),
+                ("vis_h", vp), ("vispe_h", vp), ("pre", vp),
+                ("B", i32), ("L", i32), ("Nv", i32), ("H", i32), ("vocab", i32), ("type_vocab", i32)]
+
+
+class EmbedBwdArgs(C.Structure):
+    _fields_ = [("dpre", vp), ("input_ids", vp), ("segment_ids", vp), ("vis_h", vp), ("vispe_h", vp),
+                ("d_word_emb", vp), ("d_pos_emb", vp), ("d_type_emb", vp), ("d_vis_h", vp), ("d_vispe_h", vp), ("acc32", vp),
+                ("B", i32), ("L", i32), ("Nv", i32), ("H", i32), ("vocab", i32), ("type_vocab", i32),
+                ("drop_p", f32), ("seed", u64), ("vis_stream", u32), ("vispe_stream", u32)]
+
+
+class MlmLossFwdArgs(C.Structure):
+    _fields_ = [("logits", vp), ("ld_logits", i64), ("labels", vp), ("weights", vp), ("loss", vp), ("lse", vp), ("coef", vp),
+                ("row_loss", vp), ("B", i32), ("P", i32), ("V", i32), ("drop_worst_ratio", f32)]
+
+
+class MlmLossBwdArgs(C.Structure):
+    _fields_ = [("logits", vp), ("ld_logits", i64), ("labels", vp), ("lse", vp), ("coef", vp), ("grad_scale", vp),
+                ("dlogits", vp), ("ld_dlogits", i64), ("rows", i32), ("V", i32)]
+
+
+class FusedAdamArgs(C.Structure):
+    _fields_ = [("p32", vp), ("m", vp), ("v", vp), ("g16", vp), ("p16", vp), ("n", i64),
+                ("b1", f32), ("b2", f32), ("eps", f32), ("decay", f32), ("eps_inside_sqrt", i32), ("hyper", vp)]
+
+
+class BertAdamArgs(C.Structure):
+    _fields_ = [("p32", vp), ("m", vp), ("v", vp), ("g", vp), ("g_is_f32", i32), ("p16", vp),
+                ("seg_off", vp), ("ntensors", i32), ("n", i64), ("norms", vp),
+                ("lr", f32), ("b1", f32), ("b2", f32), ("eps", f32), ("decay", f32), ("max_grad_norm", f32), ("grad_scale", f32)]
+
+
+# every symbol include/vlp_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "vlp_version": (C.c_int, []),
+    "vlp_last_error_string": (C.c_char_p, []),
+    "vlp_gemm_nt": (C.c_int, [C.POINTER(GemmNtArgs), vp]),
+    "vlp_gemm_tn_workspace_bytes": (i64, [i32, i32, i32]),
+    "vlp_gemm_tn": (C.c_int, [C.POINTER(GemmTnArgs), vp]),
+    "vlp_colsum_workspace_bytes": (i64, [i32, i32]),
+    "vlp_colsum": (C.c_int, [C.POINTER(ColsumArgs), vp]),
+    "vlp_attn_fwd": (C.c_int, [C.POINTER(AttnFwdArgs), vp]),
+    "vlp_attn_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), vp]),
+    "vlp_mask_pack": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+    "vlp_layernorm_fwd": (C.c_int, [C.POINTER(LayerNormFwdArgs), vp]),
+    "vlp_layernorm_bwd_workspace_bytes": (i64, [i32]),
+    "vlp_layernorm_bwd": (C.c_int, [C.POINTER(LayerNormBwdArgs), vp]),
+    "vlp_embed_fwd": (C.c_int, [C.POINTER(EmbedFwdArgs), vp]),
+    "vlp_embed_bwd": (C.c_int, [C.POINTER(EmbedBwdArgs), vp]),
+    "vlp_copy2d": (C.c_int, [vp, i64, i32, vp, i64, i32, i32, i32, i32, vp]),
+    "vlp_transpose": (C.c_int, [vp, i64, vp, i64, i32, i32, i32, vp]),
+    "vlp_gather_rows": (C.c_int, [vp, i64, vp, vp, i64, i32, i32, i32, i32, vp]),
+    "vlp_scatter_add_rows": (C.c_int, [vp, i64, vp, vp, i64, i32, i32, i32, i32, vp]),
+    "vlp_vqa_mul_fwd": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+    "vlp_vqa_mul_bwd": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "vlp_relu_dropout_bwd": (C.c_int, [vp, vp, vp, i64, i64, f32, u64, u32, vp]),
+    "vlp_mlm_loss_fwd": (C.c_int, [C.POINTER(MlmLossFwdArgs), vp]),
+    "vlp_mlm_loss_bwd": (C.c_int, [C.POINTER(MlmLossBwdArgs), vp]),
+    "vlp_bce_loss_fwd": (C.c_int, [vp, i64, vp, i64, i32, i32, vp, vp]),
+    "vlp_bce_loss_bwd": (C.c_int, [vp, i64, vp, i64, i32, i32, vp, vp, i64, vp]),
+    "vlp_sumsq": (C.c_int, [vp, i64, vp, vp, vp]),
+    "vlp_fused_adam": (C.c_int, [C.POINTER(FusedAdamArgs), vp]),
+    "vlp_adam_hyper": (C.c_int, [vp, vp, f32, f32, f32, vp, vp]),
+    "vlp_bert_adam": (C.c_int, [C.POINTER(BertAdamArgs), vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libvlp_hip.so (built by vlp_amd/build.py).  Raises if it is absent: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libvlp_hip.so not found at %s -- run `python -m vlp_amd.build` (or "
+                           "__graft_entry__.build()).  vlp_amd has no CPU / torch fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.vlp_version() != 1:
+        raise RuntimeError("libvlp_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError("libvlp_hip: %s (status %d)" % (load().vlp_last_error_string().decode(), rc))
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _req_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("vlp_amd kernels need device tensors (got a CPU tensor); there is no CPU fallback")
+
+
+# --------------------------------------------------------------------------------------------------
+# thin typed wrappers
+# --------------------------------------------------------------------------------------------------
+def gemm_nt(x, w, y, M, N, K, ldx=None, ldw=None, ldy=None, bias=None, residual=None, ldr=None, preact=None, ldp=None,
+            mul_src=None, ldm=None, act=ACT_NONE, mul_mode=MUL_NONE, alpha=1.0, dropout_p=0.0, seed=0, rng_stream=0,
+            variant=0):
+    _req_cuda(x, w, y)
+    a = GemmNtArgs(ptr(x), ldx if ldx is not None else x.stride(0), ptr(w), ldw if ldw is not None else w.stride(0),
+                   ptr(y), ldy if ldy is not None else y.stride(0), ptr(bias),
+                   ptr(residual), (ldr if ldr is not None else (residual.stride(0) if residual is not None else 0)),
+                   ptr(preact), (ldp if ldp is not None else (preact.stride(0) if preact is not None else 0)),
+                   ptr(mul_src), (ldm if ldm is not None else (mul_src.stride(0) if mul_src is not None else 0)),
+                   M, N, K, act, mul_mode, alpha, dropout_p, seed, rng_stream, variant)
+    _check(load().vlp_gemm_nt(C.byref(a), stream_ptr()))
+
+
+def gemm_tn_workspace_bytes(M, N, K):
+    return int(load().vlp_gemm_tn_workspace_bytes(M, N, K))
+
+
+def gemm_tn(a_, b_, c_, M, N, K, lda=None, ldb=None, ldc=None, beta=0, workspace=None, variant=0, splits=0):
+    _req_cuda(a_, b_, c_)
+    a = GemmTnArgs(ptr(a_), lda if lda is not None else a_.stride(0), ptr(b_), ldb if ldb is not None else b_.stride(0),
+                   ptr(c_), ldc if ldc is not None else c_.stride(0), M, N, K, beta,
+                   ptr(workspace), workspace.numel() * workspace.element_size() if workspace is not None else 0, variant, splits)
+    _check(load().vlp_gemm_tn(C.byref(a), stream_ptr()))
+
+
+def colsum_workspace_bytes(M, N):
+    return int(load().vlp_colsum_workspace_bytes(M, N))
+
+
+def colsum(a_, out, M, N, lda=None, beta=0, workspace=None):
+    _req_cuda(a_, out)
+    a = ColsumArgs(ptr(a_), lda if lda is not None else a_.stride(0), M, N, ptr(out), beta, ptr(workspace),
+                   workspace.numel() * workspace.element_size())
+    _check(load().vlp_colsum(C.byref(a), stream_ptr()))
+
+
+def attn_fwd(qkv, mask, ctx, lse, B, L, heads, scale, dropout_p=0.0, seed=0, rng_stream=0):
+    _req_cuda(qkv, mask, ctx, lse)
+    a = AttnFwdArgs(ptr(qkv), qkv.stride(0), ptr(mask), ptr(ctx), ctx.stride(0), ptr(lse), B, L, heads, scale, dropout_p, seed, rng_stream)
+    _check(load().vlp_attn_fwd(C.byref(a), stream_ptr()))
+
+
+def attn_bwd(qkv, mask, ctx, dctx, lse, dqkv, delta, B, L, heads, scale, dropout_p=0.0, seed=0, rng_stream=0):
+    _req_cuda(qkv, mask, ctx, dctx, lse, dqkv, delta)
+    a = AttnBwdArgs(ptr(qkv), qkv.stride(0), ptr(mask), ptr(ctx), ctx.stride(0), ptr(dctx), dctx.stride(0), ptr(lse),
+                    ptr(dqkv), dqkv.stride(0), ptr(delta), B, L, heads, scale, dropout_p, seed, rng_stream)
+    _check(load().vlp_attn_bwd(C.byref(a), stream_ptr()))
+
+
+def mask_pack(mask_i64, out_u8, B, L, Lp):
+    _req_cuda(mask_i64, out_u8)
+    _check(load().vlp_mask_pack(ptr(mask_i64), ptr(out_u8), B, L, Lp, stream_ptr()))
+
+
+def layernorm_fwd(x, gamma, beta, y, M, H, mean=None, rstd=None, eps=1e-5, dropout_p=0.0, seed=0, rng_stream=0, ldx=None, ldy=None):
+    _req_cuda(x, gamma, beta, y)
+    a = LayerNormFwdArgs(ptr(x), ldx if ldx is not None else x.stride(0), ptr(gamma), ptr(beta), ptr(y),
+                         ldy if ldy is not None else y.stride(0), ptr(mean), ptr(rstd), M, H, eps, dropout_p, seed, rng_stream)
+    _check(load().vlp_layernorm_fwd(C.byref(a), stream_ptr()))
+
+
+def layernorm_bwd_workspace_bytes(H):
+    return int(load().vlp_layernorm_bwd_workspace_bytes(H))
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M, H, workspace, beta=0, dx_drop=None,
+                  dy_drop=(0.0, 0, 0), out_drop=(0.0, 0, 0)):
+    _req_cuda(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace)
+    a = LayerNormBwdArgs(ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), dx.stride(0),
+                         ptr(dx_drop), dx_drop.stride(0) if dx_drop is not None else 0, ptr(dgamma), ptr(dbeta), M, H, beta,
+                         dy_drop[0], dy_drop[1], dy_drop[2], out_drop[0], out_drop[1], out_drop[2],
+                         ptr(workspace), workspace.numel() * workspace.element_size())
+    _check(load().vlp_layernorm_bwd(C.byref(a), stream_ptr()))
+
+
+def embed_fwd(input_ids, segment_ids, word_emb, pos_emb, type_emb, vis_h, vispe_h, pre, B, L, Nv, H):
+    _req_cuda(input_ids, segment_ids, word_emb, pos_emb, type_emb, pre)
+    a = EmbedFwdArgs(ptr(input_ids), ptr(segment_ids), ptr(word_emb), ptr(pos_emb), ptr(type_emb), ptr(vis_h), ptr(vispe_h),
+                     ptr(pre), B, L, Nv, H, word_emb.shape[0], type_emb.shape[0])
+    _check(load().vlp_embed_fwd(C.byref(a), stream_ptr()))
+
+
+def embed_bwd(dpre, input_ids, segment_ids, vis_h, vispe_h, d_word, d_pos, d_type, d_vis_h, d_vispe_h, acc32,
+              B, L, Nv, H, vocab, type_vocab, drop_p=0.0, seed=0, vis_stream=0, vispe_stream=0):
+    _req_cuda(dpre, input_ids, segment_ids, d_word, d_pos, d_type, acc32)
+    a = EmbedBwdArgs(ptr(dpre), ptr(input_ids), ptr(segment_ids), ptr(vis_h), ptr(vispe_h), ptr(d_word), ptr(d_pos), ptr(d_type),
+                     ptr(d_vis_h), ptr(d_vispe_h), ptr(acc32), B, L, Nv, H, vocab, type_vocab, drop_p, seed, vis_stream, vispe_stream)
+    _check(load().vlp_embed_bwd(C.byref(a), stream_ptr()))
+
+
+def copy2d(src, lds, src_f32, dst, ldd, rows, cols_src, cols_dst, beta=0):
+    _req_cuda(src, dst)
+    _check(load().vlp_copy2d(ptr(src), lds, int(src_f32), ptr(dst), ldd, rows, cols_src, cols_dst, beta, stream_ptr()))
+
+
+def transpose(src, lds, dst, ldd, rows, cols, rows_pad):
+    _req_cuda(src, dst)
+    _check(load().vlp_transpose(ptr(src), lds, ptr(dst), ldd, rows, cols, rows_pad, stream_ptr()))
+
+
+def gather_rows(src, lds, pos, out, ldo, B, P, L, H):
+    _req_cuda(src, pos, out)
+    _check(load().vlp_gather_rows(ptr(src), lds, ptr(pos), ptr(out), ldo, B, P, L, H, stream_ptr()))
+
+
+def scatter_add_rows(src, lds, pos, dst, ldd, B, P, L, H):
+    _req_cuda(src, pos, dst)
+    _check(load().vlp_scatter_add_rows(ptr(src), lds, ptr(pos), ptr(dst), ldd, B, P, L, H, stream_ptr()))
+
+
+def vqa_mul_fwd(h, out, B, L, Nv, H):
+    _req_cuda(h, out)
+    _check(load().vlp_vqa_mul_fwd(ptr(h), ptr(out), B, L, Nv, H, stream_ptr()))
+
+
+def vqa_mul_bwd(h, dout, dh, B, L, Nv, H):
+    _req_cuda(h, dout, dh)
+    _check(load().vlp_vqa_mul_bwd(ptr(h), ptr(dout), ptr(dh), B, L, Nv, H, stream_ptr()))
+
+
+def relu_dropout_bwd(dy, y, dz, n, ncols, drop_p=0.0, seed=0, rng_stream=0):
+    _req_cuda(dy, y, dz)
+    _check(load().vlp_relu_dropout_bwd(ptr(dy), ptr(y), ptr(dz), n, ncols, drop_p, seed, rng_stream, stream_ptr()))
+
+
+def mlm_loss_fwd(logits, ld, labels, weights, loss, lse, coef, row_loss, B, P, V, drop_worst_ratio=0.0):
+    _req_cuda(logits, labels, weights, loss, lse, coef, row_loss)
+    a = MlmLossFwdArgs(ptr(logits), ld, ptr(labels), ptr(weights), ptr(loss), ptr(lse), ptr(coef), ptr(row_loss), B, P, V, drop_worst_ratio)
+    _check(load().vlp_mlm_loss_fwd(C.byref(a), stream_ptr()))
+
+
+def mlm_loss_bwd(logits, ld, labels, lse, coef, grad_scale, dlogits, ldd, rows, V):
+    _req_cuda(logits, labels, lse, coef, grad_scale, dlogits)
+    a = MlmLossBwdArgs(ptr(logits), ld, ptr(labels), ptr(lse), ptr(coef), ptr(grad_scale), ptr(dlogits), ldd, rows, V)
+    _check(load().vlp_mlm_loss_bwd(C.byref(a), stream_ptr()))
+
+
+def bce_loss_fwd(logits, ld, labels, ldl, B, N, loss257):
+    _req_cuda(logits, labels, loss257)
+    _check(load().vlp_bce_loss_fwd(ptr(logits), ld, ptr(labels), ldl, B, N, ptr(loss257), stream_ptr()))
+
+
+def bce_loss_bwd(logits, ld, labels, ldl, B, N, grad_scale, dlogits, ldd):
+    _req_cuda(logits, labels, grad_scale, dlogits)
+    _check(load().vlp_bce_loss_bwd(ptr(logits), ld, ptr(labels), ldl, B, N, ptr(grad_scale), ptr(dlogits), ldd, stream_ptr()))
+
+
+def sumsq(g16, n, out2, partial):
+    _req_cuda(g16, out2, partial)
+    _check(load().vlp_sumsq(ptr(g16), n, ptr(out2), ptr(partial), stream_ptr()))
+
+
+def adam_hyper(sumsq2, any_overflow, loss_scale, max_grad_norm, step_size, hyper3):
+    _req_cuda(sumsq2, hyper3)
+    _check(load().vlp_adam_hyper(ptr(sumsq2), ptr(any_overflow), loss_scale, max_grad_norm, step_size, ptr(hyper3), stream_ptr()))
+
+
+def fused_adam(p32, m, v, g16, p16, n, hyper, b1=0.9, b2=0.999, eps=1e-8, decay=0.0, eps_inside_sqrt=False):
+    _req_cuda(p32, m, v, g16, p16, hyper)
+    a = FusedAdamArgs(ptr(p32), ptr(m), ptr(v), ptr(g16), ptr(p16), n, b1, b2, eps, decay, int(eps_inside_sqrt), ptr(hyper))
+    _check(load().vlp_fused_adam(C.byref(a), stream_ptr()))
+
+
+def bert_adam(p32, m, v, g, g_is_f32, p16, seg_off, ntensors, n, norms, lr, b1=0.9, b2=0.999, eps=1e-6, decay=0.01,
+              max_grad_norm=1.0, grad_scale=1.0):
+    _req_cuda(p32, m, v, g, seg_off, norms)
+    a = BertAdamArgs(ptr(p32), ptr(m), ptr(v), ptr(g), int(g_is_f32), ptr(p16), ptr(seg_off), ntensors, n, ptr(norms),
+                     lr, b1, b2, eps, decay, max_grad_norm, grad_scale)
+    _check(load().vlp_bert_adam(C.byref(a), stream_ptr()))

@@ -1,0 +1,228 @@
+// Optimizer kernels for gfx950 (HBM-bound, 16/32-byte vector accesses, flat parameter buffers).
+//
+//  * vlp_sumsq / vlp_adam_hyper / vlp_fused_adam: apex FP16_Optimizer + FusedAdam as configured by the
+//    reference (run_img2txt_dist.py:411-420, step at :584; optimization_fp16.py:7-80): global grad norm and
+//    overflow check over the flat fp16 gradient of a param group, clip folded into the unscale factor, one
+//    pass that updates fp32 master weights + both moments and writes the fp16 model copy.  All scalar
+//    decisions (clip coefficient, skip-on-overflow) stay on the device, so a step needs no host sync.
+//  * vlp_bert_adam: BertAdam.step (optimization.py:112-182): per-TENSOR clip, eps outside the sqrt added to
+//    sqrt(v), decoupled weight decay, no bias correction.
+#include "common.h"
+
+#define SQ_BLOCKS 1024
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const f16* __restrict__ g, int64_t n, float* __restrict__ partial) {
+    __shared__ float sh[4], shb[4];
+    float s = 0.f, bad = 0.f;
+    const int64_t n8 = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        f16x8 v = ld8(g + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = (float)v[e];
+            s += f * f;
+            if (!(fabsf(f) <= 65504.f)) bad = 1.f;   // inf or nan
+        }
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = n8 * 8 + threadIdx.x; i < n; i += blockDim.x) {
+            const float f = (float)g[i];
+            s += f * f;
+            if (!(fabsf(f) <= 65504.f)) bad = 1.f;
+        }
+    s = wave_sum(s);
+    bad = wave_max(bad);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) { sh[w] = s; shb[w] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+        partial[SQ_BLOCKS + blockIdx.x] = fmaxf(fmaxf(shb[0], shb[1]), fmaxf(shb[2], shb[3]));
+    }
+}
+__global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ out2) {
+    __shared__ float sh[4], shb[4];
+    float s = 0.f, bad = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) { s += partial[i]; bad = fmaxf(bad, partial[SQ_BLOCKS + i]); }
+    s = wave_sum(s);
+    bad = wave_max(bad);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) { sh[w] = s; shb[w] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = sh[0] + sh[1] + sh[2] + sh[3];
+        float b = fmaxf(fmaxf(shb[0], shb[1]), fmaxf(shb[2], shb[3]));
+        if (!(tot <= 3.0e38f)) b = 1.f;   // the fp32 norm itself overflowed
+        out2[0] = tot;
+        out2[1] = b;
+    }
+}
+extern "C" int vlp_sumsq(const void* g, int64_t n, float* out2, float* partial, void* stream) {
+    VLP_CHECK_ARG(g && out2 && partial && n > 0 && (uintptr_t)g % 16 == 0, "vlp_sumsq: bad args (partial must hold 2048 floats)");
+    int blocks = (int)((n / 8 + 255) / 256);
+    if (blocks > SQ_BLOCKS) blocks = SQ_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, s, (const f16*)g, n, partial);
+    VLP_CHECK_LAUNCH("vlp_sumsq");
+    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, s, partial, blocks, out2);
+    VLP_CHECK_LAUNCH("vlp_sumsq(finish)");
+    return VLP_OK;
+}
+
+__global__ void adam_hyper_kernel(const float* sumsq2, const float* any_overflow, float scale, float max_grad_norm, float step_size, float* hyper) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float overflow = sumsq2[1];
+    if (any_overflow) overflow = fmaxf(overflow, any_overflow[0]);
+    const float norm = sqrtf(sumsq2[0]);          // = true norm * scale
+    float combined = scale;
+    if (max_grad_norm > 0.f) {
+        const float clip = (norm / scale + 1e-6f) / max_grad_norm;
+        if (clip > 1.f) combined = clip * scale;
+    }
+    hyper[0] = combined;
+    hyper[1] = step_size;
+    hyper[2] = overflow;
+}
+extern "C" int vlp_adam_hyper(const float* sumsq2, const float* any_overflow, float loss_scale, float max_grad_norm, float step_size, float* hyper3,
+                              void* stream) {
+    VLP_CHECK_ARG(sumsq2 && hyper3 && loss_scale > 0.f, "vlp_adam_hyper: bad args");
+    hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sumsq2, any_overflow, loss_scale, max_grad_norm, step_size, hyper3);
+    VLP_CHECK_LAUNCH("vlp_adam_hyper");
+    return VLP_OK;
+}
+
+__global__ __launch_bounds__(256) void fused_adam_kernel(vlp_fused_adam_args a) {
+    const float combined = a.hyper[0], step_size = a.hyper[1], skip = a.hyper[2];
+    if (skip != 0.f) return;
+    const float inv = 1.f / combined;
+    const f16* g = (const f16*)a.g16;
+    f16* p16 = (f16*)a.p16;
+    const int64_t n8 = a.n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const f16x8 gv = ld8(g + i * 8);
+        float pp[8], mm[8], vv[8];
+        {
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(a.p32 + i * 8), p1 = *reinterpret_cast<const f32x4*>(a.p32 + i * 8 + 4);
+            const f32x4 m0 = *reinterpret_cast<const f32x4*>(a.m + i * 8), m1 = *reinterpret_cast<const f32x4*>(a.m + i * 8 + 4);
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(a.v + i * 8), v1 = *reinterpret_cast<const f32x4*>(a.v + i * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pp[e] = p0[e]; pp[4 + e] = p1[e]; mm[e] = m0[e]; mm[4 + e] = m1[e]; vv[e] = v0[e]; vv[4 + e] = v1[e]; }
+        }
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sg = (float)gv[e] * inv;
+            mm[e] = a.b1 * mm[e] + (1.f - a.b1) * sg;
+            vv[e] = a.b2 * vv[e] + (1.f - a.b2) * sg * sg;
+            const float denom = a.eps_inside_sqrt ? sqrtf(vv[e] + a.eps) : sqrtf(vv[e]) + a.eps;
+            pp[e] = pp[e] - step_size * (mm[e] / denom + a.decay * pp[e]);
+            o[e] = (f16)pp[e];
+        }
+        *reinterpret_cast<f32x4*>(a.p32 + i * 8) = (f32x4){pp[0], pp[1], pp[2], pp[3]};
+        *reinterpret_cast<f32x4*>(a.p32 + i * 8 + 4) = (f32x4){pp[4], pp[5], pp[6], pp[7]};
+        *reinterpret_cast<f32x4*>(a.m + i * 8) = (f32x4){mm[0], mm[1], mm[2], mm[3]};
+        *reinterpret_cast<f32x4*>(a.m + i * 8 + 4) = (f32x4){mm[4], mm[5], mm[6], mm[7]};
+        *reinterpret_cast<f32x4*>(a.v + i * 8) = (f32x4){vv[0], vv[1], vv[2], vv[3]};
+        *reinterpret_cast<f32x4*>(a.v + i * 8 + 4) = (f32x4){vv[4], vv[5], vv[6], vv[7]};
+        st8(p16 + i * 8, o);
+    }
+}
+extern "C" int vlp_fused_adam(const vlp_fused_adam_args* a, void* stream) {
+    VLP_CHECK_ARG(a && a->p32 && a->m && a->v && a->g16 && a->p16 && a->hyper, "vlp_fused_adam: null operand");
+    VLP_CHECK_ARG(a->n > 0 && a->n % 8 == 0, "vlp_fused_adam: n must be a positive multiple of 8 (pad the flat buffer)");
+    VLP_CHECK_ARG(((uintptr_t)a->p32 | (uintptr_t)a->m | (uintptr_t)a->v | (uintptr_t)a->g16 | (uintptr_t)a->p16) % 16 == 0, "vlp_fused_adam: alignment");
+    int blocks = (int)((a->n / 8 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fused_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    VLP_CHECK_LAUNCH("vlp_fused_adam");
+    return VLP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BertAdam: pass 1 = per-tensor sum of squares (one block per (tensor, slice), atomics into norms[]),
+// pass 2 = update with the per-tensor clip coefficient.
+// ---------------------------------------------------------------------------------------------
+#define BA_CHUNK 4096   // elements per block in both passes
+
+DEVFN float ba_load(const void* g, int g_is_f32, int64_t i) { return g_is_f32 ? ((const float*)g)[i] : (float)((const f16*)g)[i]; }
+
+// binary search: tensor t with seg_off[t] <= i < seg_off[t+1]
+DEVFN int ba_find(const int64_t* seg_off, int nt, int64_t i) {
+    int lo = 0, hi = nt - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (seg_off[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void bert_adam_norm_kernel(vlp_bert_adam_args a) {
+    __shared__ float sh[4];
+    const int64_t start = (int64_t)blockIdx.x * BA_CHUNK;
+    const int64_t end = min(a.n, start + BA_CHUNK);
+    // a chunk may straddle tensor boundaries: accumulate per element into its tensor (rarely > 2 tensors)
+    int t = ba_find(a.seg_off, a.ntensors, start);
+    int64_t pos = start;
+    while (pos < end) {
+        const int64_t tend = min(end, a.seg_off[t + 1]);
+        float s = 0.f;
+        for (int64_t i = pos + threadIdx.x; i < tend; i += blockDim.x) {
+            const float f = ba_load(a.g, a.g_is_f32, i) / a.grad_scale;
+            s += f * f;
+        }
+        s = wave_sum(s);
+        const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+        __syncthreads();
+        if (l == 0) sh[w] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(a.norms + t, sh[0] + sh[1] + sh[2] + sh[3]);
+        pos = tend;
+        ++t;
+    }
+}
+__global__ __launch_bounds__(256) void bert_adam_update_kernel(vlp_bert_adam_args a) {
+    const int64_t start = (int64_t)blockIdx.x * BA_CHUNK;
+    const int64_t end = min(a.n, start + BA_CHUNK);
+    int t = ba_find(a.seg_off, a.ntensors, start);
+    int64_t pos = start;
+    f16* p16 = (f16*)a.p16;
+    while (pos < end) {
+        const int64_t tend = min(end, a.seg_off[t + 1]);
+        float coef = 1.f;
+        if (a.max_grad_norm > 0.f) {
+            // torch clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), applied when < 1
+            const float c = a.max_grad_norm / (sqrtf(a.norms[t]) + 1e-6f);
+            if (c < 1.f) coef = c;
+        }
+        coef /= a.grad_scale;
+        for (int64_t i = pos + threadIdx.x; i < tend; i += blockDim.x) {
+            const float g = ba_load(a.g, a.g_is_f32, i) * coef;
+            const float m = a.b1 * a.m[i] + (1.f - a.b1) * g;
+            const float v = a.b2 * a.v[i] + (1.f - a.b2) * g * g;
+            float p = a.p32[i];
+            float upd = m / (sqrtf(v) + a.eps);
+            if (a.decay > 0.f) upd += a.decay * p;
+            p -= a.lr * upd;
+            a.m[i] = m; a.v[i] = v; a.p32[i] = p;
+            if (p16) p16[i] = (f16)p;
+        }
+        pos = tend;
+        ++t;
+    }
+}
+extern "C" int vlp_bert_adam(const vlp_bert_adam_args* a, void* stream) {
+    VLP_CHECK_ARG(a && a->p32 && a->m && a->v && a->g && a->seg_off && a->norms, "vlp_bert_adam: null operand");
+    VLP_CHECK_ARG(a->n > 0 && a->ntensors > 0 && a->grad_scale > 0.f, "vlp_bert_adam: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = (int)((a->n + BA_CHUNK - 1) / BA_CHUNK);
+    if (a->max_grad_norm > 0.f) {
+        hipError_t e = hipMemsetAsync(a->norms, 0, sizeof(float) * a->ntensors, s);
+        if (e != hipSuccess) return vlp_set_error(VLP_ERR_HIP, "vlp_bert_adam: memset: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(bert_adam_norm_kernel, dim3(blocks), dim3(256), 0, s, *a);
+        VLP_CHECK_LAUNCH("vlp_bert_adam(norm)");
+    }
+    hipLaunchKernelGGL(bert_adam_update_kernel, dim3(blocks), dim3(256), 0, s, *a);
+    VLP_CHECK_LAUNCH("vlp_bert_adam(update)");
+    return VLP_OK;
+}

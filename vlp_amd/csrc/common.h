@@ -1,0 +1,97 @@
+// Shared device/host helpers for libvlp_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vlp_hip.h"
+
+typedef _Float16 f16;
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define WAVE 64
+#define DEVFN __device__ __forceinline__
+
+// ---------------------------------------------------------------------------------------------
+// host-side error plumbing (thread-local last error string; never throws, never aborts)
+// ---------------------------------------------------------------------------------------------
+int vlp_set_error(int code, const char* fmt, ...);
+#define VLP_CHECK_ARG(cond, ...)                                         \
+    do {                                                                 \
+        if (!(cond)) return vlp_set_error(VLP_ERR_BAD_ARG, __VA_ARGS__); \
+    } while (0)
+#define VLP_CHECK_LAUNCH(name)                                                                        \
+    do {                                                                                              \
+        hipError_t e_ = hipGetLastError();                                                            \
+        if (e_ != hipSuccess) return vlp_set_error(VLP_ERR_HIP, "%s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------------
+// counter-based dropout RNG.  keep(seed, stream, idx) is a pure function, so backward recomputes the
+// mask instead of storing it.  (The reference uses torch's Philox stream, which cannot be matched
+// bit-for-bit anyway -- parity tests run with p = 0; see DESIGN.md.)
+// ---------------------------------------------------------------------------------------------
+DEVFN uint32_t mix32(uint32_t x) {   // "lowbias32" finalizer
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+struct DropCtx {
+    uint32_t k0, k1, thresh;   // drop when hash < thresh
+    float scale;               // 1/(1-p)
+};
+static inline DropCtx make_drop(float p, uint64_t seed, uint32_t stream) {
+    DropCtx d;
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + (uint64_t)stream * 0xD1B54A32D192ED03ull + 0x632BE59BD9B4E019ull;
+    d.k0 = (uint32_t)s;
+    d.k1 = (uint32_t)(s >> 32) | 1u;
+    double t = (double)p * 4294967296.0;
+    d.thresh = p <= 0.f ? 0u : (t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t);
+    d.scale = p <= 0.f ? 1.f : 1.f / (1.f - p);
+    return d;
+}
+// The mask of element (row, col) of a logical 2-D tensor: a 32-bit row key (computed once per row) mixed
+// with the column.  Forward and backward of an op must agree on what (row, col) mean -- each kernel
+// documents it.
+DEVFN uint32_t drop_rowkey(const DropCtx& d, uint64_t row) {
+    return mix32((uint32_t)row ^ d.k0) + mix32((uint32_t)(row >> 32) + d.k1);
+}
+// returns the multiplier (0 or 1/(1-p))
+DEVFN float drop_mult(const DropCtx& d, uint32_t rowkey, uint32_t col) {
+    const uint32_t h = mix32(rowkey + col * 0x9E3779B9u);
+    return h < d.thresh ? 0.f : d.scale;
+}
+
+// ---------------------------------------------------------------------------------------------
+// math
+// ---------------------------------------------------------------------------------------------
+DEVFN float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+DEVFN float gelu_grad_f(float x) {
+    // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+DEVFN float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+DEVFN float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+DEVFN f16x8 ld8(const f16* p) { return *reinterpret_cast<const f16x8*>(p); }
+DEVFN void st8(f16* p, f16x8 v) { *reinterpret_cast<f16x8*>(p) = v; }
+DEVFN f16x4 ld4(const f16* p) { return *reinterpret_cast<const f16x4*>(p); }
+DEVFN void st4(f16* p, f16x4 v) { *reinterpret_cast<f16x4*>(p) = v; }

@@ -1,0 +1,352 @@
+// Memory-bound glue kernels of the VLP hot path for gfx950 (16-byte vector accesses where layout permits).
+#include <hip/hip_fp16.h>
+#include "common.h"
+
+// =================================================================================================
+// Embedding splice, modeling.py:217-236
+// =================================================================================================
+__global__ __launch_bounds__(256) void embed_fwd_kernel(vlp_embed_fwd_args a) {
+    const int nch = a.H >> 3;
+    const int64_t total = (int64_t)a.B * a.L * nch;
+    const f16* word = (const f16*)a.word_emb;
+    const f16* pos = (const f16*)a.pos_emb;
+    const f16* typ = (const f16*)a.type_emb;
+    const f16* vis = (const f16*)a.vis_h;
+    const f16* vpe = (const f16*)a.vispe_h;
+    f16* pre = (f16*)a.pre;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nch);
+        const int64_t row = i / nch;
+        const int l = (int)(row % a.L);
+        const int b = (int)(row / a.L);
+        f16x8 w, p;
+        if (l >= 1 && l <= a.Nv) {
+            const int64_t vr = (int64_t)b * a.Nv + (l - 1);
+            w = ld8(vis + vr * a.H + c * 8);
+            p = ld8(vpe + vr * a.H + c * 8);
+        } else {
+            int64_t id = a.input_ids[row];
+            id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
+            w = ld8(word + id * a.H + c * 8);
+            p = ld8(pos + (int64_t)l * a.H + c * 8);
+        }
+        int64_t sg = a.segment_ids[row];
+        sg = sg < 0 ? 0 : (sg >= a.type_vocab ? a.type_vocab - 1 : sg);
+        f16x8 t = ld8(typ + sg * a.H + c * 8), o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)((float)w[e] + (float)p[e] + (float)t[e]);
+        st8(pre + row * a.H + c * 8, o);
+    }
+}
+extern "C" int vlp_embed_fwd(const vlp_embed_fwd_args* a, void* stream) {
+    VLP_CHECK_ARG(a && a->input_ids && a->segment_ids && a->word_emb && a->pos_emb && a->type_emb && a->pre, "vlp_embed_fwd: null operand");
+    VLP_CHECK_ARG(a->H % 8 == 0 && a->B > 0 && a->L > 0 && a->Nv >= 0 && a->Nv + 1 < a->L + 1, "vlp_embed_fwd: bad shape");
+    VLP_CHECK_ARG(a->Nv == 0 || (a->vis_h && a->vispe_h), "vlp_embed_fwd: region rows need vis_h / vispe_h");
+    const int64_t total = (int64_t)a->B * a->L * (a->H / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    VLP_CHECK_LAUNCH("vlp_embed_fwd");
+    return VLP_OK;
+}
+
+// backward.  (1) one pass over dpre: region rows -> d_vis_h / d_vispe_h (through ReLU + dropout), token rows
+// -> packed fp16 atomics into d_word_emb (all-zero rows, i.e. padding, are skipped); (2) position table:
+// deterministic sum over the batch per token position; (3) type table: masked column sums (one register
+// accumulator per type) over row splits + a small reduce.  No float atomics.
+#define EMB_TSPLITS 64
+#define EMB_MAXT 8
+__global__ __launch_bounds__(256) void embed_bwd_kernel(vlp_embed_bwd_args a, DropCtx dvis, DropCtx dvpe) {
+    const int nch = a.H >> 3;
+    const int64_t total = (int64_t)a.B * a.L * nch;
+    const f16* dpre = (const f16*)a.dpre;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nch);
+        const int64_t row = i / nch;
+        const int l = (int)(row % a.L);
+        const int b = (int)(row / a.L);
+        const f16x8 d = ld8(dpre + row * a.H + c * 8);
+        if (l >= 1 && l <= a.Nv) {
+            const int64_t vr = (int64_t)b * a.Nv + (l - 1);
+            const f16x8 yv = ld8((const f16*)a.vis_h + vr * a.H + c * 8);
+            const f16x8 yp = ld8((const f16*)a.vispe_h + vr * a.H + c * 8);
+            f16x8 ov, op;
+            const uint32_t kv = dvis.thresh ? drop_rowkey(dvis, (uint64_t)vr) : 0u;   // (row of the [B*Nv, H] projection, col)
+            const uint32_t kp = dvpe.thresh ? drop_rowkey(dvpe, (uint64_t)vr) : 0u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t col = (uint32_t)(c * 8 + e);
+                // y > 0 implies the ReLU was active AND the element survived dropout
+                float gv = ((float)yv[e] > 0.f) ? (float)d[e] : 0.f;
+                float gp = ((float)yp[e] > 0.f) ? (float)d[e] : 0.f;
+                if (dvis.thresh) gv *= drop_mult(dvis, kv, col);
+                if (dvpe.thresh) gp *= drop_mult(dvpe, kp, col);
+                ov[e] = (f16)gv;
+                op[e] = (f16)gp;
+            }
+            st8((f16*)a.d_vis_h + vr * a.H + c * 8, ov);
+            st8((f16*)a.d_vispe_h + vr * a.H + c * 8, op);
+        } else {
+            const u32x4 bits = __builtin_bit_cast(u32x4, d);
+            if (((bits[0] | bits[1] | bits[2] | bits[3]) & 0x7fff7fffu) == 0u) continue;   // +-0 everywhere: nothing to add
+            int64_t id = a.input_ids[row];
+            id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
+            __half2* wdst = reinterpret_cast<__half2*>((f16*)a.d_word_emb + id * a.H + c * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) unsafeAtomicAdd(wdst + e, __floats2half2_rn((float)d[2 * e], (float)d[2 * e + 1]));
+        }
+    }
+}
+// d_pos_emb[l] += sum_b dpre[b,l]  for token positions (l == 0 or l > Nv)
+__global__ void embed_bwd_pos_kernel(const f16* dpre, f16* dpos, int B, int L, int Nv, int H) {
+    const int nch = H >> 3;
+    const int64_t total = (int64_t)L * nch;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nch);
+        const int l = (int)(i / nch);
+        if (l >= 1 && l <= Nv) continue;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const f16x8 d = ld8(dpre + ((int64_t)b * L + l) * H + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)d[e];
+        }
+        f16* dst = dpos + (int64_t)l * H + c * 8;
+        f16x8 o = ld8(dst);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)((float)o[e] + acc[e]);
+        st8(dst, o);
+    }
+}
+// part[split][t][H] = sum over the split's rows with segment t of dpre
+__global__ __launch_bounds__(256) void embed_bwd_type_kernel(const f16* dpre, const int64_t* seg, float* part, int64_t rows, int H, int T) {
+    __shared__ float red[8][256];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 256 + tx * 8;
+    const int64_t rows_per = (rows + gridDim.y - 1) / gridDim.y;
+    const int64_t r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+    float acc[EMB_MAXT][8];
+#pragma unroll
+    for (int t = 0; t < EMB_MAXT; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+    if (c0 < H) {
+        for (int64_t r = r0 + ty; r < r1; r += 8) {
+            int64_t sg = seg[r];
+            sg = sg < 0 ? 0 : (sg >= T ? T - 1 : sg);
+            const f16x8 d = ld8(dpre + r * H + c0);
+#pragma unroll
+            for (int t = 0; t < EMB_MAXT; ++t) {
+                const float m = (sg == t) ? 1.f : 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[t][e] += m * (float)d[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < EMB_MAXT; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[ty][tx * 8 + e] = acc[t][e];
+        __syncthreads();
+        float s = 0.f;
+#pragma unroll
+        for (int y = 0; y < 8; ++y) s += red[y][threadIdx.x];
+        const int col = blockIdx.x * 256 + threadIdx.x;
+        if (col < H && t < T) part[((int64_t)blockIdx.y * EMB_MAXT + t) * H + col] = s;
+    }
+}
+__global__ void embed_bwd_type_reduce_kernel(const float* part, int nsplits, f16* dtyp, int T, int H) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * H) return;
+    const int t = i / H, c = i % H;
+    float s = 0.f;
+    for (int p = 0; p < nsplits; ++p) s += part[((int64_t)p * EMB_MAXT + t) * H + c];
+    dtyp[i] = (f16)((float)dtyp[i] + s);
+}
+extern "C" int vlp_embed_bwd(const vlp_embed_bwd_args* a, void* stream) {
+    VLP_CHECK_ARG(a && a->dpre && a->input_ids && a->segment_ids && a->d_word_emb && a->d_pos_emb && a->d_type_emb && a->acc32, "vlp_embed_bwd: null operand");
+    VLP_CHECK_ARG(a->H % 8 == 0 && a->B > 0 && a->L > 0 && a->type_vocab >= 1 && a->type_vocab <= EMB_MAXT, "vlp_embed_bwd: bad shape (type_vocab <= 8)");
+    VLP_CHECK_ARG(a->Nv == 0 || (a->vis_h && a->vispe_h && a->d_vis_h && a->d_vispe_h), "vlp_embed_bwd: region buffers");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)a->B * a->L * (a->H / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(256), 0, s, *a, make_drop(a->drop_p, a->seed, a->vis_stream),
+                       make_drop(a->drop_p, a->seed, a->vispe_stream));
+    VLP_CHECK_LAUNCH("vlp_embed_bwd");
+    hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3(cdiv((int64_t)a->L * (a->H / 8), 256)), dim3(256), 0, s, (const f16*)a->dpre,
+                       (f16*)a->d_pos_emb, a->B, a->L, a->Nv, a->H);
+    VLP_CHECK_LAUNCH("vlp_embed_bwd_pos");
+    const int64_t rows = (int64_t)a->B * a->L;
+    int splits = rows >= EMB_TSPLITS * 8 ? EMB_TSPLITS : (int)((rows + 7) / 8);
+    hipLaunchKernelGGL(embed_bwd_type_kernel, dim3(cdiv(a->H, 256), splits), dim3(256), 0, s, (const f16*)a->dpre, a->segment_ids, a->acc32,
+                       rows, a->H, a->type_vocab);
+    VLP_CHECK_LAUNCH("vlp_embed_bwd_type");
+    hipLaunchKernelGGL(embed_bwd_type_reduce_kernel, dim3(cdiv((int64_t)a->type_vocab * a->H, 256)), dim3(256), 0, s, a->acc32, splits,
+                       (f16*)a->d_type_emb, a->type_vocab, a->H);
+    VLP_CHECK_LAUNCH("vlp_embed_bwd_type_reduce");
+    return VLP_OK;
+}
+
+// =================================================================================================
+// copy2d (pad / crop / cast / accumulate) and transpose
+// =================================================================================================
+__global__ void copy2d_kernel(const void* src, int64_t lds, int src_f32, f16* dst, int64_t ldd, int rows, int cols_src, int cols_dst, int beta) {
+    const int64_t total = (int64_t)rows * cols_dst;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols_dst;
+        const int c = (int)(i % cols_dst);
+        float v = 0.f;
+        if (c < cols_src) v = src_f32 ? ((const float*)src)[r * lds + c] : (float)((const f16*)src)[r * lds + c];
+        f16* d = dst + r * ldd + c;
+        *d = (f16)(beta ? (float)*d + v : v);
+    }
+}
+extern "C" int vlp_copy2d(const void* src, int64_t lds, int32_t src_f32, void* dst, int64_t ldd, int32_t rows, int32_t cols_src,
+                          int32_t cols_dst, int32_t beta, void* stream) {
+    VLP_CHECK_ARG(src && dst && rows > 0 && cols_src > 0 && cols_dst > 0, "vlp_copy2d: bad args");
+    VLP_CHECK_ARG(lds >= (cols_src < cols_dst ? cols_src : cols_dst) && ldd >= cols_dst, "vlp_copy2d: leading dims");
+    const int64_t total = (int64_t)rows * cols_dst;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(copy2d_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, lds, src_f32, (f16*)dst, ldd, rows,
+                       cols_src < cols_dst ? cols_src : cols_dst, cols_dst, beta);
+    VLP_CHECK_LAUNCH("vlp_copy2d");
+    return VLP_OK;
+}
+
+// dst[c][r] = src[r][c]; 64x64 tiles through LDS; dst columns r in [rows, rows_pad) are zero-filled.
+__global__ __launch_bounds__(256) void transpose_kernel(const f16* __restrict__ src, int64_t lds, f16* __restrict__ dst, int64_t ldd, int rows, int cols, int rows_pad) {
+    __shared__ f16 tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? src[(int64_t)r * lds + c] : (f16)0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows_pad) dst[(int64_t)c * ldd + r] = tile[tx][i];
+    }
+}
+extern "C" int vlp_transpose(const void* src, int64_t lds, void* dst, int64_t ldd, int32_t rows, int32_t cols, int32_t rows_pad, void* stream) {
+    VLP_CHECK_ARG(src && dst && rows > 0 && cols > 0 && rows_pad >= rows && ldd >= rows_pad && lds >= cols, "vlp_transpose: bad args");
+    dim3 grid(cdiv(cols, 64), cdiv(rows_pad, 64));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)src, lds, (f16*)dst, ldd, rows, cols, rows_pad);
+    VLP_CHECK_LAUNCH("vlp_transpose");
+    return VLP_OK;
+}
+
+// =================================================================================================
+// gather / scatter of masked positions (modeling.py:1068-1069) and the VQA fusion (:1044, :1138)
+// =================================================================================================
+__global__ void gather_rows_kernel(const f16* src, int64_t lds, const int64_t* pos, f16* out, int64_t ldo, int B, int P, int L, int H) {
+    const int nch = H >> 3;
+    const int64_t total = (int64_t)B * P * nch;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nch);
+        const int64_t r = i / nch;
+        int64_t ps = pos[r];
+        ps = ps < 0 ? 0 : (ps >= L ? L - 1 : ps);
+        st8(out + r * ldo + c * 8, ld8(src + ((r / P) * L + ps) * lds + c * 8));
+    }
+}
+extern "C" int vlp_gather_rows(const void* src, int64_t lds, const int64_t* pos, void* out, int64_t ldo, int32_t B, int32_t P, int32_t L,
+                               int32_t H, void* stream) {
+    VLP_CHECK_ARG(src && pos && out && B > 0 && P > 0 && L > 0 && H % 8 == 0 && lds % 8 == 0 && ldo % 8 == 0, "vlp_gather_rows: bad args");
+    const int64_t total = (int64_t)B * P * (H / 8);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)src, lds, pos,
+                       (f16*)out, ldo, B, P, L, H);
+    VLP_CHECK_LAUNCH("vlp_gather_rows");
+    return VLP_OK;
+}
+__global__ void scatter_add_rows_kernel(const f16* src, int64_t lds, const int64_t* pos, f16* dst, int64_t ldd, int B, int P, int L, int H) {
+    const int nch = H >> 3;
+    const int64_t total = (int64_t)B * P * nch;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nch);
+        const int64_t r = i / nch;
+        int64_t ps = pos[r];
+        ps = ps < 0 ? 0 : (ps >= L ? L - 1 : ps);
+        const f16x8 v = ld8(src + r * lds + c * 8);
+        __half2* d = reinterpret_cast<__half2*>(dst + ((r / P) * L + ps) * ldd + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(d + e, __floats2half2_rn((float)v[2 * e], (float)v[2 * e + 1]));
+    }
+}
+extern "C" int vlp_scatter_add_rows(const void* src, int64_t lds, const int64_t* pos, void* dst, int64_t ldd, int32_t B, int32_t P, int32_t L,
+                                    int32_t H, void* stream) {
+    VLP_CHECK_ARG(src && pos && dst && B > 0 && P > 0 && L > 0 && H % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0, "vlp_scatter_add_rows: bad args");
+    const int64_t total = (int64_t)B * P * (H / 8);
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)src, lds,
+                       pos, (f16*)dst, ldd, B, P, L, H);
+    VLP_CHECK_LAUNCH("vlp_scatter_add_rows");
+    return VLP_OK;
+}
+
+__global__ void vqa_mul_fwd_kernel(const f16* h, f16* out, int B, int L, int Nv, int H) {
+    const int64_t total = (int64_t)B * H;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / H;
+        const int c = (int)(i % H);
+        const float a0 = (float)h[(b * L) * H + c], a1 = (float)h[(b * L + Nv + 1) * H + c];
+        out[i] = (f16)(a0 * a1);
+    }
+}
+extern "C" int vlp_vqa_mul_fwd(const void* h, void* out, int32_t B, int32_t L, int32_t Nv, int32_t H, void* stream) {
+    VLP_CHECK_ARG(h && out && B > 0 && Nv + 1 < L, "vlp_vqa_mul_fwd: bad args");
+    hipLaunchKernelGGL(vqa_mul_fwd_kernel, dim3(cdiv((int64_t)B * H, 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)h, (f16*)out, B, L, Nv, H);
+    VLP_CHECK_LAUNCH("vlp_vqa_mul_fwd");
+    return VLP_OK;
+}
+// dh[b,0] += dout * h[b,Nv+1];  dh[b,Nv+1] += dout * h[b,0]   (rows are private to this kernel -> plain RMW)
+__global__ void vqa_mul_bwd_kernel(const f16* h, const f16* dout, f16* dh, int B, int L, int Nv, int H) {
+    const int64_t total = (int64_t)B * H;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / H;
+        const int c = (int)(i % H);
+        const int64_t i0 = (b * L) * H + c, i1 = (b * L + Nv + 1) * H + c;
+        const float d = (float)dout[i], a0 = (float)h[i0], a1 = (float)h[i1];
+        dh[i0] = (f16)((float)dh[i0] + d * a1);
+        dh[i1] = (f16)((float)dh[i1] + d * a0);
+    }
+}
+extern "C" int vlp_vqa_mul_bwd(const void* h, const void* dout, void* dh, int32_t B, int32_t L, int32_t Nv, int32_t H, void* stream) {
+    VLP_CHECK_ARG(h && dout && dh && B > 0 && Nv + 1 < L, "vlp_vqa_mul_bwd: bad args");
+    hipLaunchKernelGGL(vqa_mul_bwd_kernel, dim3(cdiv((int64_t)B * H, 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)h, (const f16*)dout,
+                       (f16*)dh, B, L, Nv, H);
+    VLP_CHECK_LAUNCH("vlp_vqa_mul_bwd");
+    return VLP_OK;
+}
+
+// dz = dy * dropmask * (y > 0), idx = row*ncols + col (the forward GEMM epilogue's index)
+__global__ void relu_dropout_bwd_kernel(const f16* dy, const f16* y, f16* dz, int64_t n8, int64_t ncols, DropCtx d) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const f16x8 g = ld8(dy + i * 8), yv = ld8(y + i * 8);
+        const int64_t row = (i * 8) / ncols;
+        const uint32_t col0 = (uint32_t)((i * 8) % ncols);
+        const uint32_t rk = d.thresh ? drop_rowkey(d, (uint64_t)row) : 0u;
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = ((float)yv[e] > 0.f) ? (float)g[e] : 0.f;
+            if (d.thresh) v *= drop_mult(d, rk, col0 + (uint32_t)e);
+            o[e] = (f16)v;
+        }
+        st8(dz + i * 8, o);
+    }
+}
+extern "C" int vlp_relu_dropout_bwd(const void* dy, const void* y, void* dz, int64_t n, int64_t ncols, float drop_p, uint64_t seed,
+                                    uint32_t rng_stream, void* stream) {
+    VLP_CHECK_ARG(dy && y && dz && n > 0 && ncols > 0 && ncols % 8 == 0 && n % ncols == 0, "vlp_relu_dropout_bwd: contiguous [rows, ncols], ncols % 8 == 0");
+    int blocks = (int)((n / 8 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)dy, (const f16*)y, (f16*)dz, n / 8, ncols,
+                       make_drop(drop_p, seed, rng_stream));
+    VLP_CHECK_LAUNCH("vlp_relu_dropout_bwd");
+    return VLP_OK;
+}

@@ -1,0 +1,299 @@
+// NT GEMM with fused epilogue for gfx950:   Y[M,N] = epi( alpha * X[M,K] . W[N,K]^T )
+//
+// Replaces (reference): every nn.Linear forward on the hot path and, with a transposed weight
+// shadow as W, every dgrad:  modeling.py:270-272 (QKV), :314 (attn out), :341 (FFN up + gelu :62-67),
+// :354 (FFN down), :432 (head transform), :481 (tied decoder), :1003-1005 (fc7 + region proj),
+// :1016 (box/class proj), :1027-1029 (VQA classifier), plus dropout/residual (:315-316, :355-356).
+//
+// Design (CDNA4): 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 4x4 v_mfma_f32_16x16x32_f16
+// tiles, fp32 accumulate.  The MFMA "A" operand is fed from W rows and the "B" operand from X rows,
+// i.e. the instruction computes Y^T tiles: in the C/D layout (col = lane&15, row = 4*(lane>>4)+reg) a
+// lane then owns ONE output row m and FOUR consecutive n per tile; with the W rows of the wave's 64-row
+// sub-tile visited in the permuted order  n = 16*(i>>2) + 4*tn + (i&3)  the 4 tiles x 4 regs of a lane
+// are 16 *consecutive* n, so bias / residual / gelu'() inputs are read and Y is written as 16-byte
+// vectors straight from registers -- no LDS round trip in the epilogue.
+// LDS tiles are [128 rows][64 halfs] (128-B rows) with a 16-B-chunk XOR swizzle chosen per operand so
+// that every ds_read_b128 lane group of the fragment reads touches 16 distinct 16-B slots.
+// Staging: VARIANT 0 = global_load_dwordx4 -> VGPR -> ds_write_b128 (issued before / written after the
+// MFMA block of the current tile), VARIANT 1 = global_load_lds_dwordx4 (LDS-DMA; the swizzle is applied
+// to the per-lane SOURCE address because the LDS destination is lane-linear).
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define NTHREADS 256
+
+struct GemmNtParams {
+    const f16* X; int64_t ldx;
+    const f16* W; int64_t ldw;
+    f16* Y; int64_t ldy;
+    const f16* bias;
+    const f16* residual; int64_t ldr;
+    f16* preact; int64_t ldp;
+    const f16* mulsrc; int64_t ldm;
+    int M, N, K;
+    int act;       // VLP_ACT_*
+    int mulmode;   // VLP_MUL_*
+    float alpha;
+    DropCtx drop;
+    int tiles_n;
+};
+
+DEVFN int swz_x(int r) { return r & 7; }
+DEVFN int swz_w(int r) { return (((r >> 4) & 3) << 1) | ((r >> 1) & 1); }
+
+template <int VARIANT>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmNtParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    f16* smem = reinterpret_cast<f16*>(smem_raw);
+    // layout: [buf][ X tile 128*64 | W tile 128*64 ]
+    const int TILE = BM * BK;            // halfs
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int g = lane >> 4, li = lane & 15;
+
+    const int tile_m = blockIdx.x / p.tiles_n;
+    const int tile_n = blockIdx.x % p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- staging geometry: thread -> (row, physical chunk) for 4 passes -------------------------
+    const int srow = tid >> 3;        // 0..31 (+32*i)
+    const int sx = tid & 7;           // physical 16-B chunk inside the 128-B LDS row
+    const f16* xsrc[4];
+    const f16* wsrc[4];
+    int lds_off[4];                   // halfs, inside a tile (register-staged writes)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = srow + 32 * i;
+        int mr = min(m0 + r, p.M - 1);
+        int nr = min(n0 + r, p.N - 1);
+        // logical chunk held at physical slot sx of row r
+        int cx = sx ^ swz_x(r);
+        int cw = sx ^ swz_w(r);
+        xsrc[i] = p.X + (int64_t)mr * p.ldx + cx * 8;
+        wsrc[i] = p.W + (int64_t)nr * p.ldw + cw * 8;
+        lds_off[i] = r * BK + sx * 8;
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+
+    // fragment read offsets (halfs) inside a tile, per tile index and k-step
+    // X tile (natural rows): row = wm*64 + 16*tm + li ; W tile (permuted rows): row = wn*64 + 16*(li>>2) + 4*tn + (li&3)
+    int xrow[4], wrow[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        xrow[t] = wm * 64 + 16 * t + li;
+        wrow[t] = wn * 64 + 16 * (li >> 2) + 4 * t + (li & 3);
+    }
+
+    u32x4 xreg[4], wreg[4];
+
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xreg[i] = *reinterpret_cast<const u32x4*>(xsrc[i] + (int64_t)kt * BK);
+            wreg[i] = *reinterpret_cast<const u32x4*>(wsrc[i] + (int64_t)kt * BK);
+        }
+    };
+    auto lstore = [&](int buf) {
+        f16* xs = smem + buf * 2 * TILE;
+        f16* ws = xs + TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(xs + lds_off[i]) = xreg[i];
+            *reinterpret_cast<u32x4*>(ws + lds_off[i]) = wreg[i];
+        }
+    };
+    auto glds = [&](int kt, int buf) {
+        // LDS-DMA: destination = wave-uniform base + lane*16 B.  Pass i covers LDS rows 32*i..32*i+31;
+        // this wave's 64 lanes cover rows 32*i + 8*wid .. +7 (8 lanes per 128-B row).
+        f16* xs = smem + buf * 2 * TILE;
+        f16* ws = xs + TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int base = (32 * i + 8 * wid) * BK;   // halfs, wave-uniform
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(xsrc[i] + (int64_t)kt * BK),
+                (__attribute__((address_space(3))) void*)(xs + base), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(wsrc[i] + (int64_t)kt * BK),
+                (__attribute__((address_space(3))) void*)(ws + base), 16, 0, 0);
+        }
+    };
+    auto compute = [&](int buf) {
+        const f16* xs = smem + buf * 2 * TILE;
+        const f16* ws = xs + TILE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int c = ks * 4 + g;
+            f16x8 xf[4], wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                xf[t] = ld8(xs + xrow[t] * BK + ((c ^ swz_x(xrow[t])) << 3));
+                wf[t] = ld8(ws + wrow[t] * BK + ((c ^ swz_w(wrow[t])) << 3));
+            }
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], acc[tm][tn], 0, 0, 0);
+        }
+    };
+
+    if (VARIANT == 0) {
+        gload(0);
+        lstore(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) gload(kt + 1);
+            compute(buf);
+            if (kt + 1 < nk) lstore(buf ^ 1);
+            __syncthreads();
+        }
+    } else {
+        glds(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) glds(kt + 1, buf ^ 1);
+            compute(buf);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: lane owns row m (per tm) and 16 consecutive n -------------------------------
+    const int ncol0 = n0 + wn * 64 + 16 * g;
+    const bool full_n = (ncol0 + 16 <= p.N);
+    float bias_v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bias_v[j] = 0.f;
+    if (p.bias) {
+        if (full_n) {
+            f16x8 b0 = ld8(p.bias + ncol0), b1 = ld8(p.bias + ncol0 + 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { bias_v[j] = (float)b0[j]; bias_v[8 + j] = (float)b1[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) if (ncol0 + j < p.N) bias_v[j] = (float)p.bias[ncol0 + j];
+        }
+    }
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+        const int m = m0 + wm * 64 + 16 * tm + li;
+        if (m >= p.M) continue;
+        const uint32_t rkey = p.drop.thresh ? drop_rowkey(p.drop, (uint64_t)m) : 0u;   // dropout element = (row m, col n)
+        float v[16];
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[tn * 4 + r] = acc[tm][tn][r] * p.alpha + bias_v[tn * 4 + r];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {            // two 8-wide vectors
+            const int nc = ncol0 + 8 * h;
+            if (nc >= p.N) continue;
+            float* vv = v + 8 * h;
+            if (p.preact) {
+                f16x8 z;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) z[j] = (nc + j < p.N) ? (f16)vv[j] : (f16)0.f;
+                st8(p.preact + (int64_t)m * p.ldp + nc, z);
+                // keep forward/backward consistent: the activation sees the fp16-rounded pre-activation
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vv[j] = (float)z[j];
+            }
+            if (p.act == VLP_ACT_GELU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vv[j] = gelu_f(vv[j]);
+            } else if (p.act == VLP_ACT_RELU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vv[j] = fmaxf(vv[j], 0.f);
+            } else if (p.act == VLP_ACT_TANH) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vv[j] = tanhf(vv[j]);
+            }
+            if (p.mulmode != VLP_MUL_NONE) {
+                f16x8 s = ld8(p.mulsrc + (int64_t)m * p.ldm + nc);
+                if (p.mulmode == VLP_MUL_GELU_GRAD) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) vv[j] *= gelu_grad_f((float)s[j]);
+                } else {   // VLP_MUL_RELU_MASK
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) vv[j] = ((float)s[j] > 0.f) ? vv[j] : 0.f;
+                }
+            }
+            if (p.drop.thresh) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vv[j] *= drop_mult(p.drop, rkey, (uint32_t)(nc + j));
+            }
+            if (p.residual) {
+                f16x8 r = ld8(p.residual + (int64_t)m * p.ldr + nc);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vv[j] += (float)r[j];
+            }
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (nc + j < p.N) ? (f16)vv[j] : (f16)0.f;
+            st8(p.Y + (int64_t)m * p.ldy + nc, o);
+        }
+    }
+}
+
+extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
+    VLP_CHECK_ARG(a != nullptr, "vlp_gemm_nt: null args");
+    VLP_CHECK_ARG(a->X && a->W && a->Y, "vlp_gemm_nt: null operand");
+    VLP_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "vlp_gemm_nt: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
+    VLP_CHECK_ARG(a->K % BK == 0, "vlp_gemm_nt: K=%d must be a multiple of %d (pad with vlp_copy2d)", a->K, BK);
+    VLP_CHECK_ARG(a->ldx % 8 == 0 && a->ldw % 8 == 0 && a->ldy % 8 == 0, "vlp_gemm_nt: leading dims must be multiples of 8 halfs");
+    VLP_CHECK_ARG(a->ldx >= a->K && a->ldw >= a->K, "vlp_gemm_nt: ldx/ldw < K");
+    const int n8 = (a->N + 7) / 8 * 8;
+    VLP_CHECK_ARG(a->ldy >= n8, "vlp_gemm_nt: ldy=%lld < roundup8(N)=%d", (long long)a->ldy, n8);
+    VLP_CHECK_ARG(((uintptr_t)a->X | (uintptr_t)a->W | (uintptr_t)a->Y) % 16 == 0, "vlp_gemm_nt: operands must be 16-byte aligned");
+    if (a->residual) VLP_CHECK_ARG(a->ldr % 8 == 0 && a->ldr >= n8 && (uintptr_t)a->residual % 16 == 0, "vlp_gemm_nt: bad residual layout");
+    if (a->preact) VLP_CHECK_ARG(a->ldp % 8 == 0 && a->ldp >= n8 && (uintptr_t)a->preact % 16 == 0, "vlp_gemm_nt: bad preact layout");
+    if (a->mul_mode != VLP_MUL_NONE)
+        VLP_CHECK_ARG(a->mul_src && a->ldm % 8 == 0 && a->ldm >= n8 && (uintptr_t)a->mul_src % 16 == 0, "vlp_gemm_nt: bad mul_src layout");
+    if (a->bias) VLP_CHECK_ARG((uintptr_t)a->bias % 16 == 0, "vlp_gemm_nt: bias must be 16-byte aligned");
+    VLP_CHECK_ARG(a->act >= VLP_ACT_NONE && a->act <= VLP_ACT_TANH, "vlp_gemm_nt: bad act %d", a->act);
+    VLP_CHECK_ARG(a->dropout_p >= 0.f && a->dropout_p < 1.f, "vlp_gemm_nt: bad dropout p");
+
+    GemmNtParams p;
+    p.X = (const f16*)a->X; p.ldx = a->ldx;
+    p.W = (const f16*)a->W; p.ldw = a->ldw;
+    p.Y = (f16*)a->Y; p.ldy = a->ldy;
+    p.bias = (const f16*)a->bias;
+    p.residual = (const f16*)a->residual; p.ldr = a->ldr;
+    p.preact = (f16*)a->preact; p.ldp = a->ldp;
+    p.mulsrc = (const f16*)a->mul_src; p.ldm = a->ldm;
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.act = a->act; p.mulmode = a->mul_mode;
+    p.alpha = a->alpha;
+    p.drop = make_drop(a->dropout_p, a->seed, a->rng_stream);
+    p.tiles_n = cdiv(a->N, BN);
+    const int tiles_m = cdiv(a->M, BM);
+    dim3 grid(tiles_m * p.tiles_n), block(NTHREADS);
+    const size_t smem = 2 * 2 * BM * BK * sizeof(f16);   // 64 KiB
+    hipStream_t s = (hipStream_t)stream;
+    if (a->variant == 1) {
+        static bool attr1 = false;
+        if (!attr1) { hipFuncSetAttribute((const void*)gemm_nt_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr1 = true; }
+        hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, block, smem, s, p);
+    } else {
+        static bool attr0 = false;
+        if (!attr0) { hipFuncSetAttribute((const void*)gemm_nt_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr0 = true; }
+        hipLaunchKernelGGL(gemm_nt_kernel<0>, grid, block, smem, s, p);
+    }
+    VLP_CHECK_LAUNCH("vlp_gemm_nt");
+    return VLP_OK;
+}

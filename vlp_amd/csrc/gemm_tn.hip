@@ -1,0 +1,260 @@
+// TN GEMM (weight gradients) for gfx950:   dW[N,K] (+)= dY[M,N]^T . X[M,K]
+//
+// Replaces autograd's LinearBackward weight-gradient GEMMs of every nn.Linear on the reference's hot
+// path (modeling.py:270-272, 314, 341, 354, 432, 481, 1003-1005, 1016, 1027-1029).
+//
+// Both operands are stored with the contraction index (token row m) as the SLOW dimension, so MFMA
+// fragments (8 consecutive contraction values per lane) are column gathers.  Tiles are staged row-major
+// [64 m][128 cols] in LDS exactly as they lie in HBM (16-byte coalesced loads), and fragments are read
+//   VARIANT 1: with ds_read_b64_tr_b16 (CDNA4 LDS transpose read: a 16-lane group reads a [4 m][16 col]
+//              block, lane s supplying the 8-byte piece (row s>>2, cols 4*(s&3)..+3) and receiving
+//              column s) -- two reads per 16x16x32 fragment;
+//   VARIANT 0: with eight scalar 16-bit LDS reads (slow but layout-obvious; kept as the cross-check).
+// The MFMA "A" operand is fed from X columns (k) and "B" from dY columns (n): in the C/D layout a lane
+// then owns one output row n and, with the permuted column order  k = 16*(i>>2) + 4*tk + (i&3), sixteen
+// consecutive k -> 16-byte stores.  M is split across blockIdx.z; partial products go to fp32 slabs
+// that a second kernel reduces (deterministic, no atomics) and converts to fp16 (+= when beta = 1).
+#include "common.h"
+
+#define TN_BN 128     // output rows (n) per block
+#define TN_BK 128     // output cols (k) per block
+#define TN_BM 64      // contraction rows per stage
+#define TN_THREADS 256
+#define TN_PITCH (128 + 8)   // halfs; +16 B pad per LDS row
+
+struct GemmTnParams {
+    const f16* A; int64_t lda;   // dY [M,N]
+    const f16* B; int64_t ldb;   // X  [M,K]
+    f16* C; int64_t ldc;         // [N,K]
+    float* slab;                 // [splits][N][K] fp32 (when splits > 1)
+    int M, N, K, beta, splits, rows_per_split;
+};
+
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+DEVFN f16x4 lds_tr_read(const f16* p) {
+    fp16x4_t t = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(p));
+    return __builtin_bit_cast(f16x4, t);
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(GemmTnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    f16* smem = reinterpret_cast<f16*>(smem_raw);
+    const int TILE = TN_BM * TN_PITCH;   // halfs
+    // layout: [buf][ A tile | B tile ]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wid >> 1, wk = wid & 1;
+    const int g = lane >> 4, li = lane & 15;
+
+    const int n0 = blockIdx.y * TN_BN;
+    const int k0 = blockIdx.x * TN_BK;
+    const int m_begin = blockIdx.z * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+    const int nstages = (m_end - m_begin + TN_BM - 1) / TN_BM;
+
+    // staging: thread -> (row = tid/16 + 16*i, chunk = tid%16)
+    const int srow = tid >> 4, sch = tid & 15;
+    const bool a_ok = (n0 + sch * 8) < p.N;   // chunk start inside the logical width (lda >= roundup8(N))
+    const bool b_ok = (k0 + sch * 8) < p.K;
+
+    f32x4 acc[4][4];   // [tn][tk]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    u32x4 areg[4], breg[4];
+    auto gload = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m_begin + st * TN_BM + srow + 16 * i;
+            const bool ok = m < m_end;
+            areg[i] = (ok && a_ok) ? *reinterpret_cast<const u32x4*>(p.A + (int64_t)m * p.lda + n0 + sch * 8) : (u32x4){0, 0, 0, 0};
+            breg[i] = (ok && b_ok) ? *reinterpret_cast<const u32x4*>(p.B + (int64_t)m * p.ldb + k0 + sch * 8) : (u32x4){0, 0, 0, 0};
+        }
+    };
+    auto lstore = [&](int buf) {
+        f16* as = smem + buf * 2 * TILE;
+        f16* bs = as + TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = srow + 16 * i;
+            *reinterpret_cast<u32x4*>(as + r * TN_PITCH + sch * 8) = areg[i];
+            *reinterpret_cast<u32x4*>(bs + r * TN_PITCH + sch * 8) = breg[i];
+        }
+    };
+    auto compute = [&](int buf) {
+        const f16* as = smem + buf * 2 * TILE;   // dY tile [m][n]
+        const f16* bs = as + TILE;               // X tile  [m][k]
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) {
+            const int mrow = ms * 32 + 8 * g;     // this lane group's 8 contraction rows
+            f16x8 xf[4], yf[4];
+            if (VARIANT == 1) {
+                // lane s = li supplies piece (row s>>2, 4 cols at 4*(s&3) [+ permutation]) and receives column s
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const f16* px = bs + (mrow + (li >> 2)) * TN_PITCH + wk * 64 + 16 * (li & 3) + 4 * t;
+                    const f16* py = as + (mrow + (li >> 2)) * TN_PITCH + wn * 64 + 16 * t + 4 * (li & 3);
+                    f16x4 x0 = lds_tr_read(px), x1 = lds_tr_read(px + 4 * TN_PITCH);
+                    f16x4 y0 = lds_tr_read(py), y1 = lds_tr_read(py + 4 * TN_PITCH);
+                    xf[t] = (f16x8){x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+                    yf[t] = (f16x8){y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int xc = wk * 64 + 16 * (li >> 2) + 4 * t + (li & 3);
+                    const int yc = wn * 64 + 16 * t + li;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        xf[t][e] = bs[(mrow + e) * TN_PITCH + xc];
+                        yf[t][e] = as[(mrow + e) * TN_PITCH + yc];
+                    }
+                }
+            }
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tk = 0; tk < 4; ++tk)
+                    acc[tn][tk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[tk], yf[tn], acc[tn][tk], 0, 0, 0);
+        }
+    };
+
+    if (nstages > 0) {
+        gload(0);
+        lstore(0);
+        __syncthreads();
+        for (int st = 0; st < nstages; ++st) {
+            const int buf = st & 1;
+            if (st + 1 < nstages) gload(st + 1);
+            compute(buf);
+            if (st + 1 < nstages) lstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: lane owns row n (per tn) and 16 consecutive k starting at kc0
+    const int kc0 = k0 + wk * 64 + 16 * g;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+        const int n = n0 + wn * 64 + 16 * tn + li;
+        if (n >= p.N) continue;
+        if (p.splits > 1) {
+            float* dst = p.slab + ((int64_t)blockIdx.z * p.N + n) * p.K + kc0;
+#pragma unroll
+            for (int tk = 0; tk < 4; ++tk)
+                if (kc0 + 4 * tk < p.K) *reinterpret_cast<f32x4*>(dst + 4 * tk) = acc[tn][tk];
+        } else {
+            f16* dst = p.C + (int64_t)n * p.ldc + kc0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (kc0 + 8 * h >= p.K) continue;
+                f16x8 o;
+                if (p.beta) o = ld8(dst + 8 * h);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float v = acc[tn][2 * h + (j >> 2)][j & 3];
+                    o[j] = (f16)(p.beta ? (float)o[j] + v : v);
+                }
+                st8(dst + 8 * h, o);
+            }
+        }
+    }
+}
+
+// out[n,k] = (beta ? out : 0) + sum_s slab[s][n][k]
+__global__ void gemm_tn_reduce_kernel(const float* slab, f16* C, int64_t ldc, int N, int K, int splits, int beta) {
+    const int64_t total8 = (int64_t)N * (K / 8);
+    const int64_t stride = (int64_t)N * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / (K / 8));
+        const int k = (int)(i % (K / 8)) * 8;
+        const float* s = slab + (int64_t)n * K + k;
+        float v[8];
+        f32x4 a0 = *reinterpret_cast<const f32x4*>(s), a1 = *reinterpret_cast<const f32x4*>(s + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = a0[j]; v[4 + j] = a1[j]; }
+        for (int sp = 1; sp < splits; ++sp) {
+            a0 = *reinterpret_cast<const f32x4*>(s + sp * stride);
+            a1 = *reinterpret_cast<const f32x4*>(s + sp * stride + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] += a0[j]; v[4 + j] += a1[j]; }
+        }
+        f16* dst = C + (int64_t)n * ldc + k;
+        f16x8 o;
+        if (beta) o = ld8(dst);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)(beta ? (float)o[j] + v[j] : v[j]);
+        st8(dst, o);
+    }
+}
+
+static int choose_splits(int M, int N, int K) {
+    const int tiles = cdiv(N, TN_BN) * cdiv(K, TN_BK);
+    int s = cdiv(512, tiles);                // aim for >= 2 workgroups per CU
+    const int max_by_rows = M / 256 > 0 ? M / 256 : 1;
+    if (s > max_by_rows) s = max_by_rows;
+    if (s > 16) s = 16;
+    if (s < 1) s = 1;
+    return s;
+}
+
+extern "C" int64_t vlp_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K) {
+    const int s = 16;   // upper bound of choose_splits / explicit splits
+    (void)M;
+    return (int64_t)s * N * K * (int64_t)sizeof(float);
+}
+
+extern "C" int vlp_gemm_tn(const vlp_gemm_tn_args* a, void* stream) {
+    VLP_CHECK_ARG(a != nullptr, "vlp_gemm_tn: null args");
+    VLP_CHECK_ARG(a->A && a->B && a->C, "vlp_gemm_tn: null operand");
+    VLP_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "vlp_gemm_tn: bad shape");
+    VLP_CHECK_ARG(a->K % 8 == 0, "vlp_gemm_tn: K=%d must be a multiple of 8", a->K);
+    VLP_CHECK_ARG(a->lda % 8 == 0 && a->ldb % 8 == 0 && a->ldc % 8 == 0, "vlp_gemm_tn: leading dims must be multiples of 8");
+    VLP_CHECK_ARG(a->lda >= (a->N + 7) / 8 * 8 && a->ldb >= a->K && a->ldc >= a->K, "vlp_gemm_tn: leading dim too small");
+    VLP_CHECK_ARG(((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) % 16 == 0, "vlp_gemm_tn: operands must be 16-byte aligned");
+    VLP_CHECK_ARG(a->beta == 0 || a->beta == 1, "vlp_gemm_tn: beta must be 0 or 1");
+    int splits = a->splits > 0 ? a->splits : choose_splits(a->M, a->N, a->K);
+    if (splits > 16) splits = 16;
+    GemmTnParams p;
+    p.A = (const f16*)a->A; p.lda = a->lda;
+    p.B = (const f16*)a->B; p.ldb = a->ldb;
+    p.C = (f16*)a->C; p.ldc = a->ldc;
+    p.M = a->M; p.N = a->N; p.K = a->K; p.beta = a->beta;
+    int rps = cdiv(a->M, splits);
+    rps = (rps + TN_BM - 1) / TN_BM * TN_BM;
+    splits = cdiv(a->M, rps);
+    p.splits = splits; p.rows_per_split = rps;
+    p.slab = (float*)a->workspace;
+    if (splits > 1) {
+        const int64_t need = (int64_t)splits * a->N * a->K * (int64_t)sizeof(float);
+        if (!a->workspace || a->workspace_bytes < need)
+            return vlp_set_error(VLP_ERR_WORKSPACE, "vlp_gemm_tn: workspace %lld < %lld bytes", (long long)a->workspace_bytes, (long long)need);
+        VLP_CHECK_ARG((uintptr_t)a->workspace % 16 == 0, "vlp_gemm_tn: workspace must be 16-byte aligned");
+    }
+    dim3 grid(cdiv(a->K, TN_BK), cdiv(a->N, TN_BN), splits), block(TN_THREADS);
+    const size_t smem = 2 * 2 * TN_BM * TN_PITCH * sizeof(f16);   // 68 KiB
+    hipStream_t s = (hipStream_t)stream;
+    if (a->variant == 1) {
+        static bool attr1 = false;
+        if (!attr1) { hipFuncSetAttribute((const void*)gemm_tn_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr1 = true; }
+        hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, block, smem, s, p);
+    } else {
+        static bool attr0 = false;
+        if (!attr0) { hipFuncSetAttribute((const void*)gemm_tn_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr0 = true; }
+        hipLaunchKernelGGL(gemm_tn_kernel<0>, grid, block, smem, s, p);
+    }
+    VLP_CHECK_LAUNCH("vlp_gemm_tn");
+    if (splits > 1) {
+        const int64_t total8 = (int64_t)a->N * (a->K / 8);
+        int blocks = (int)((total8 + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, p.C, p.ldc, a->N, a->K, splits, a->beta);
+        VLP_CHECK_LAUNCH("vlp_gemm_tn_reduce");
+    }
+    return VLP_OK;
+}

@@ -1,0 +1,270 @@
+// LayerNorm forward / backward and column sums (bias gradients) for gfx950.  HBM-bound kernels:
+// 16-byte vector loads, one wave per row, fp32 statistics, two-pass variance from registers.
+//
+// Replaces BertLayerNorm = apex FusedLayerNorm / the python fallback (modeling.py:174-192; used at
+// :214,239 embeddings, :310,316 attention output, :350,356 FFN output, :429,434 head transform) and
+// the dropout that follows the embedding LayerNorm (:240); backward replaces their autograd plus the
+// SumBackward of every broadcast bias add.
+#include "common.h"
+
+#define LN_THREADS 256
+#define LN_WAVES 4
+
+template <int MAXJ>   // per-lane chunks of 8 halfs: H <= 512*MAXJ
+__global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(
+    const f16* __restrict__ x, int64_t ldx, const f16* __restrict__ gamma, const f16* __restrict__ beta,
+    f16* __restrict__ y, int64_t ldy, float* __restrict__ mean, float* __restrict__ rstd, int M, int H, float eps, DropCtx drop) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * LN_WAVES;
+    const int nch = H >> 3;
+    const float invH = 1.f / (float)H;
+    for (int row = wave; row < M; row += nwaves) {
+        const f16* xr = x + (int64_t)row * ldx;
+        float v[MAXJ][8];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int c = lane + 64 * j;
+            if (c < nch) {
+                f16x8 t = ld8(xr + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[j][e] = (float)t[e]; s += v[j][e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+            }
+        }
+        const float mu = wave_sum(s) * invH;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j)
+            if (lane + 64 * j < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[j][e] - mu; q += d * d; }
+            }
+        const float var = wave_sum(q) * invH;
+        const float rs = 1.f / sqrtf(var + eps);
+        if (lane == 0) {
+            if (mean) mean[row] = mu;
+            if (rstd) rstd[row] = rs;
+        }
+        f16* yr = y + (int64_t)row * ldy;
+        const uint32_t rkey = drop.thresh ? drop_rowkey(drop, (uint64_t)row) : 0u;   // dropout element = (row, col)
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int c = lane + 64 * j;
+            if (c < nch) {
+                f16x8 gv = ld8(gamma + c * 8), bv = ld8(beta + c * 8), o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t = (float)gv[e] * ((v[j][e] - mu) * rs) + (float)bv[e];
+                    if (drop.thresh) t *= drop_mult(drop, rkey, (uint32_t)(c * 8 + e));
+                    o[e] = (f16)t;
+                }
+                st8(yr + c * 8, o);
+            }
+        }
+    }
+}
+
+extern "C" int vlp_layernorm_fwd(const vlp_layernorm_fwd_args* a, void* stream) {
+    VLP_CHECK_ARG(a && a->x && a->gamma && a->beta && a->y, "vlp_layernorm_fwd: null operand");
+    VLP_CHECK_ARG(a->M > 0 && a->H > 0 && a->H % 8 == 0 && a->H <= 4096, "vlp_layernorm_fwd: H=%d must be a multiple of 8 and <= 4096", a->H);
+    VLP_CHECK_ARG(a->ldx % 8 == 0 && a->ldy % 8 == 0 && a->ldx >= a->H && a->ldy >= a->H, "vlp_layernorm_fwd: leading dims");
+    VLP_CHECK_ARG(((uintptr_t)a->x | (uintptr_t)a->y | (uintptr_t)a->gamma | (uintptr_t)a->beta) % 16 == 0, "vlp_layernorm_fwd: alignment");
+    DropCtx d = make_drop(a->dropout_p, a->seed, a->rng_stream);
+    int blocks = cdiv(a->M, LN_WAVES);
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t s = (hipStream_t)stream;
+    if (a->H <= 1024)
+        hipLaunchKernelGGL(layernorm_fwd_kernel<2>, dim3(blocks), dim3(LN_THREADS), 0, s, (const f16*)a->x, a->ldx, (const f16*)a->gamma,
+                           (const f16*)a->beta, (f16*)a->y, a->ldy, a->mean, a->rstd, a->M, a->H, a->eps, d);
+    else
+        hipLaunchKernelGGL(layernorm_fwd_kernel<8>, dim3(blocks), dim3(LN_THREADS), 0, s, (const f16*)a->x, a->ldx, (const f16*)a->gamma,
+                           (const f16*)a->beta, (f16*)a->y, a->ldy, a->mean, a->rstd, a->M, a->H, a->eps, d);
+    VLP_CHECK_LAUNCH("vlp_layernorm_fwd");
+    return VLP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward.  Each wave walks rows (grid-stride) keeping per-column partial sums of dgamma / dbeta in
+// registers; partials [nwaves][2][H] go to the workspace and a second kernel reduces them.
+// ---------------------------------------------------------------------------------------------
+#define LNB_BLOCKS 256
+
+template <int MAXJ>
+__global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(
+    const f16* __restrict__ dy, int64_t lddy, const f16* __restrict__ x, int64_t ldx, const f16* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ rstd, f16* __restrict__ dx, int64_t lddx,
+    f16* __restrict__ dxd, int64_t lddxd, float* __restrict__ part, int M, int H, DropCtx dyd, DropCtx outd) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * LN_WAVES;
+    const int nch = H >> 3;
+    const float invH = 1.f / (float)H;
+    float g[MAXJ][8], dg[MAXJ][8], db[MAXJ][8];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        const int c = lane + 64 * j;
+        f16x8 gv = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (c < nch) gv = ld8(gamma + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { g[j][e] = (float)gv[e]; dg[j][e] = 0.f; db[j][e] = 0.f; }
+    }
+    for (int row = wave; row < M; row += nwaves) {
+        const float mu = mean[row], rs = rstd[row];
+        const uint32_t rk_dy = dyd.thresh ? drop_rowkey(dyd, (uint64_t)row) : 0u;
+        const uint32_t rk_out = outd.thresh ? drop_rowkey(outd, (uint64_t)row) : 0u;
+        float xh[MAXJ][8], d[MAXJ][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int c = lane + 64 * j;
+            if (c < nch) {
+                f16x8 xv = ld8(x + (int64_t)row * ldx + c * 8);
+                f16x8 dv = ld8(dy + (int64_t)row * lddy + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float dd = (float)dv[e];
+                    if (dyd.thresh) dd *= drop_mult(dyd, rk_dy, (uint32_t)(c * 8 + e));
+                    xh[j][e] = ((float)xv[e] - mu) * rs;
+                    dg[j][e] += dd * xh[j][e];
+                    db[j][e] += dd;
+                    d[j][e] = dd * g[j][e];
+                    s1 += d[j][e];
+                    s2 += d[j][e] * xh[j][e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { xh[j][e] = 0.f; d[j][e] = 0.f; }
+            }
+        }
+        s1 = wave_sum(s1) * invH;
+        s2 = wave_sum(s2) * invH;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int c = lane + 64 * j;
+            if (c < nch) {
+                f16x8 o, od;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float t = rs * (d[j][e] - s1 - xh[j][e] * s2);
+                    o[e] = (f16)t;
+                    if (dxd) od[e] = (f16)(t * drop_mult(outd, rk_out, (uint32_t)(c * 8 + e)));
+                }
+                st8(dx + (int64_t)row * lddx + c * 8, o);
+                if (dxd) st8(dxd + (int64_t)row * lddxd + c * 8, od);
+            }
+        }
+    }
+    float* pg = part + (int64_t)wave * 2 * H;
+    float* pb = pg + H;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { pg[c * 8 + e] = dg[j][e]; pb[c * 8 + e] = db[j][e]; }
+        }
+    }
+}
+
+// out[0..H) = dgamma, out[H..2H) = dbeta from part[nparts][2H]
+__global__ void ln_bwd_reduce_kernel(const float* __restrict__ part, int nparts, int H, f16* dgamma, f16* dbeta, int beta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // 0..2H
+    if (i >= 2 * H) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * 2 * H + i];
+    f16* dst = i < H ? dgamma + i : dbeta + (i - H);
+    *dst = (f16)(beta ? (float)*dst + s : s);
+}
+
+extern "C" int64_t vlp_layernorm_bwd_workspace_bytes(int32_t H) {
+    return (int64_t)LNB_BLOCKS * LN_WAVES * 2 * H * (int64_t)sizeof(float);
+}
+
+extern "C" int vlp_layernorm_bwd(const vlp_layernorm_bwd_args* a, void* stream) {
+    VLP_CHECK_ARG(a && a->dy && a->x && a->gamma && a->mean && a->rstd && a->dx && a->dgamma && a->dbeta, "vlp_layernorm_bwd: null operand");
+    VLP_CHECK_ARG(a->M > 0 && a->H > 0 && a->H % 8 == 0 && a->H <= 4096, "vlp_layernorm_bwd: bad H=%d", a->H);
+    VLP_CHECK_ARG(a->lddy % 8 == 0 && a->ldx % 8 == 0 && a->lddx % 8 == 0, "vlp_layernorm_bwd: leading dims");
+    VLP_CHECK_ARG(((uintptr_t)a->dy | (uintptr_t)a->x | (uintptr_t)a->dx | (uintptr_t)a->gamma) % 16 == 0, "vlp_layernorm_bwd: alignment");
+    if (a->dx_drop) VLP_CHECK_ARG(a->lddxd % 8 == 0 && (uintptr_t)a->dx_drop % 16 == 0 && a->out_drop_p > 0.f, "vlp_layernorm_bwd: dx_drop needs out_drop_p > 0");
+    const int64_t need = vlp_layernorm_bwd_workspace_bytes(a->H);
+    if (!a->workspace || a->workspace_bytes < need) return vlp_set_error(VLP_ERR_WORKSPACE, "vlp_layernorm_bwd: workspace %lld < %lld", (long long)a->workspace_bytes, (long long)need);
+    DropCtx dyd = make_drop(a->dy_drop_p, a->dy_seed, a->dy_stream);
+    DropCtx outd = make_drop(a->out_drop_p, a->out_seed, a->out_stream);
+    int blocks = cdiv(a->M, LN_WAVES);
+    if (blocks > LNB_BLOCKS) blocks = LNB_BLOCKS;
+    hipStream_t s = (hipStream_t)stream;
+    float* part = (float*)a->workspace;
+    if (a->H <= 1024)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(LN_THREADS), 0, s, (const f16*)a->dy, a->lddy, (const f16*)a->x, a->ldx,
+                           (const f16*)a->gamma, a->mean, a->rstd, (f16*)a->dx, a->lddx, (f16*)a->dx_drop, a->lddxd, part, a->M, a->H, dyd, outd);
+    else
+        hipLaunchKernelGGL(layernorm_bwd_kernel<8>, dim3(blocks), dim3(LN_THREADS), 0, s, (const f16*)a->dy, a->lddy, (const f16*)a->x, a->ldx,
+                           (const f16*)a->gamma, a->mean, a->rstd, (f16*)a->dx, a->lddx, (f16*)a->dx_drop, a->lddxd, part, a->M, a->H, dyd, outd);
+    VLP_CHECK_LAUNCH("vlp_layernorm_bwd");
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * a->H, 256)), dim3(256), 0, s, part, blocks * LN_WAVES, a->H, (f16*)a->dgamma,
+                       (f16*)a->dbeta, a->beta);
+    VLP_CHECK_LAUNCH("vlp_layernorm_bwd_reduce");
+    return VLP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// column sums: out[n] (+)= sum_m A[m,n].  grid (col blocks of 256, row splits); partials -> reduce.
+// ---------------------------------------------------------------------------------------------
+#define CS_SPLITS 64
+
+__global__ __launch_bounds__(256) void colsum_kernel(const f16* __restrict__ A, int64_t lda, int M, int N, float* __restrict__ part) {
+    __shared__ float red[8][256];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 column-chunks x 8 row lanes
+    const int c0 = blockIdx.x * 256 + tx * 8;
+    const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (c0 < N) {
+        for (int r = r0 + ty; r < r1; r += 8) {
+            f16x8 v = ld8(A + (int64_t)r * lda + c0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[ty][tx * 8 + e] = acc[e];
+    __syncthreads();
+    const int c = threadIdx.x;
+    float s = 0.f;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) s += red[y][c];
+    const int col = blockIdx.x * 256 + c;
+    if (col < N) part[(int64_t)blockIdx.y * N + col] = s;
+}
+__global__ void colsum_reduce_kernel(const float* __restrict__ part, int nparts, int N, f16* out, int beta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * N + i];
+    out[i] = (f16)(beta ? (float)out[i] + s : s);
+}
+
+extern "C" int64_t vlp_colsum_workspace_bytes(int32_t M, int32_t N) {
+    (void)M;
+    return (int64_t)CS_SPLITS * N * (int64_t)sizeof(float);
+}
+extern "C" int vlp_colsum(const vlp_colsum_args* a, void* stream) {
+    VLP_CHECK_ARG(a && a->A && a->out && a->M > 0 && a->N > 0, "vlp_colsum: bad args");
+    VLP_CHECK_ARG(a->lda % 8 == 0 && a->lda >= (a->N + 7) / 8 * 8 && (uintptr_t)a->A % 16 == 0, "vlp_colsum: layout (lda must cover roundup8(N))");
+    int splits = a->M >= CS_SPLITS * 8 ? CS_SPLITS : (a->M + 7) / 8;
+    if (splits < 1) splits = 1;
+    const int64_t need = (int64_t)splits * a->N * (int64_t)sizeof(float);
+    if (!a->workspace || a->workspace_bytes < need) return vlp_set_error(VLP_ERR_WORKSPACE, "vlp_colsum: workspace %lld < %lld", (long long)a->workspace_bytes, (long long)need);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(a->N, 256), splits), dim3(256), 0, s, (const f16*)a->A, a->lda, a->M, a->N, (float*)a->workspace);
+    VLP_CHECK_LAUNCH("vlp_colsum");
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(a->N, 256)), dim3(256), 0, s, (const float*)a->workspace, splits, a->N, (f16*)a->out, a->beta);
+    VLP_CHECK_LAUNCH("vlp_colsum_reduce");
+    return VLP_OK;
+}
