@@ -158,30 +158,50 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(
             }
         }
     }
-    float* pg = part + (int64_t)wave * 2 * H;
-    float* pb = pg + H;
+    // block-level reduction of the 4 waves' column partials through LDS, one partial row per block
+    extern __shared__ float lnb_sh[];      // [LN_WAVES][2H]
+    {
+        float* sg = lnb_sh + (threadIdx.x >> 6) * 2 * H;
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-        const int c = lane + 64 * j;
-        if (c < nch) {
+        for (int j = 0; j < MAXJ; ++j) {
+            const int c = lane + 64 * j;
+            if (c < nch) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { pg[c * 8 + e] = dg[j][e]; pb[c * 8 + e] = db[j][e]; }
+                for (int e = 0; e < 8; ++e) { sg[c * 8 + e] = dg[j][e]; sg[H + c * 8 + e] = db[j][e]; }
+            }
         }
+    }
+    __syncthreads();
+    float* dst = part + (int64_t)blockIdx.x * 2 * H;
+    for (int i = threadIdx.x; i < 2 * H; i += LN_THREADS) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < LN_WAVES; ++w) t += lnb_sh[w * 2 * H + i];
+        dst[i] = t;
     }
 }
 
-// out[0..H) = dgamma, out[H..2H) = dbeta from part[nparts][2H]
-__global__ void ln_bwd_reduce_kernel(const float* __restrict__ part, int nparts, int H, f16* dgamma, f16* dbeta, int beta) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // 0..2H
-    if (i >= 2 * H) return;
+// out[0..H) = dgamma, out[H..2H) = dbeta from part[nparts][2H].  Block = 64 columns x 16 partial-groups.
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nparts, int H, f16* dgamma, f16* dbeta, int beta) {
+    __shared__ float sh[16][64];
+    const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * 2 * H + i];
-    f16* dst = i < H ? dgamma + i : dbeta + (i - H);
-    *dst = (f16)(beta ? (float)*dst + s : s);
+    if (i < 2 * H)
+        for (int p = pg; p < nparts; p += 16) s += part[(int64_t)p * 2 * H + i];
+    sh[pg][cl] = s;
+    __syncthreads();
+    if (pg == 0 && i < 2 * H) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k][cl];
+        f16* dst = i < H ? dgamma + i : dbeta + (i - H);
+        *dst = (f16)(beta ? (float)*dst + t : t);
+    }
 }
 
 extern "C" int64_t vlp_layernorm_bwd_workspace_bytes(int32_t H) {
-    return (int64_t)LNB_BLOCKS * LN_WAVES * 2 * H * (int64_t)sizeof(float);
+    return (int64_t)LNB_BLOCKS * 2 * H * (int64_t)sizeof(float);
 }
 
 extern "C" int vlp_layernorm_bwd(const vlp_layernorm_bwd_args* a, void* stream) {
@@ -198,14 +218,21 @@ extern "C" int vlp_layernorm_bwd(const vlp_layernorm_bwd_args* a, void* stream) 
     if (blocks > LNB_BLOCKS) blocks = LNB_BLOCKS;
     hipStream_t s = (hipStream_t)stream;
     float* part = (float*)a->workspace;
+    const size_t lnb_smem = (size_t)LN_WAVES * 2 * a->H * sizeof(float);   // <= 128 KiB at H = 4096
+    static bool lnb_attr = false;
+    if (!lnb_attr) {
+        hipFuncSetAttribute((const void*)layernorm_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 1024 * 4);
+        hipFuncSetAttribute((const void*)layernorm_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 4096 * 4);
+        lnb_attr = true;
+    }
     if (a->H <= 1024)
-        hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(LN_THREADS), 0, s, (const f16*)a->dy, a->lddy, (const f16*)a->x, a->ldx,
+        hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(LN_THREADS), lnb_smem, s, (const f16*)a->dy, a->lddy, (const f16*)a->x, a->ldx,
                            (const f16*)a->gamma, a->mean, a->rstd, (f16*)a->dx, a->lddx, (f16*)a->dx_drop, a->lddxd, part, a->M, a->H, dyd, outd);
     else
-        hipLaunchKernelGGL(layernorm_bwd_kernel<8>, dim3(blocks), dim3(LN_THREADS), 0, s, (const f16*)a->dy, a->lddy, (const f16*)a->x, a->ldx,
+        hipLaunchKernelGGL(layernorm_bwd_kernel<8>, dim3(blocks), dim3(LN_THREADS), lnb_smem, s, (const f16*)a->dy, a->lddy, (const f16*)a->x, a->ldx,
                            (const f16*)a->gamma, a->mean, a->rstd, (f16*)a->dx, a->lddx, (f16*)a->dx_drop, a->lddxd, part, a->M, a->H, dyd, outd);
     VLP_CHECK_LAUNCH("vlp_layernorm_bwd");
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * a->H, 256)), dim3(256), 0, s, part, blocks * LN_WAVES, a->H, (f16*)a->dgamma,
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * a->H, 64)), dim3(1024), 0, s, part, blocks, a->H, (f16*)a->dgamma,
                        (f16*)a->dbeta, a->beta);
     VLP_CHECK_LAUNCH("vlp_layernorm_bwd_reduce");
     return VLP_OK;
@@ -242,12 +269,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const f16* __restrict__ A, 
     const int col = blockIdx.x * 256 + c;
     if (col < N) part[(int64_t)blockIdx.y * N + col] = s;
 }
-__global__ void colsum_reduce_kernel(const float* __restrict__ part, int nparts, int N, f16* out, int beta) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __restrict__ part, int nparts, int N, f16* out, int beta) {
+    __shared__ float sh[16][64];
+    const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * N + i];
-    out[i] = (f16)(beta ? (float)out[i] + s : s);
+    if (i < N)
+        for (int p = pg; p < nparts; p += 16) s += part[(int64_t)p * N + i];
+    sh[pg][cl] = s;
+    __syncthreads();
+    if (pg == 0 && i < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k][cl];
+        out[i] = (f16)(beta ? (float)out[i] + t : t);
+    }
 }
 
 extern "C" int64_t vlp_colsum_workspace_bytes(int32_t M, int32_t N) {
@@ -264,7 +300,7 @@ extern "C" int vlp_colsum(const vlp_colsum_args* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(a->N, 256), splits), dim3(256), 0, s, (const f16*)a->A, a->lda, a->M, a->N, (float*)a->workspace);
     VLP_CHECK_LAUNCH("vlp_colsum");
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(a->N, 256)), dim3(256), 0, s, (const float*)a->workspace, splits, a->N, (f16*)a->out, a->beta);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(a->N, 64)), dim3(1024), 0, s, (const float*)a->workspace, splits, a->N, (f16*)a->out, a->beta);
     VLP_CHECK_LAUNCH("vlp_colsum_reduce");
     return VLP_OK;
 }
