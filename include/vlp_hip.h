@@ -228,6 +228,9 @@ int vlp_vqa_mul_bwd(const void* h, const void* dout, void* dh, int32_t B, int32_
 int vlp_relu_dropout_bwd(const void* dy, const void* y, void* dz, int64_t n, int64_t ncols, float drop_p,
                          uint64_t seed, uint32_t rng_stream, void* stream);
 
+/* dz = dy * gelu'(z)   (backward of the head transform's gelu, modeling.py:433; n % 8 == 0) */
+int vlp_gelu_bwd(const void* dy, const void* z, void* dz, int64_t n, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Losses
  * Masked-LM loss (modeling.py:1083-1111): per-row CE in fp32 over V logits, * masked_weights,
@@ -309,6 +312,8 @@ typedef struct {
     float* norms;
     float lr, b1, b2, eps, decay, max_grad_norm;
     float grad_scale;                    /* gradients are divided by this (loss scale), 1 for fp32 */
+    const int32_t* active;               /* [ntensors] device flags or NULL: tensors with 0 are skipped entirely
+                                            (the reference skips parameters whose .grad is None, optimization.py:125-126) */
 } vlp_bert_adam_args;
 int vlp_bert_adam(const vlp_bert_adam_args* a, void* stream);
 

@@ -83,7 +83,7 @@ def embeddings(p, vis_feats_h, vis_pe_h, input_ids, token_type_ids, len_vis_inpu
     1..Nv of the position stream are the projected box/class encodings."""
     B, L = input_ids.shape
     if position_ids is None:
-        position_ids = torch.arange(L, dtype=torch.long).unsqueeze(0).expand_as(input_ids)
+        position_ids = torch.arange(L, dtype=torch.long, device=input_ids.device).unsqueeze(0).expand_as(input_ids)
     words = p["bert.embeddings.word_embeddings.weight"][input_ids]
     pos = p["bert.embeddings.position_embeddings.weight"][position_ids]
     if vis_input:

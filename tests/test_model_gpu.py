@@ -1,0 +1,210 @@
+"""GPU end-to-end parity of the fused HIP model (vlp_amd.modeling.BertForPreTrainingLossMask) against
+(a) the fixtures the UNMODIFIED reference produced (tests/golden, fp32 ground truth) and
+(b) the oracle restatement run in fp16 on the same device (= the reference's algorithm at the
+    reference's fp16 precision; its own distance to fp32 is the tolerance yardstick).
+
+Tolerance (north_star: logits within 1e-3 relative of the reference at fp16):
+    err(hip vs fp32 truth) <= err(reference-fp16 vs fp32 truth) + 1e-3 * max|truth|
+and, reported alongside, the direct distance hip vs reference-fp16.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+if not torch.cuda.is_available():
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+from oracle import vlp_oracle as O                         # noqa: E402  (checker)
+from tests.golden_util import CASES, load_case, sample     # noqa: E402
+from vlp_amd import synthetic as S                         # noqa: E402
+from vlp_amd.modeling import BertConfig, BertForPreTrainingLossMask   # noqa: E402
+
+DEV = torch.device("cuda:0")
+REPORT = {}
+
+
+def relmax(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def relL2(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def build(p, mk, Nv=100, drop=0.0):
+    cfg = BertConfig(mk["vocab_size"], num_hidden_layers=mk["layers"], type_vocab_size=6, hidden_dropout_prob=drop,
+                     attention_probs_dropout_prob=drop)
+    m = BertForPreTrainingLossMask(cfg, enable_butd=True, len_vis_input=Nv, tasks=mk["tasks"], allow_random_fc7=True)
+    sd = dict(p)
+    sd["cls.predictions.decoder.weight"] = p["bert.embeddings.word_embeddings.weight"]
+    m.load_state_dict(sd, strict=True)
+    return m.half().to(DEV)
+
+
+def run_model(m, batch, drop_worst_ratio=0.0):
+    b = S.batch_to(batch, DEV, half=True)
+    losses = m(b.img, b.vis_pe, b.input_ids, b.segment_ids, b.input_mask, b.lm_label_ids, b.ans_labels, b.is_next,
+               masked_pos=b.masked_pos, masked_weights=b.masked_weights, task_idx=b.task_idx, vis_masked_pos=b.vis_masked_pos,
+               mask_image_regions=False, drop_worst_ratio=drop_worst_ratio)
+    return losses
+
+
+def oracle_on_device(p, batch, tasks, dtype, Nv=100, grads=False):
+    pd = {k: v.to(DEV).to(dtype).clone().requires_grad_(grads) for k, v in p.items()}
+    b = S.batch_to(batch, DEV)
+    if grads:
+        out, g = O.loss_and_grads(pd, b, tasks=tasks, len_vis_input=Nv, capture=True)
+        return out, g
+    with torch.no_grad():
+        return O.forward_pretraining_loss_mask(pd, b, tasks=tasks, len_vis_input=Nv, capture=True), None
+
+
+@pytest.mark.parametrize("name", list(CASES.keys()))
+def test_forward_backward_vs_reference_fixture(name):
+    try:
+        g, p, batch, mk = load_case(name)
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    tasks = mk["tasks"]
+    m = build(p, mk).eval()
+    losses = run_model(m, batch)
+    total = losses[0] + losses[1] + losses[2]
+    total.sum().backward()
+    torch.cuda.synchronize()
+    # shapes of the 3-tuple (reference fixture stores .dim() of each)
+    assert [l.dim() for l in losses] == list(g["loss_shapes"])
+    ref16, _ = oracle_on_device(p, batch, tasks, torch.float16)
+    key = "vqa_logits" if tasks == "vqa2" else "mlm_logits"
+    truth = torch.from_numpy(g[key])
+    ours = (m.last_vqa_logits if tasks == "vqa2" else m.last_mlm_logits).float().cpu().reshape(truth.shape)
+    yard = relmax(ref16[key].float().cpu().reshape(truth.shape), truth)
+    mine = relmax(ours, truth)
+    direct = relmax(ours, ref16[key].float().cpu().reshape(truth.shape))
+    REPORT[name] = {"logits_err_vs_fp32_truth": mine, "reference_fp16_err_vs_fp32_truth": yard, "hip_vs_reference_fp16": direct}
+    assert mine <= yard + 1e-3, REPORT[name]
+    assert direct <= 4e-3, REPORT[name]
+    # losses: fp32 CE over fp16 logits
+    lt = float(g["losses"].sum())
+    assert abs(float(total.sum()) - lt) <= 2e-3 * abs(lt), (float(total.sum()), lt)
+    # hidden states of the last layer (strided sample, same sampling as the fixture)
+    nl = mk["layers"]
+    eng = m.engine
+    hs = eng._ws[next(iter(eng._ws))]["layers"][nl - 1]["x2"]
+    yard_h = relL2(sample(ref16["hidden"][-1].float().cpu()), g["hidden_%d" % nl])
+    mine_h = relL2(sample(hs.float().cpu()), g["hidden_%d" % nl])
+    REPORT[name].update(hidden_relL2=mine_h, hidden_relL2_reference_fp16=yard_h)
+    assert mine_h <= yard_h + 1e-3
+    # gradients: every parameter's L2 norm against the reference's, and sampled entries
+    gscale = max(x for x in g["grad_norms"] if x > 0)
+    params = dict(m.named_parameters())
+    unused = eng.unused_parameter_names()
+    worst = 0.0
+    for n, ref_norm in zip(g["param_names"], g["grad_norms"]):
+        n = str(n)
+        gr = params[n].grad
+        if ref_norm < 0:
+            assert n in unused, n
+            assert float(gr.float().abs().max()) == 0.0
+            continue
+        assert n not in unused
+        d = abs(float(gr.double().norm()) - ref_norm)
+        worst = max(worst, d / (ref_norm + 1e-3 * gscale))
+        assert d <= 2e-2 * ref_norm + 2e-3 * gscale, (n, float(gr.double().norm()), ref_norm)
+    for k in g:
+        if k.startswith("grad::"):
+            n = k[6:]
+            a, r = sample(params[n].grad.float().cpu()), g[k]
+            assert np.linalg.norm(a - r) <= 3e-2 * np.linalg.norm(r) + 2e-3 * gscale * np.sqrt(r.size) / 64, n
+    REPORT[name]["worst_grad_norm_rel_dev"] = worst
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_report.json", "w") as f:
+        json.dump(REPORT, f, indent=1)
+
+
+def test_plumbing_config_8_regions():
+    """BASELINE.json configs[0]: 2 layers, 8 regions, seq_len 32, bs 4 (the reference itself asserts 100 regions,
+    so the yardstick here is the oracle restatement with that assert relaxed)."""
+    Nv = 8
+    p = O.init_params(vocab_size=1024, layers=2, tasks="img2txt", seed=21)
+    batch = S.make_batch(4, max_len_b=32, len_vis_input=Nv, vocab_size=1024, max_pred=3, s2s_prob=0.5, seed=31)
+    m = build(p, dict(vocab_size=1024, layers=2, tasks="img2txt"), Nv=Nv).eval()
+    losses = run_model(m, batch)
+    (losses[0] + losses[1] + losses[2]).sum().backward()
+    truth, gt = oracle_on_device(p, batch, "img2txt", torch.float32, Nv=Nv, grads=True)
+    ref16, _ = oracle_on_device(p, batch, "img2txt", torch.float16, Nv=Nv)
+    t = truth["mlm_logits"].detach()
+    assert relmax(m.last_mlm_logits.float(), t) <= relmax(ref16["mlm_logits"].float(), t) + 1e-3
+    assert abs(float(losses[0]) - float(truth["mlm_loss"])) < 2e-3 * float(truth["mlm_loss"])
+    params = dict(m.named_parameters())
+    gscale = max(float(v.norm()) for v in gt.values() if v is not None)
+    for n, v in gt.items():
+        if v is None or n in m.engine.unused_parameter_names():
+            continue
+        assert abs(float(params[n].grad.double().norm()) - float(v.norm())) <= 2e-2 * float(v.norm()) + 2e-3 * gscale, n
+
+
+def test_vqa_inference_and_drop_worst():
+    p = O.init_params(vocab_size=1024, layers=2, tasks="vqa2", seed=5)
+    batch = S.make_batch(5, max_len_b=20, vocab_size=1024, tasks="vqa2", max_pred=1, seed=9)
+    m = build(p, dict(vocab_size=1024, layers=2, tasks="vqa2")).eval()
+    b = S.batch_to(batch, DEV, half=True)
+    with torch.no_grad():
+        ans = m(b.img, b.vis_pe, b.input_ids, b.segment_ids, b.input_mask, vqa_inference=True)
+    ref, _ = oracle_on_device(p, batch, "vqa2", torch.float32)
+    out = O.forward_pretraining_loss_mask({k: v.to(DEV) for k, v in p.items()}, S.batch_to(batch, DEV), tasks="vqa2", vqa_inference=True)
+    # argmax can legitimately flip on near ties at fp16: compare logits, and require the chosen answers' logits to tie within tol
+    assert relmax(m.last_vqa_logits.float(), out["vqa_logits"]) < 4e-3
+    chosen = out["vqa_logits"].gather(1, ans[:, None]).squeeze(1)
+    best = out["vqa_logits"][:, 1:].max(-1)[0]
+    assert float((best - chosen).max()) <= 4e-3 * float(out["vqa_logits"].abs().max())
+    del ref
+    # drop-worst path of the MLM loss
+    p2 = O.init_params(vocab_size=1024, layers=2, tasks="img2txt", seed=6)
+    batch2 = S.make_batch(8, max_len_b=20, vocab_size=1024, max_pred=3, seed=10)
+    m2 = build(p2, dict(vocab_size=1024, layers=2, tasks="img2txt")).eval()
+    l = run_model(m2, batch2, drop_worst_ratio=0.25)
+    t, _ = oracle_on_device(p2, batch2, "img2txt", torch.float32)
+    pd = {k: v.to(DEV) for k, v in p2.items()}
+    t = O.forward_pretraining_loss_mask(pd, S.batch_to(batch2, DEV), tasks="img2txt", drop_worst_ratio=0.25)
+    assert abs(float(l[0]) - float(t["mlm_loss"])) < 3e-3 * float(t["mlm_loss"])
+
+
+def test_training_mode_dropout_is_deterministic_and_accumulates():
+    p = O.init_params(vocab_size=1024, layers=2, tasks="img2txt", seed=7)
+    batch = S.make_batch(4, max_len_b=20, vocab_size=1024, max_pred=3, seed=11)
+    m = build(p, dict(vocab_size=1024, layers=2, tasks="img2txt"), drop=0.1).train()
+    m.engine.step_seed = 100
+    l1 = run_model(m, batch)
+    (l1[0] + l1[1] + l1[2]).sum().backward()
+    g1 = m.engine.gflat["decay"].clone()
+    assert torch.isfinite(g1.float()).all() and float(g1.float().abs().max()) > 0
+    # same seed -> bit-identical loss and gradients
+    m.engine.step_seed = 100
+    m.engine.zero_grad()
+    l2 = run_model(m, batch)
+    (l2[0] + l2[1] + l2[2]).sum().backward()
+    assert float(l1[0]) == float(l2[0])
+    # fp16 atomics in the embedding scatter may reorder: compare with a tight tolerance instead of bitwise
+    assert relL2(m.engine.gflat["decay"].float(), g1.float()) < 1e-3
+    # a different seed changes the mask
+    l3 = run_model(m, batch)
+    assert float(l3[0]) != float(l1[0])
+    # accumulation: a second backward without zero_grad doubles the gradient
+    m.engine.step_seed = 100
+    m.engine.zero_grad()
+    la = run_model(m, batch)
+    (la[0] + la[1] + la[2]).sum().backward()
+    m.engine.step_seed = 100
+    lb = run_model(m, batch)
+    (lb[0] + lb[1] + lb[2]).sum().backward()
+    assert relL2(m.engine.gflat["decay"].float(), 2 * g1.float()) < 2e-3
+    # eval mode ignores dropout
+    m.eval()
+    e1, e2 = run_model(m, batch), run_model(m, batch)
+    assert float(e1[0]) == float(e2[0])

@@ -97,7 +97,8 @@ class FusedAdamArgs(C.Structure):
 class BertAdamArgs(C.Structure):
     _fields_ = [("p32", vp), ("m", vp), ("v", vp), ("g", vp), ("g_is_f32", i32), ("p16", vp),
                 ("seg_off", vp), ("ntensors", i32), ("n", i64), ("norms", vp),
-                ("lr", f32), ("b1", f32), ("b2", f32), ("eps", f32), ("decay", f32), ("max_grad_norm", f32), ("grad_scale", f32)]
+                ("lr", f32), ("b1", f32), ("b2", f32), ("eps", f32), ("decay", f32), ("max_grad_norm", f32), ("grad_scale", f32),
+                ("active", vp)]
 
 
 # every symbol include/vlp_hip.h declares: name -> (restype, argtypes)
@@ -124,6 +125,7 @@ SYMBOLS = {
     "vlp_vqa_mul_fwd": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "vlp_vqa_mul_bwd": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "vlp_relu_dropout_bwd": (C.c_int, [vp, vp, vp, i64, i64, f32, u64, u32, vp]),
+    "vlp_gelu_bwd": (C.c_int, [vp, vp, vp, i64, vp]),
     "vlp_mlm_loss_fwd": (C.c_int, [C.POINTER(MlmLossFwdArgs), vp]),
     "vlp_mlm_loss_bwd": (C.c_int, [C.POINTER(MlmLossBwdArgs), vp]),
     "vlp_bce_loss_fwd": (C.c_int, [vp, i64, vp, i64, i32, i32, vp, vp]),
@@ -303,6 +305,11 @@ def relu_dropout_bwd(dy, y, dz, n, ncols, drop_p=0.0, seed=0, rng_stream=0):
     _check(load().vlp_relu_dropout_bwd(ptr(dy), ptr(y), ptr(dz), n, ncols, drop_p, seed, rng_stream, stream_ptr()))
 
 
+def gelu_bwd(dy, z, dz, n):
+    _req_cuda(dy, z, dz)
+    _check(load().vlp_gelu_bwd(ptr(dy), ptr(z), ptr(dz), n, stream_ptr()))
+
+
 def mlm_loss_fwd(logits, ld, labels, weights, loss, lse, coef, row_loss, B, P, V, drop_worst_ratio=0.0):
     _req_cuda(logits, labels, weights, loss, lse, coef, row_loss)
     a = MlmLossFwdArgs(ptr(logits), ld, ptr(labels), ptr(weights), ptr(loss), ptr(lse), ptr(coef), ptr(row_loss), B, P, V, drop_worst_ratio)
@@ -342,8 +349,8 @@ def fused_adam(p32, m, v, g16, p16, n, hyper, b1=0.9, b2=0.999, eps=1e-8, decay=
 
 
 def bert_adam(p32, m, v, g, g_is_f32, p16, seg_off, ntensors, n, norms, lr, b1=0.9, b2=0.999, eps=1e-6, decay=0.01,
-              max_grad_norm=1.0, grad_scale=1.0):
+              max_grad_norm=1.0, grad_scale=1.0, active=None):
     _req_cuda(p32, m, v, g, seg_off, norms)
     a = BertAdamArgs(ptr(p32), ptr(m), ptr(v), ptr(g), int(g_is_f32), ptr(p16), ptr(seg_off), ntensors, n, ptr(norms),
-                     lr, b1, b2, eps, decay, max_grad_norm, grad_scale)
+                     lr, b1, b2, eps, decay, max_grad_norm, grad_scale, ptr(active))
     _check(load().vlp_bert_adam(C.byref(a), stream_ptr()))

@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256) void bert_adam_norm_kernel(vlp_bert_adam_args 
     int64_t pos = start;
     while (pos < end) {
         const int64_t tend = min(end, a.seg_off[t + 1]);
+        if (a.active && !a.active[t]) { pos = tend; ++t; continue; }
         float s = 0.f;
         for (int64_t i = pos + threadIdx.x; i < tend; i += blockDim.x) {
             const float f = ba_load(a.g, a.g_is_f32, i) / a.grad_scale;
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(256) void bert_adam_update_kernel(vlp_bert_adam_arg
     f16* p16 = (f16*)a.p16;
     while (pos < end) {
         const int64_t tend = min(end, a.seg_off[t + 1]);
+        if (a.active && !a.active[t]) { pos = tend; ++t; continue; }
         float coef = 1.f;
         if (a.max_grad_norm > 0.f) {
             // torch clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), applied when < 1

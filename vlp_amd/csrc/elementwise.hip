@@ -350,3 +350,21 @@ extern "C" int vlp_relu_dropout_bwd(const void* dy, const void* y, void* dz, int
     VLP_CHECK_LAUNCH("vlp_relu_dropout_bwd");
     return VLP_OK;
 }
+
+__global__ void gelu_bwd_kernel(const f16* dy, const f16* z, f16* dz, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const f16x8 g = ld8(dy + i * 8), zv = ld8(z + i * 8);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)((float)g[e] * gelu_grad_f((float)zv[e]));
+        st8(dz + i * 8, o);
+    }
+}
+extern "C" int vlp_gelu_bwd(const void* dy, const void* z, void* dz, int64_t n, void* stream) {
+    VLP_CHECK_ARG(dy && z && dz && n > 0 && n % 8 == 0, "vlp_gelu_bwd: n must be a positive multiple of 8");
+    int blocks = (int)((n / 8 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)dy, (const f16*)z, (f16*)dz, n / 8);
+    VLP_CHECK_LAUNCH("vlp_gelu_bwd");
+    return VLP_OK;
+}

@@ -1,0 +1,517 @@
+"""Fused forward/backward executor of the VLP unified transformer on MI355X.
+
+This is the host-side orchestration that replaces the reference's per-op autograd graph
+(pytorch_pretrained_bert/modeling.py:217-482, 1033-1143): one Python call sequence over the C ABI of
+libvlp_hip.so per training step, with
+
+  * parameters living in two flat fp16 buffers (weight-decay group / no-decay group -- the same two
+    groups the train script builds, run_img2txt_dist.py:394-401), laid out in *backward completion
+    order* so that a gradient bucket is a contiguous slice that can be handed to RCCL the moment the
+    last weight-gradient GEMM of that slice has been launched;
+  * gradients written by the kernels straight into matching flat fp16 buffers (`param.grad` are views);
+  * activations kept in a per-shape workspace that is reused every step (288 GB of HBM: nothing is
+    recomputed except dropout masks, which are a pure function of (seed, stream, index));
+  * transposed weight shadows for the dgrad GEMMs refreshed once per backward.
+
+PyTorch is used for memory (torch.empty), streams and the autograd hand-off only.  There is no
+fallback: every compute step is a HIP kernel.
+"""
+import math
+import weakref
+
+import torch
+
+from . import _lib as K
+
+ALIGN = 64            # elements; every parameter starts on a 128-byte boundary inside its flat buffer
+NO_DECAY = ("bias", "LayerNorm.bias", "LayerNorm.weight")    # run_img2txt_dist.py:395
+PE_DIM = 1607         # 6 box numbers + 1601 class probabilities (modeling.py:1016)
+PE_PAD = 1664         # next multiple of 64: GEMM K alignment
+
+
+def _ru(x, m):
+    return (x + m - 1) // m * m
+
+
+def is_no_decay(name):
+    return any(nd in name for nd in NO_DECAY)
+
+
+class _State(object):
+    """What one forward leaves behind for its backward."""
+    __slots__ = ("gen", "B", "L", "P", "seed", "p_drop", "ws", "batch", "task", "has_mlm", "task_labels")
+
+
+class Engine(object):
+    GEMM_NT_VARIANT = 1      # LDS-DMA staging (faster on the measured shapes; profiles/r01_microbench_kernels.json)
+    GEMM_TN_VARIANT = 1      # ds_read_b64_tr_b16 fragment reads
+
+    def __init__(self, model):
+        self._model = weakref.ref(model)
+        self.packed = False
+        self.gen = 0
+        self.step_seed = 0
+        self.base_seed = 0x5EED
+        self.grads_dirty = False          # False -> next backward overwrites (beta = 0), True -> accumulates
+        self.grad_ready_hook = None       # callable(bucket_index) set by the DDP wrapper
+        self.post_backward_hook = None    # callable() set by the DDP wrapper
+        self._ws = {}
+        self._shadow = None
+
+    # ------------------------------------------------------------------------------------------
+    # parameter packing
+    # ------------------------------------------------------------------------------------------
+    def _ordered_names(self, model):
+        cfg = model.config
+        tasks = model.tasks
+        names = {n for n, _ in model.named_parameters()}
+        decay, buckets = [], []
+
+        def add(group):
+            start = len(decay)
+            decay.extend(group)
+            buckets.append((start, len(decay)))
+
+        head_unused = []
+        if tasks == "vqa2":
+            add(["ans_classifier.2.weight", "ans_classifier.0.weight"])
+            head_unused.append("cls.predictions.transform.dense.weight")
+        else:
+            add(["cls.predictions.transform.dense.weight"])
+        for i in reversed(range(cfg.num_hidden_layers)):
+            L = "bert.encoder.layer.%d." % i
+            add([L + "output.dense.weight", L + "intermediate.dense.weight", L + "attention.output.dense.weight",
+                 L + "attention.self.query.weight", L + "attention.self.key.weight", L + "attention.self.value.weight"])
+        add(["bert.embeddings.position_embeddings.weight", "bert.embeddings.token_type_embeddings.weight",
+             "bert.embeddings.word_embeddings.weight", "vis_pe_embed.0.weight", "vis_embed.2.weight", "vis_embed.0.weight",
+             "bert.pooler.dense.weight"] + head_unused)
+        nodecay = sorted(n for n in names if is_no_decay(n))
+        # q/k/v biases of a layer must be contiguous (packed QKV GEMM)
+        for i in range(cfg.num_hidden_layers):
+            L = "bert.encoder.layer.%d.attention.self." % i
+            for n in (L + "query.bias", L + "key.bias", L + "value.bias"):
+                nodecay.remove(n)
+            nodecay.extend([L + "query.bias", L + "key.bias", L + "value.bias"])
+        missing = names - set(decay) - set(nodecay)
+        extra = (set(decay) | set(nodecay)) - names
+        if missing or extra:
+            raise RuntimeError("vlp_amd.Engine: unexpected parameter set (missing %s, unknown %s)" % (sorted(missing), sorted(extra)))
+        return decay, nodecay, buckets
+
+    def pack(self):
+        """Move every parameter into the flat buffers (idempotent).  Needs fp16 parameters on a GPU:
+        this is the `model.half(); model.to(device)` state of run_img2txt_dist.py:370-377."""
+        if self.packed:
+            return
+        model = self._model()
+        params = dict(model.named_parameters())
+        dev = next(iter(params.values())).device
+        if dev.type != "cuda":
+            raise RuntimeError("vlp_amd: the model must be on an MI355X (`model.to('cuda')`); there is no CPU path")
+        for n, p in params.items():
+            if p.dtype != torch.float16:
+                raise RuntimeError("vlp_amd: parameters must be fp16 (`model.half()`, i.e. --fp16): %s is %s. "
+                                   "The fp32 path of the reference is not implemented (DESIGN.md, out of scope)." % (n, p.dtype))
+        K.load()
+        decay, nodecay, buckets = self._ordered_names(model)
+        self.names = {"decay": decay, "nodecay": nodecay}
+        self.flat, self.gflat, self.offsets, self.sizes = {}, {}, {}, {}
+        for grp, names in self.names.items():
+            off, offs = 0, {}
+            for n in names:
+                offs[n] = off
+                off += _ru(params[n].numel(), ALIGN)
+            total = _ru(off, 8)
+            flat = torch.zeros(total, device=dev, dtype=torch.float16)
+            gflat = torch.zeros(total, device=dev, dtype=torch.float16)
+            for n in names:
+                p = params[n]
+                view = flat[offs[n]:offs[n] + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = gflat[offs[n]:offs[n] + p.numel()].view(p.shape)
+                p._vlp_engine = self
+            self.flat[grp], self.gflat[grp], self.offsets[grp], self.sizes[grp] = flat, gflat, offs, total
+        # gradient buckets: contiguous slices of the decay buffer in completion order
+        self.buckets = []
+        for s, e in buckets:
+            lo = self.offsets["decay"][decay[s]]
+            hi = self.offsets["decay"][decay[e - 1]] + _ru(params[decay[e - 1]].numel(), ALIGN)
+            self.buckets.append((lo, min(hi, self.sizes["decay"])))
+        self._params = params
+        self.device = dev
+        self.packed = True
+        self.grads_dirty = False
+        self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+        self._unused = set(["bert.pooler.dense.weight", "bert.pooler.dense.bias"])
+        if model.tasks == "vqa2":
+            self._unused |= {"cls.predictions.bias", "cls.predictions.transform.dense.weight", "cls.predictions.transform.dense.bias",
+                             "cls.predictions.transform.LayerNorm.weight", "cls.predictions.transform.LayerNorm.bias"}
+
+    def invalidate(self):
+        """Called when nn.Module._apply() replaced parameter storage (.half()/.to()/.cpu())."""
+        self.packed = False
+        self._ws = {}
+        self._shadow = None
+
+    def P(self, name):
+        return self._params[name].data
+
+    def G(self, name):
+        return self._params[name].grad
+
+    def unused_parameter_names(self):
+        return set(self._unused)
+
+    def zero_grad(self):
+        """optimizer.zero_grad() of the train loop (run_img2txt_dist.py:585): no memset -- the next
+        backward simply overwrites (beta = 0) instead of accumulating."""
+        self.grads_dirty = False
+
+    # ------------------------------------------------------------------------------------------
+    # workspaces
+    # ------------------------------------------------------------------------------------------
+    def _workspace(self, B, L, P):
+        key = (B, L, P)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        model = self._model()
+        cfg = model.config
+        H, I, A, NL, Nv, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers, model.len_vis_input, cfg.vocab_size
+        M, Mv = B * L, B * Nv
+        dev = self.device
+
+        def h(*s):
+            return torch.empty(*s, device=dev, dtype=torch.float16)
+
+        def f(*s):
+            return torch.empty(*s, device=dev, dtype=torch.float32)
+
+        ws = {"Lp": _ru(L, 32)}
+        ws["maskb"] = torch.empty(B, L, ws["Lp"], device=dev, dtype=torch.uint8)
+        ws["img16"], ws["vpe_in"], ws["wpe_pad"] = h(Mv, 2048), h(Mv, PE_PAD), h(H, PE_PAD)
+        ws["h1"], ws["vis_h"], ws["vispe_h"] = h(Mv, 2048), h(Mv, H), h(Mv, H)
+        ws["emb_pre"], ws["x0"] = h(M, H), h(M, H)
+        ws["stat0"] = (f(M), f(M))
+        lay = []
+        for _ in range(NL):
+            lay.append({"qkv": h(M, 3 * H), "ctx": h(M, H), "lse": f(B, A, L), "pre1": h(M, H), "x1": h(M, H),
+                        "st1": (f(M), f(M)), "z": h(M, I), "g": h(M, I), "pre2": h(M, H), "x2": h(M, H), "st2": (f(M), f(M))})
+        ws["layers"] = lay
+        # heads
+        Vp = _ru(V, 64)
+        ws["Vp"] = Vp
+        if P > 0:
+            R = B * P
+            ws.update(sel=h(R, H), tz=h(R, H), tg=h(R, H), tln=h(R, H), tstat=(f(R), f(R)), logits=h(R, Vp), dlogits=h(R, Vp),
+                      lse_ce=f(R), coef=f(R), row_loss=f(R), dtln=h(R, H), dtg=h(R, H), dtz=h(R, H), dsel=h(R, H))
+        ws["loss"] = f(260)
+        if model.tasks == "vqa2":
+            NA = model.num_answers
+            NAp = _ru(NA, 64)
+            ws.update(NAp=NAp, vq_e=h(B, H), vq_a1=h(B, 2 * H), vq_logits=h(B, NAp), vq_dlogits=h(B, NAp), vq_dz1=h(B, 2 * H), vq_de=h(B, H))
+        # backward scratch (shared by all layers)
+        ws.update(dx=h(M, H), dx_alt=h(M, H), dpre=h(M, H), dpre_d=h(M, H), dz=h(M, I), dctx=h(M, H), dqkv=h(M, 3 * H),
+                  delta=f(B, A, L), d_vis_h=h(Mv, H), d_vispe_h=h(Mv, H), dz1v=h(Mv, 2048), dwpe_pad=h(H, PE_PAD), acc32=f(64 * 8 * H))
+        tn_bytes = max(K.gemm_tn_workspace_bytes(M, I, H), K.gemm_tn_workspace_bytes(Mv, 2048, 2048), K.gemm_tn_workspace_bytes(M, 3 * H, H))
+        ws["tn_ws"] = torch.empty(tn_bytes, device=dev, dtype=torch.uint8)
+        ws["cs_ws"] = torch.empty(max(K.colsum_workspace_bytes(M, I), K.colsum_workspace_bytes(B * max(P, 1), Vp)), device=dev, dtype=torch.uint8)
+        ws["ln_ws"] = torch.empty(K.layernorm_bwd_workspace_bytes(max(H, 8)), device=dev, dtype=torch.uint8)
+        self._ws[key] = ws
+        return ws
+
+    def _shadows(self):
+        """Transposed weight copies W^T (zero padded so that every dgrad K is a multiple of 64)."""
+        if self._shadow is not None:
+            return self._shadow
+        model = self._model()
+        cfg = model.config
+        H, I, V = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
+        dev = self.device
+
+        def h(*s):
+            return torch.zeros(*s, device=dev, dtype=torch.float16)
+
+        sh = {"layers": [{"qkvT": h(H, 3 * H), "oT": h(H, H), "w1T": h(H, I), "w2T": h(I, H)} for _ in range(cfg.num_hidden_layers)],
+              "v2T": h(2048, H)}
+        if model.tasks == "vqa2":
+            NAp = _ru(model.num_answers, 64)
+            sh.update(a2T=h(2 * H, NAp), a0T=h(H, 2 * H))
+        else:
+            sh.update(ET=h(H, _ru(V, 64)), tT=h(H, H))
+        self._shadow = sh
+        return sh
+
+    def _refresh_shadows(self):
+        model = self._model()
+        cfg = model.config
+        H, I, V = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
+        sh = self._shadows()
+        for i, s in enumerate(sh["layers"]):
+            L = "bert.encoder.layer.%d." % i
+            K.transpose(self.P(L + "attention.self.query.weight"), H, s["qkvT"], 3 * H, 3 * H, H, 3 * H)   # packed [3H, H] -> [H, 3H]
+            K.transpose(self.P(L + "attention.output.dense.weight"), H, s["oT"], H, H, H, H)
+            K.transpose(self.P(L + "intermediate.dense.weight"), H, s["w1T"], I, I, H, I)
+            K.transpose(self.P(L + "output.dense.weight"), I, s["w2T"], H, H, I, H)
+        K.transpose(self.P("vis_embed.2.weight"), 2048, sh["v2T"], H, H, 2048, H)
+        if model.tasks == "vqa2":
+            NA = model.num_answers
+            K.transpose(self.P("ans_classifier.2.weight"), 2 * H, sh["a2T"], _ru(NA, 64), NA, 2 * H, _ru(NA, 64))
+            K.transpose(self.P("ans_classifier.0.weight"), H, sh["a0T"], 2 * H, 2 * H, H, 2 * H)
+        else:
+            K.transpose(self.P("bert.embeddings.word_embeddings.weight"), H, sh["ET"], _ru(V, 64), V, H, _ru(V, 64))
+            K.transpose(self.P("cls.predictions.transform.dense.weight"), H, sh["tT"], H, H, H, H)
+
+    # ------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------
+    def _nt(self, x, w, y, M, N, Kd, **kw):
+        K.gemm_nt(x, w, y, M, N, Kd, variant=self.GEMM_NT_VARIANT, **kw)
+
+    def forward(self, vis_feats, vis_pe, input_ids, token_type_ids, attention_mask, masked_pos, train, want_mlm, want_vqa):
+        """Runs embeddings + encoder (+ heads' forward up to the logits).  Returns the _State."""
+        self.pack()
+        model = self._model()
+        cfg = model.config
+        H, I, A, NL, Nv, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers, model.len_vis_input, cfg.vocab_size
+        B, L = input_ids.shape
+        if H != A * 64:
+            raise RuntimeError("vlp_amd: attention kernels need head_dim == 64 (hidden %d, heads %d)" % (H, A))
+        if vis_feats.shape[1] != Nv or vis_feats.shape[2] != 2048 or vis_pe.shape[2] != PE_DIM:
+            raise RuntimeError("vlp_amd: expected vis_feats [B,%d,2048] and vis_pe [B,%d,%d]" % (Nv, Nv, PE_DIM))
+        if L < Nv + 2:
+            raise RuntimeError("vlp_amd: sequence length %d too short for %d regions" % (L, Nv))
+        P = masked_pos.shape[1] if (want_mlm and masked_pos is not None and masked_pos.numel() > 0) else 0
+        ws = self._workspace(B, L, P)
+        self.gen += 1
+        st = _State()
+        st.gen, st.B, st.L, st.P, st.ws = self.gen, B, L, P, ws
+        p = cfg.hidden_dropout_prob if train else 0.0
+        pa = cfg.attention_probs_dropout_prob if train else 0.0
+        st.p_drop = (p, pa)
+        if train and (p > 0 or pa > 0):
+            self.step_seed += 1
+        seed = st.seed = self.base_seed + self.step_seed
+        M, Mv = B * L, B * Nv
+
+        # ---- inputs -----------------------------------------------------------------------------
+        if attention_mask is None:
+            attention_mask = torch.ones(B, L, dtype=torch.long, device=input_ids.device)
+        if attention_mask.dim() == 2:       # modeling.py:818-819
+            attention_mask = attention_mask[:, None, :].expand(B, L, L)
+        attention_mask = attention_mask.to(torch.long).contiguous()
+        K.mask_pack(attention_mask, ws["maskb"], B, L, ws["Lp"])
+        vf = vis_feats.reshape(Mv, 2048)
+        if vf.dtype == torch.float32:
+            K.copy2d(vf.contiguous(), 2048, True, ws["img16"], 2048, Mv, 2048, 2048)
+            img = ws["img16"]
+        else:
+            img = vf.contiguous()
+        vp = vis_pe.reshape(Mv, PE_DIM).contiguous()
+        K.copy2d(vp, PE_DIM, vp.dtype == torch.float32, ws["vpe_in"], PE_PAD, Mv, PE_DIM, PE_PAD)
+        K.copy2d(self.P("vis_pe_embed.0.weight"), PE_DIM, False, ws["wpe_pad"], PE_PAD, H, PE_DIM, PE_PAD)
+        st.batch = (img, input_ids.contiguous(), token_type_ids.contiguous(), masked_pos)
+
+        # ---- region projections (modeling.py:1003-1018,1035-1036) ---------------------------------
+        self._nt(img, self.P("vis_embed.0.weight"), ws["h1"], Mv, 2048, 2048, bias=self.P("vis_embed.0.bias"), act=K.ACT_RELU)
+        self._nt(ws["h1"], self.P("vis_embed.2.weight"), ws["vis_h"], Mv, H, 2048, bias=self.P("vis_embed.2.bias"), act=K.ACT_RELU,
+                 dropout_p=p, seed=seed, rng_stream=1001)
+        self._nt(ws["vpe_in"], ws["wpe_pad"], ws["vispe_h"], Mv, H, PE_PAD, bias=self.P("vis_pe_embed.0.bias"), act=K.ACT_RELU,
+                 dropout_p=p, seed=seed, rng_stream=1002)
+        # ---- embeddings (modeling.py:217-241) ------------------------------------------------------
+        E = "bert.embeddings."
+        K.embed_fwd(st.batch[1], st.batch[2], self.P(E + "word_embeddings.weight"), self.P(E + "position_embeddings.weight"),
+                    self.P(E + "token_type_embeddings.weight"), ws["vis_h"], ws["vispe_h"], ws["emb_pre"], B, L, Nv, H)
+        K.layernorm_fwd(ws["emb_pre"], self.P(E + "LayerNorm.weight"), self.P(E + "LayerNorm.bias"), ws["x0"], M, H, ws["stat0"][0], ws["stat0"][1],
+                        dropout_p=p, seed=seed, rng_stream=1000)
+        # ---- encoder (modeling.py:268-372) -----------------------------------------------------------
+        x = ws["x0"]
+        scale = 1.0 / math.sqrt(H // A)
+        for i in range(NL):
+            Ln = "bert.encoder.layer.%d." % i
+            a = ws["layers"][i]
+            self._nt(x, self.P(Ln + "attention.self.query.weight"), a["qkv"], M, 3 * H, H, bias=self.P(Ln + "attention.self.query.bias"))
+            K.attn_fwd(a["qkv"], ws["maskb"], a["ctx"], a["lse"], B, L, A, scale, dropout_p=pa, seed=seed, rng_stream=16 * i + 1)
+            self._nt(a["ctx"], self.P(Ln + "attention.output.dense.weight"), a["pre1"], M, H, H, bias=self.P(Ln + "attention.output.dense.bias"),
+                     residual=x, dropout_p=p, seed=seed, rng_stream=16 * i + 2)
+            K.layernorm_fwd(a["pre1"], self.P(Ln + "attention.output.LayerNorm.weight"), self.P(Ln + "attention.output.LayerNorm.bias"),
+                            a["x1"], M, H, a["st1"][0], a["st1"][1])
+            self._nt(a["x1"], self.P(Ln + "intermediate.dense.weight"), a["g"], M, I, H, bias=self.P(Ln + "intermediate.dense.bias"),
+                     preact=a["z"], act=K.ACT_GELU)
+            self._nt(a["g"], self.P(Ln + "output.dense.weight"), a["pre2"], M, H, I, bias=self.P(Ln + "output.dense.bias"),
+                     residual=a["x1"], dropout_p=p, seed=seed, rng_stream=16 * i + 3)
+            K.layernorm_fwd(a["pre2"], self.P(Ln + "output.LayerNorm.weight"), self.P(Ln + "output.LayerNorm.bias"), a["x2"], M, H,
+                            a["st2"][0], a["st2"][1])
+            x = a["x2"]
+        # ---- heads ------------------------------------------------------------------------------------
+        st.has_mlm = P > 0
+        if P > 0:
+            C = "cls.predictions."
+            R = B * P
+            K.gather_rows(x, H, masked_pos.contiguous(), ws["sel"], H, B, P, L, H)
+            self._nt(ws["sel"], self.P(C + "transform.dense.weight"), ws["tg"], R, H, H, bias=self.P(C + "transform.dense.bias"),
+                     preact=ws["tz"], act=K.ACT_GELU)
+            K.layernorm_fwd(ws["tg"], self.P(C + "transform.LayerNorm.weight"), self.P(C + "transform.LayerNorm.bias"), ws["tln"], R, H,
+                            ws["tstat"][0], ws["tstat"][1])
+            self._nt(ws["tln"], self.P("bert.embeddings.word_embeddings.weight"), ws["logits"], R, V, H, bias=self.P(C + "bias"), ldy=ws["Vp"])
+        if want_vqa:
+            NA = model.num_answers
+            K.vqa_mul_fwd(x, ws["vq_e"], B, L, Nv, H)
+            self._nt(ws["vq_e"], self.P("ans_classifier.0.weight"), ws["vq_a1"], B, 2 * H, H, bias=self.P("ans_classifier.0.bias"), act=K.ACT_RELU)
+            self._nt(ws["vq_a1"], self.P("ans_classifier.2.weight"), ws["vq_logits"], B, NA, 2 * H, bias=self.P("ans_classifier.2.bias"), ldy=ws["NAp"])
+        return st
+
+    def mlm_loss(self, st, labels, weights, drop_worst_ratio):
+        """modeling.py:1083-1111 on the logits of this forward; returns a [1] f32 view holding the loss."""
+        ws = st.ws
+        V = self._model().config.vocab_size
+        st.task_labels = labels.contiguous()
+        K.mlm_loss_fwd(ws["logits"], ws["Vp"], st.task_labels, weights.to(torch.long).contiguous(), ws["loss"], ws["lse_ce"], ws["coef"],
+                       ws["row_loss"], st.B, st.P, V, drop_worst_ratio=float(drop_worst_ratio))
+        return ws["loss"][0:1]
+
+    def vqa_loss(self, st, ans_labels):
+        """modeling.py:1140: BCEWithLogits(mean) * num_answers."""
+        ws = st.ws
+        st.task_labels = ans_labels.to(torch.float32).contiguous()
+        NA = self._model().num_answers
+        K.bce_loss_fwd(ws["vq_logits"], ws["NAp"], st.task_labels, st.task_labels.stride(0), st.B, NA, ws["loss"])
+        return ws["loss"][0:1]
+
+    def mlm_logits(self, st):
+        V = self._model().config.vocab_size
+        return st.ws["logits"][:, :V].view(st.B, st.P, V)
+
+    def vqa_logits(self, st):
+        return st.ws["vq_logits"][:, :self._model().num_answers]
+
+    def sequence_output(self, st):
+        cfg = self._model().config
+        return st.ws["layers"][cfg.num_hidden_layers - 1]["x2"].view(st.B, st.L, cfg.hidden_size)
+
+    # ------------------------------------------------------------------------------------------
+    # backward
+    # ------------------------------------------------------------------------------------------
+    def _tn(self, a, b, c, M, N, Kd, ws, beta, **kw):
+        K.gemm_tn(a, b, c, M, N, Kd, beta=beta, workspace=ws["tn_ws"], variant=self.GEMM_TN_VARIANT, **kw)
+
+    def _bucket_done(self, idx):
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(idx)
+
+    def backward(self, st, gscale, task):
+        """gscale: device f32 tensor [1] = upstream gradient of the loss (x loss scale).  Writes every
+        parameter gradient into the flat gradient buffers."""
+        if st.gen != self.gen:
+            raise RuntimeError("vlp_amd: the activations of this forward were overwritten by a later forward "
+                               "(one in-flight forward per model; run backward before the next forward)")
+        model = self._model()
+        cfg = model.config
+        H, I, A, NL, Nv, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers, model.len_vis_input, cfg.vocab_size
+        B, L, P, ws, seed = st.B, st.L, st.P, st.ws, st.seed
+        p, pa = st.p_drop
+        M, Mv = B * L, B * Nv
+        beta = 1 if self.grads_dirty else 0
+        img, input_ids, token_type_ids, masked_pos = st.batch
+        self._refresh_shadows()
+        sh = self._shadows()
+        x_last = ws["layers"][NL - 1]["x2"]
+        dx = ws["dx"]
+        dx.zero_()
+        E = "bert.embeddings."
+        if beta == 0:
+            # tables that are only ever accumulated into (+=) start from zero
+            self.G(E + "position_embeddings.weight").zero_()
+            self.G(E + "token_type_embeddings.weight").zero_()
+
+        # ---- heads ------------------------------------------------------------------------------------
+        if task == "vqa2":
+            NA, NAp = model.num_answers, ws["NAp"]
+            K.bce_loss_bwd(ws["vq_logits"], NAp, st_labels(st), st_labels(st).stride(0), B, NA, gscale, ws["vq_dlogits"], NAp)
+            self._tn(ws["vq_dlogits"], ws["vq_a1"], self.G("ans_classifier.2.weight"), B, NA, 2 * H, ws, beta)
+            K.colsum(ws["vq_dlogits"], self.G("ans_classifier.2.bias"), B, NA, beta=beta, workspace=ws["cs_ws"])
+            self._nt(ws["vq_dlogits"], sh["a2T"], ws["vq_dz1"], B, 2 * H, NAp, mul_src=ws["vq_a1"], mul_mode=K.MUL_RELU_MASK)
+            self._tn(ws["vq_dz1"], ws["vq_e"], self.G("ans_classifier.0.weight"), B, 2 * H, H, ws, beta)
+            K.colsum(ws["vq_dz1"], self.G("ans_classifier.0.bias"), B, 2 * H, beta=beta, workspace=ws["cs_ws"])
+            self._nt(ws["vq_dz1"], sh["a0T"], ws["vq_de"], B, H, 2 * H)
+            K.vqa_mul_bwd(x_last, ws["vq_de"], dx, B, L, Nv, H)
+            if beta == 0:
+                self.G(E + "word_embeddings.weight").zero_()     # no tied-decoder wgrad in this task: scatter needs zeros
+        else:
+            C = "cls.predictions."
+            R, Vp = B * P, ws["Vp"]
+            K.mlm_loss_bwd(ws["logits"], Vp, st_labels(st), ws["lse_ce"], ws["coef"], gscale, ws["dlogits"], Vp, R, V)
+            # tied decoder (modeling.py:445-448): dE[V,H] = dlogits^T . t ; the embedding scatter adds to it later
+            self._tn(ws["dlogits"], ws["tln"], self.G(E + "word_embeddings.weight"), R, V, H, ws, beta)
+            K.colsum(ws["dlogits"], self.G(C + "bias"), R, V, beta=beta, workspace=ws["cs_ws"])
+            self._nt(ws["dlogits"], sh["ET"], ws["dtln"], R, H, Vp)
+            K.layernorm_bwd(ws["dtln"], ws["tg"], self.P(C + "transform.LayerNorm.weight"), ws["tstat"][0], ws["tstat"][1], ws["dtg"],
+                            self.G(C + "transform.LayerNorm.weight"), self.G(C + "transform.LayerNorm.bias"), R, H, ws["ln_ws"], beta=beta)
+            K.gelu_bwd(ws["dtg"], ws["tz"], ws["dtz"], R * H)
+            self._tn(ws["dtz"], ws["sel"], self.G(C + "transform.dense.weight"), R, H, H, ws, beta)
+            K.colsum(ws["dtz"], self.G(C + "transform.dense.bias"), R, H, beta=beta, workspace=ws["cs_ws"])
+            self._nt(ws["dtz"], sh["tT"], ws["dsel"], R, H, H)
+            K.scatter_add_rows(ws["dsel"], H, masked_pos.contiguous(), dx, H, B, P, L, H)
+        self._bucket_done(0)
+
+        # ---- encoder layers, last to first ----------------------------------------------------------------
+        dpre, dpre_d, dz, dctx, dqkv = ws["dpre"], ws["dpre_d"], ws["dz"], ws["dctx"], ws["dqkv"]
+        scale = 1.0 / math.sqrt(H // A)
+        for i in reversed(range(NL)):
+            Ln = "bert.encoder.layer.%d." % i
+            a = ws["layers"][i]
+            s = sh["layers"][i]
+            x_in = ws["layers"][i - 1]["x2"] if i > 0 else ws["x0"]
+            # BertOutput: LN(dropout(dense(g)) + x1)   (modeling.py:353-357)
+            dd = dpre_d if p > 0 else None
+            K.layernorm_bwd(dx, a["pre2"], self.P(Ln + "output.LayerNorm.weight"), a["st2"][0], a["st2"][1], dpre,
+                            self.G(Ln + "output.LayerNorm.weight"), self.G(Ln + "output.LayerNorm.bias"), M, H, ws["ln_ws"], beta=beta,
+                            dx_drop=dd, out_drop=(p, seed, 16 * i + 3))
+            dy = dpre_d if p > 0 else dpre
+            self._tn(dy, a["g"], self.G(Ln + "output.dense.weight"), M, H, I, ws, beta)
+            K.colsum(dy, self.G(Ln + "output.dense.bias"), M, H, beta=beta, workspace=ws["cs_ws"])
+            self._nt(dy, s["w2T"], dz, M, I, H, mul_src=a["z"], mul_mode=K.MUL_GELU_GRAD)      # dG * gelu'(z)
+            # BertIntermediate (modeling.py:340-343)
+            self._tn(dz, a["x1"], self.G(Ln + "intermediate.dense.weight"), M, I, H, ws, beta)
+            K.colsum(dz, self.G(Ln + "intermediate.dense.bias"), M, I, beta=beta, workspace=ws["cs_ws"])
+            self._nt(dz, s["w1T"], dx, M, H, I, residual=dpre)                                  # + residual path of LN2's input
+            # BertSelfOutput: LN(dropout(dense(ctx)) + x)   (modeling.py:313-317)
+            K.layernorm_bwd(dx, a["pre1"], self.P(Ln + "attention.output.LayerNorm.weight"), a["st1"][0], a["st1"][1], dpre,
+                            self.G(Ln + "attention.output.LayerNorm.weight"), self.G(Ln + "attention.output.LayerNorm.bias"), M, H, ws["ln_ws"],
+                            beta=beta, dx_drop=dd, out_drop=(p, seed, 16 * i + 2))
+            dy = dpre_d if p > 0 else dpre
+            self._tn(dy, a["ctx"], self.G(Ln + "attention.output.dense.weight"), M, H, H, ws, beta)
+            K.colsum(dy, self.G(Ln + "attention.output.dense.bias"), M, H, beta=beta, workspace=ws["cs_ws"])
+            self._nt(dy, s["oT"], dctx, M, H, H)
+            # BertSelfAttention (modeling.py:268-303)
+            K.attn_bwd(a["qkv"], ws["maskb"], a["ctx"], dctx, a["lse"], dqkv, ws["delta"], B, L, A, scale, dropout_p=pa, seed=seed, rng_stream=16 * i + 1)
+            self._tn(dqkv, x_in, self.G(Ln + "attention.self.query.weight"), M, 3 * H, H, ws, beta)     # packed [3H, H] gradient
+            K.colsum(dqkv, self.G(Ln + "attention.self.query.bias"), M, 3 * H, beta=beta, workspace=ws["cs_ws"])
+            self._nt(dqkv, s["qkvT"], dx, M, H, 3 * H, residual=dpre)
+            self._bucket_done(NL - i)
+
+        # ---- embeddings -------------------------------------------------------------------------------------
+        K.layernorm_bwd(dx, ws["emb_pre"], self.P(E + "LayerNorm.weight"), ws["stat0"][0], ws["stat0"][1], dpre,
+                        self.G(E + "LayerNorm.weight"), self.G(E + "LayerNorm.bias"), M, H, ws["ln_ws"], beta=beta, dy_drop=(p, seed, 1000))
+        K.embed_bwd(dpre, input_ids, token_type_ids, ws["vis_h"], ws["vispe_h"], self.G(E + "word_embeddings.weight"),
+                    self.G(E + "position_embeddings.weight"), self.G(E + "token_type_embeddings.weight"), ws["d_vis_h"], ws["d_vispe_h"],
+                    ws["acc32"], B, L, Nv, H, V, cfg.type_vocab_size, drop_p=p, seed=seed, vis_stream=1001, vispe_stream=1002)
+        # vis_pe_embed: Linear(1607, H) -- wgrad into the padded shadow, then crop-accumulate
+        self._tn(ws["d_vispe_h"], ws["vpe_in"], ws["dwpe_pad"], Mv, H, PE_PAD, ws, 0)
+        K.copy2d(ws["dwpe_pad"], PE_PAD, False, self.G("vis_pe_embed.0.weight"), PE_DIM, H, PE_DIM, PE_DIM, beta=beta)
+        K.colsum(ws["d_vispe_h"], self.G("vis_pe_embed.0.bias"), Mv, H, beta=beta, workspace=ws["cs_ws"])
+        # vis_embed: Linear(2048,2048)+ReLU -> Linear(2048,H)+ReLU+Dropout
+        self._tn(ws["d_vis_h"], ws["h1"], self.G("vis_embed.2.weight"), Mv, H, 2048, ws, beta)
+        K.colsum(ws["d_vis_h"], self.G("vis_embed.2.bias"), Mv, H, beta=beta, workspace=ws["cs_ws"])
+        self._nt(ws["d_vis_h"], sh["v2T"], ws["dz1v"], Mv, 2048, H, mul_src=ws["h1"], mul_mode=K.MUL_RELU_MASK)
+        self._tn(ws["dz1v"], img, self.G("vis_embed.0.weight"), Mv, 2048, 2048, ws, beta)
+        K.colsum(ws["dz1v"], self.G("vis_embed.0.bias"), Mv, 2048, beta=beta, workspace=ws["cs_ws"])
+        self._bucket_done(NL + 1)
+        self.grads_dirty = True
+        if self.post_backward_hook is not None:
+            self.post_backward_hook()
+
+
+def st_labels(st):
+    return st.task_labels
