@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""Headline benchmark of the VLP hot path on MI355X (contract in the task brief / BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one full training iteration of the reference's loop (run_img2txt_dist.py:479-585) on a synthetic
+COCO-shape batch that is already resident in HBM: forward (region projections, embeddings, 12 BertLayers, LM head,
+masked-LM loss) + backward + loss-scaled fused Adam (+ RCCL gradient buckets when N > 1), dropout 0.1 as in training.
+Workload = BASELINE.json configs[1]: BERT-base 12L, 100 regions, seq_len 64 (L = 64+100+3 = 167), batch 64 per GPU, fp16.
+Rank 0 prints ONE JSON line: whole-job samples/s, plus
+  roofline     -- the dominant kernel (gemm_nt_kernel: every forward / dgrad GEMM): algorithmic FLOPs per launch /
+                  average launch duration, both measured live with HIP events on the launch stream over the timed steps;
+  cpu_baseline -- the oracle (CPU restatement of the reference, fp32 fwd+bwd+BertAdam) timed on this box's host cores
+                  on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "samples/sec/node (COCO 100-region, seq64, bs64xN) fp16"
+MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+FLOP_PER_SAMPLE = 92.805e9         # fwd+bwd dense contractions at L=167
+
+
+def cpu_baseline_worker(seconds_budget, threads):
+    """oracle (kind 'port'): fp32 forward + backward + BertAdam on the host cores, B=8, L=167, 12 layers."""
+    torch.set_num_threads(threads)
+    from oracle import vlp_oracle as O
+    from vlp_amd import synthetic as S
+    B = 8
+    p = O.init_params(vocab_size=28996, layers=12, tasks="img2txt", seed=0)
+    p = {k: v.requires_grad_(True) for k, v in p.items()}
+    batch = S.make_batch(B, max_len_b=64, vocab_size=28996, max_pred=3, seed=1234)
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v = {k: torch.zeros_like(t) for k, t in p.items()}
+
+    def step():
+        for t in p.values():
+            t.grad = None
+        O.loss_and_grads(p, batch, tasks="img2txt")
+        with torch.no_grad():
+            for k, t in p.items():
+                if t.grad is not None:
+                    O.bert_adam_step(t, t.grad, m[k], v[k], 1, lr=3e-5, warmup=0.1, t_total=1000,
+                                     weight_decay=0.0 if ("bias" in k or "LayerNorm" in k) else 0.01)
+
+    t0 = time.time()
+    step()                                   # warm-up (also the fallback measurement on a very slow host)
+    warm = time.time() - t0
+    n, t0 = 0, time.time()
+    while time.time() - t0 + warm < seconds_budget and n < 8:
+        step()
+        n += 1
+    dt = time.time() - t0
+    if n == 0:
+        n, dt = 1, warm
+    return {"value": round(B * n / dt, 3), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": "%d steps of B=%d, L=167, 12 layers, fp32 fwd+bwd+BertAdam (oracle/vlp_oracle.py), %d of %d host threads"
+                      % (n, B, threads, os.cpu_count() or 1)}
+
+
+def cpu_baseline(seconds_budget=25.0, hard_timeout=150.0):
+    """Runs the worker in a fresh process (no HIP context, bounded wall time)."""
+    import subprocess
+    threads = min(os.cpu_count() or 1, 32)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", str(seconds_budget), str(threads)],
+                           capture_output=True, text=True, timeout=hard_timeout, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "samples/s", "cores": threads, "kind": "port", "sample": "worker failed: " + r.stderr[-200:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "samples/s", "cores": threads, "kind": "port", "sample": "timed out after %ds" % hard_timeout}
+
+
+def main():
+    if len(sys.argv) >= 2 and sys.argv[1] == "--cpu-baseline-only":
+        print(json.dumps(cpu_baseline_worker(float(sys.argv[2]), int(sys.argv[3]))))
+        return
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE: 64)")
+    ap.add_argument("--max_len_b", type=int, default=64)
+    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: vlp_amd has no CPU path")
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+
+    from vlp_amd import synthetic as S
+    from vlp_amd.distributed import DistributedDataParallel as DDP
+    from vlp_amd.modeling import BertConfig, BertForPreTrainingLossMask
+    from vlp_amd.optimization import warmup_linear
+    from vlp_amd.optimization_fp16 import FP16_Optimizer_State, FusedAdam
+    from vlp_amd.run_img2txt_dist import train_step
+
+    torch.manual_seed(0)
+    cfg = BertConfig(28996, num_hidden_layers=args.layers, type_vocab_size=6, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    model = BertForPreTrainingLossMask(cfg, num_labels=2, enable_butd=True, len_vis_input=100, tasks="img2txt", allow_random_fc7=True)
+    model.half().to(dev)
+    eng = model.engine
+    if world > 1:
+        model = DDP(model, device_ids=[local_rank], output_device=local_rank, find_unused_parameters=True)
+    named = list(model.named_parameters())
+    no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
+    groups = [{"params": [p for n, p in named if not any(nd in n for nd in no_decay)], "weight_decay": 0.01},
+              {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": 0.0}]
+    opt = FP16_Optimizer_State(FusedAdam(groups, lr=3e-5, bias_correction=False, max_grad_norm=1.0), dynamic_loss_scale=True)
+    model.train()
+    pool = [S.batch_to(S.make_batch(args.batch, max_len_b=args.max_len_b, vocab_size=28996, max_pred=3, s2s_prob=1.0,
+                                    seed=1234 + 100 * rank + i), dev, half=True) for i in range(2)]
+    t_total = 100000
+
+    def one(i):
+        return train_step(model, opt, pool[i % len(pool)], 3e-5 * warmup_linear((i + 1) / t_total, 0.1))
+
+    for i in range(args.warmup):
+        lt = one(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    if not args.no_kernel_events:
+        eng.prof = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        lt = one(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    loss = float(lt[0].detach())
+    prof, eng.prof = eng.prof, None
+
+    if rank == 0:
+        roof = None
+        if prof:
+            ms = [a.elapsed_time(b) for a, b, _ in prof]
+            flops = [f for _, _, f in prof]
+            achieved = (sum(flops) / len(flops)) / (sum(ms) / len(ms) * 1e-3) / 1e12
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if os.path.exists(tf):
+                try:
+                    traffic = json.load(open(tf)).get("gemm_nt_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<1> (all forward + dgrad GEMMs)", "achieved": round(achieved, 1),
+                    "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "launches_per_step": len(prof) // max(args.steps, 1), "avg_launch_us": round(sum(ms) / len(ms) * 1e3, 2),
+                    "avg_gflop_per_launch": round(sum(flops) / len(flops) / 1e9, 3),
+                    "step_mfma_frac": round((world * args.batch * args.steps / dt) / world * FLOP_PER_SAMPLE / (MFMA_PEAK_TFLOPS * 1e12), 4)}
+        out = {"metric": METRIC, "value": round(world * args.batch * args.steps / dt, 2), "unit": "samples/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+               "config": {"workload": "COCO Captions fine-tune shape: BERT-base %dL, 100 regions x 2048-d, seq_len %d (L=%d), bs %d/GPU, "
+                                      "fwd+bwd+FP16 FusedAdam, dropout 0.1, dynamic loss scale" % (args.layers, args.max_len_b, args.max_len_b + 103, args.batch),
+                          "global_batch": world * args.batch, "parallelism": "dp%d" % world, "final_loss": round(loss, 4),
+                          "loss_scale": opt.cur_scale, "skipped_steps": opt.skipped_steps},
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -294,10 +294,15 @@ typedef struct {
 } vlp_fused_adam_args;
 int vlp_fused_adam(const vlp_fused_adam_args* a, void* stream);
 /* device-side scalar logic of FP16_Optimizer.step + FusedAdam.step for one param group:
- *   norm = sqrt(sumsq[0]); overflow = sumsq[1] (or any_overflow[0]);
- *   clip = (norm/scale + 1e-6)/max_grad_norm; combined = scale * max(clip, 1); hyper = {combined, lr, overflow} */
-int vlp_adam_hyper(const float* sumsq2, const float* any_overflow, float loss_scale, float max_grad_norm,
+ *   scale = scale_state[0]; norm = sqrt(sumsq[0]); overflow = max(sumsq[1], any_overflow[0]);
+ *   clip = (norm/scale + 1e-6)/max_grad_norm; combined = scale * max(clip, 1); hyper = {combined, step_size, overflow} */
+int vlp_adam_hyper(const float* sumsq2, const float* any_overflow, const float* scale_state, float max_grad_norm,
                    float step_size, float* hyper3, void* stream);
+/* apex FP16_Optimizer._update_scale on the device, so the loss scale never forces a host sync.
+ * scale_state (8 device floats) = {cur_scale, cur_iter, last_overflow_iter, scale_factor, scale_window, dynamic,
+ * skipped_steps, reserved}: on overflow cur_scale = max(cur_scale / factor, 1), last_overflow_iter = cur_iter; otherwise
+ * cur_scale *= factor whenever (cur_iter - last_overflow_iter) % window == 0; then cur_iter += 1. */
+int vlp_loss_scale_update(float* scale_state, const float* overflow, void* stream);
 
 /* BertAdam (optimization.py:112-182) over a flat fp32 master buffer made of `ntensors` tensors:
  * per-tensor L2 clip to max_grad_norm (:146-147), no bias correction, decoupled decay, lr already

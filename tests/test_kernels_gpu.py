@@ -445,10 +445,11 @@ def test_fused_adam_and_norm(gen):
     p16 = torch.empty(n, device=DEV, dtype=torch.half)
     out2, part, hyper = torch.zeros(2, device=DEV), torch.zeros(2048, device=DEV), torch.zeros(3, device=DEV)
     scale = 1024.0
+    sstate = torch.tensor([scale, 0, -1, 2, 1000, 1, 0, 0], device=DEV, dtype=torch.float32)
     rp, rm, rv = p32.cpu().clone(), m.cpu().clone(), v.cpu().clone()
     for step in range(2):
         K.sumsq(g16, n, out2, part)
-        K.adam_hyper(out2, None, scale, 1.0, 3e-5, hyper)
+        K.adam_hyper(out2, None, sstate, 1.0, 3e-5, hyper)
         K.fused_adam(p32, m, v, g16, p16, n, hyper, decay=0.01)
         norm = float(g16.float().norm())
         assert abs(math.sqrt(float(out2[0])) - norm) < 1e-4 * norm and float(out2[1]) == 0
@@ -461,9 +462,16 @@ def test_fused_adam_and_norm(gen):
     g_bad[777] = float("inf")
     before = p32.clone()
     K.sumsq(g_bad, n, out2, part)
-    K.adam_hyper(out2, None, scale, 1.0, 3e-5, hyper)
+    K.adam_hyper(out2, None, sstate, 1.0, 3e-5, hyper)
     K.fused_adam(p32, m, v, g_bad, p16, n, hyper)
     assert float(out2[1]) == 1.0 and float(hyper[2]) == 1.0 and torch.equal(before, p32)
+    # device-side loss-scale bookkeeping vs the oracle's restatement of apex
+    ls = O.LossScaler(dynamic=True, init_scale=scale, scale_window=3)
+    sstate = torch.tensor([scale, 0, -1, 2, 3, 1, 0, 0], device=DEV, dtype=torch.float32)
+    for ovf in (0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 0):
+        K.loss_scale_update(sstate, torch.tensor([float(ovf)], device=DEV))
+        ls.update(bool(ovf))
+        assert float(sstate[0]) == ls.cur_scale and int(sstate[1]) == ls.cur_iter and int(sstate[2]) == ls.last_overflow_iter
 
 
 @pytest.mark.parametrize("g_is_f32", [True, False])

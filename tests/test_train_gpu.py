@@ -1,0 +1,158 @@
+"""GPU: optimizer parity (fused Adam / BertAdam vs the oracle's restatements), the train-loop contract, the entry
+script on synthetic data, checkpoint round trip."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+if not torch.cuda.is_available():
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+from oracle import vlp_oracle as O                                      # noqa: E402 (checker)
+from vlp_amd import synthetic as S                                      # noqa: E402
+from vlp_amd.modeling import BertConfig, BertForPreTrainingLossMask     # noqa: E402
+from vlp_amd.optimization import BertAdam, warmup_linear                # noqa: E402
+from vlp_amd.optimization_fp16 import FP16_Optimizer_State, FusedAdam   # noqa: E402
+from vlp_amd.run_img2txt_dist import train_step                         # noqa: E402
+
+DEV = torch.device("cuda:0")
+ND = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
+
+
+def small_model(tasks="img2txt", drop=0.0, seed=3, layers=2):
+    p = O.init_params(vocab_size=1024, layers=layers, tasks=tasks, seed=seed)
+    cfg = BertConfig(1024, num_hidden_layers=layers, type_vocab_size=6, hidden_dropout_prob=drop, attention_probs_dropout_prob=drop)
+    m = BertForPreTrainingLossMask(cfg, enable_butd=True, len_vis_input=100, tasks=tasks, allow_random_fc7=True)
+    sd = dict(p)
+    sd["cls.predictions.decoder.weight"] = p["bert.embeddings.word_embeddings.weight"]
+    m.load_state_dict(sd, strict=True)
+    return m.half().to(DEV), p
+
+
+def groups_of(model):
+    named = list(model.named_parameters())
+    return [{"params": [q for n, q in named if not any(x in n for x in ND)], "weight_decay": 0.01},
+            {"params": [q for n, q in named if any(x in n for x in ND)], "weight_decay": 0.0}]
+
+
+def fwd_bwd(model, opt, batch):
+    b = batch
+    lt = model(b.img, b.vis_pe, b.input_ids, b.segment_ids, b.input_mask, b.lm_label_ids, b.ans_labels, b.is_next, masked_pos=b.masked_pos,
+               masked_weights=b.masked_weights, task_idx=b.task_idx, vis_masked_pos=b.vis_masked_pos, drop_worst_ratio=0)
+    opt.backward(lt[0] + lt[1] + lt[2])
+    return lt
+
+
+def test_fp16_optimizer_step_matches_apex_restatement():
+    model, _ = small_model()
+    model.train()
+    opt = FP16_Optimizer_State(FusedAdam(groups_of(model), lr=1e-3, bias_correction=False, max_grad_norm=1.0), dynamic_loss_scale=True)
+    batch = S.batch_to(S.make_batch(4, max_len_b=20, vocab_size=1024, max_pred=3, seed=1), DEV, half=True)
+    eng = model.engine
+    assert opt.cur_scale == 65536.0
+    for it in range(2):
+        fwd_bwd(model, opt, batch)
+        want = []
+        for i, key in enumerate(opt._group_key):
+            g16 = eng.gflat[key].clone()
+            norm = float(g16.float().norm())
+            p32, m, v = opt.fp32_groups_flat[i].clone(), opt._m[i].clone(), opt._v[i].clone()
+            O.fused_adam_step(p32, g16, m, v, lr=1e-3, grad_norm_scaled=norm, scale=opt.cur_scale, weight_decay=opt.param_groups[i]["weight_decay"])
+            want.append((p32, m, v))
+        for g in opt.param_groups:
+            g["lr"] = 1e-3
+        opt.step()
+        opt.zero_grad()
+        assert not opt.overflow
+        for i, key in enumerate(opt._group_key):
+            p32, m, v = want[i]
+            assert float((opt.fp32_groups_flat[i] - p32).abs().max()) <= 1e-6 * float(p32.abs().max()) + 1e-9
+            assert float((opt._m[i] - m).abs().max()) <= 1e-5 * float(m.abs().max()) + 1e-12
+            assert float((eng.flat[key].float() - p32).abs().max()) <= 1e-3 * float(p32.abs().max())    # fp16 model copy
+    assert opt.cur_iter == 2
+
+
+def test_overflow_skips_step_and_halves_scale():
+    model, _ = small_model()
+    model.train()
+    opt = FP16_Optimizer_State(FusedAdam(groups_of(model), lr=1e-3, bias_correction=False, max_grad_norm=1.0), dynamic_loss_scale=True,
+                               dynamic_loss_args={"init_scale": 2.0 ** 30})
+    batch = S.batch_to(S.make_batch(4, max_len_b=20, vocab_size=1024, max_pred=3, seed=1), DEV, half=True)
+    before = model.engine.flat["decay"].clone()
+    fwd_bwd(model, opt, batch)                 # 2^30 x gradient overflows fp16
+    opt.step()
+    opt.zero_grad()
+    assert opt.overflow and opt.cur_scale == 2.0 ** 29 and opt.skipped_steps == 1
+    assert torch.equal(before, model.engine.flat["decay"])
+
+
+def test_training_reduces_loss_and_checkpoint_round_trip(tmp_path):
+    model, _ = small_model(drop=0.1)
+    model.train()
+    opt = FP16_Optimizer_State(FusedAdam(groups_of(model), lr=2e-4, bias_correction=False, max_grad_norm=1.0), dynamic_loss_scale=True)
+    batch = S.batch_to(S.make_batch(8, max_len_b=20, vocab_size=1024, max_pred=3, seed=2), DEV, half=True)
+    losses = []
+    for it in range(30):
+        lt = train_step(model, opt, batch, 2e-4)
+        losses.append(float(lt[0]))
+    assert all(l == l for l in losses)                       # no NaN
+    assert sum(losses[-5:]) / 5 < 0.7 * sum(losses[:5]) / 5, losses
+    # checkpoint: same keys as the reference, loads into a fresh model and reproduces the eval loss
+    import copy
+    sd = copy.deepcopy(model).cpu().state_dict()
+    assert "cls.predictions.decoder.weight" in sd and all(not v.is_cuda for v in sd.values())
+    torch.save(sd, os.path.join(tmp_path, "model.1.bin"))
+    m2, _ = small_model(seed=99)
+    m2.load_state_dict(torch.load(os.path.join(tmp_path, "model.1.bin")), strict=True)
+    m2 = m2.half().to(DEV).eval()
+    model.eval()
+    b = batch
+    args = (b.img, b.vis_pe, b.input_ids, b.segment_ids, b.input_mask, b.lm_label_ids, b.ans_labels, b.is_next)
+    kw = dict(masked_pos=b.masked_pos, masked_weights=b.masked_weights, drop_worst_ratio=0)
+    with torch.no_grad():
+        assert float(model(*args, **kw)[0]) == float(m2(*args, **kw)[0])
+    # optimizer state_dict carries the reference's fields (optimization_fp16.py:28-37)
+    osd = opt.state_dict()
+    for k in ("dynamic_loss_scale", "cur_scale", "cur_iter", "last_overflow_iter", "scale_factor", "scale_window", "optimizer_state_dict",
+              "fp32_groups_flat"):
+        assert k in osd
+    opt.load_state_dict(osd)
+
+
+def test_bert_adam_on_model_matches_reference_restatement():
+    model, p0 = small_model()
+    model.train()
+    opt = BertAdam(groups_of(model), lr=1e-3, warmup=0.1, t_total=20)
+    batch = S.batch_to(S.make_batch(4, max_len_b=20, vocab_size=1024, max_pred=3, seed=1), DEV, half=True)
+    b = batch
+    ref = {k: v.clone() for k, v in p0.items()}
+    rm = {k: torch.zeros_like(v) for k, v in ref.items()}
+    rv = {k: torch.zeros_like(v) for k, v in ref.items()}
+    unused = model.engine.unused_parameter_names() if model.engine.packed else {"bert.pooler.dense.weight", "bert.pooler.dense.bias"}
+    for step in range(2):
+        lt = model(b.img, b.vis_pe, b.input_ids, b.segment_ids, b.input_mask, b.lm_label_ids, b.ans_labels, b.is_next, masked_pos=b.masked_pos,
+                   masked_weights=b.masked_weights, drop_worst_ratio=0)
+        (lt[0] + lt[1] + lt[2]).backward()
+        grads = {n: q.grad.detach().float().cpu().clone() for n, q in model.named_parameters()}
+        for n in ref:
+            if n in unused:
+                continue
+            O.bert_adam_step(ref[n], grads[n], rm[n], rv[n], step, lr=1e-3, warmup=0.1, t_total=20,
+                             weight_decay=0.0 if any(x in n for x in ND) else 0.01)
+        opt.step()
+        opt.zero_grad()
+    for n, q in model.named_parameters():
+        # fp32 masters inside the optimizer follow the restatement; the model holds their fp16 rounding
+        assert float((q.detach().float().cpu() - ref[n]).abs().max()) <= 1.5e-3 * float(ref[n].abs().max()) + 1e-6, n
+    assert opt.get_lr()[0] == pytest.approx(1e-3 * warmup_linear(2 / 20, 0.1))
+
+
+def test_entry_script_synthetic(tmp_path):
+    from vlp_amd import run_img2txt_dist as R
+    out = os.path.join(tmp_path, "run")
+    R.main(["--output_dir", out, "--do_train", "--fp16", "--enable_butd", "--new_segment_ids", "--from_scratch", "--max_len_b", "20",
+            "--train_batch_size", "4", "--num_train_epochs", "1", "--synthetic", "3", "--num_hidden_layers", "2", "--len_vis_input", "100"])
+    assert os.path.exists(os.path.join(out, "model.1.bin")) and os.path.exists(os.path.join(out, "opt.json"))
+    sd = torch.load(os.path.join(out, "model.1.bin"))
+    assert "bert.encoder.layer.1.output.LayerNorm.bias" in sd and sd["bert.embeddings.word_embeddings.weight"].shape == (28996, 768)

@@ -132,7 +132,8 @@ SYMBOLS = {
     "vlp_bce_loss_bwd": (C.c_int, [vp, i64, vp, i64, i32, i32, vp, vp, i64, vp]),
     "vlp_sumsq": (C.c_int, [vp, i64, vp, vp, vp]),
     "vlp_fused_adam": (C.c_int, [C.POINTER(FusedAdamArgs), vp]),
-    "vlp_adam_hyper": (C.c_int, [vp, vp, f32, f32, f32, vp, vp]),
+    "vlp_adam_hyper": (C.c_int, [vp, vp, vp, f32, f32, vp, vp]),
+    "vlp_loss_scale_update": (C.c_int, [vp, vp, vp]),
     "vlp_bert_adam": (C.c_int, [C.POINTER(BertAdamArgs), vp]),
 }
 
@@ -337,9 +338,14 @@ def sumsq(g16, n, out2, partial):
     _check(load().vlp_sumsq(ptr(g16), n, ptr(out2), ptr(partial), stream_ptr()))
 
 
-def adam_hyper(sumsq2, any_overflow, loss_scale, max_grad_norm, step_size, hyper3):
-    _req_cuda(sumsq2, hyper3)
-    _check(load().vlp_adam_hyper(ptr(sumsq2), ptr(any_overflow), loss_scale, max_grad_norm, step_size, ptr(hyper3), stream_ptr()))
+def adam_hyper(sumsq2, any_overflow, scale_state, max_grad_norm, step_size, hyper3):
+    _req_cuda(sumsq2, hyper3, scale_state)
+    _check(load().vlp_adam_hyper(ptr(sumsq2), ptr(any_overflow), ptr(scale_state), max_grad_norm, step_size, ptr(hyper3), stream_ptr()))
+
+
+def loss_scale_update(scale_state, overflow):
+    _req_cuda(scale_state, overflow)
+    _check(load().vlp_loss_scale_update(ptr(scale_state), ptr(overflow), stream_ptr()))
 
 
 def fused_adam(p32, m, v, g16, p16, n, hyper, b1=0.9, b2=0.999, eps=1e-8, decay=0.0, eps_inside_sqrt=False):

@@ -70,8 +70,10 @@ extern "C" int vlp_sumsq(const void* g, int64_t n, float* out2, float* partial, 
     return VLP_OK;
 }
 
-__global__ void adam_hyper_kernel(const float* sumsq2, const float* any_overflow, float scale, float max_grad_norm, float step_size, float* hyper) {
+__global__ void adam_hyper_kernel(const float* sumsq2, const float* any_overflow, const float* scale_state, float max_grad_norm, float step_size,
+                                  float* hyper) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float scale = scale_state[0];
     float overflow = sumsq2[1];
     if (any_overflow) overflow = fmaxf(overflow, any_overflow[0]);
     const float norm = sqrtf(sumsq2[0]);          // = true norm * scale
@@ -84,11 +86,34 @@ __global__ void adam_hyper_kernel(const float* sumsq2, const float* any_overflow
     hyper[1] = step_size;
     hyper[2] = overflow;
 }
-extern "C" int vlp_adam_hyper(const float* sumsq2, const float* any_overflow, float loss_scale, float max_grad_norm, float step_size, float* hyper3,
-                              void* stream) {
-    VLP_CHECK_ARG(sumsq2 && hyper3 && loss_scale > 0.f, "vlp_adam_hyper: bad args");
-    hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sumsq2, any_overflow, loss_scale, max_grad_norm, step_size, hyper3);
+extern "C" int vlp_adam_hyper(const float* sumsq2, const float* any_overflow, const float* scale_state, float max_grad_norm, float step_size,
+                              float* hyper3, void* stream) {
+    VLP_CHECK_ARG(sumsq2 && hyper3 && scale_state, "vlp_adam_hyper: bad args");
+    hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sumsq2, any_overflow, scale_state, max_grad_norm, step_size, hyper3);
     VLP_CHECK_LAUNCH("vlp_adam_hyper");
+    return VLP_OK;
+}
+
+// apex FP16_Optimizer._update_scale on the device.  state = {cur_scale, cur_iter, last_overflow_iter, scale_factor,
+// scale_window, dynamic, n_skipped, reserved}
+__global__ void loss_scale_update_kernel(float* st, const float* overflow) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool skip = overflow[0] != 0.f;
+    if (st[5] != 0.f) {
+        if (skip) {
+            st[0] = fmaxf(st[0] / st[3], 1.f);
+            st[2] = st[1];
+        } else if (fmodf(st[1] - st[2], st[4]) == 0.f) {
+            st[0] = st[0] * st[3];
+        }
+    }
+    if (skip) st[6] += 1.f;
+    st[1] += 1.f;
+}
+extern "C" int vlp_loss_scale_update(float* scale_state, const float* overflow, void* stream) {
+    VLP_CHECK_ARG(scale_state && overflow, "vlp_loss_scale_update: bad args");
+    hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scale_state, overflow);
+    VLP_CHECK_LAUNCH("vlp_loss_scale_update");
     return VLP_OK;
 }
 

@@ -57,6 +57,7 @@ class Engine(object):
         self.post_backward_hook = None    # callable() set by the DDP wrapper
         self._ws = {}
         self._shadow = None
+        self.prof = None                  # list -> every NT-GEMM launch is bracketed by HIP events (bench.py roofline)
 
     # ------------------------------------------------------------------------------------------
     # parameter packing
@@ -267,7 +268,15 @@ class Engine(object):
     # forward
     # ------------------------------------------------------------------------------------------
     def _nt(self, x, w, y, M, N, Kd, **kw):
+        if self.prof is None:
+            K.gemm_nt(x, w, y, M, N, Kd, variant=self.GEMM_NT_VARIANT, **kw)
+            return
+        # events are recorded on torch's current stream == the stream handed to the C ABI
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         K.gemm_nt(x, w, y, M, N, Kd, variant=self.GEMM_NT_VARIANT, **kw)
+        e1.record()
+        self.prof.append((e0, e1, 2.0 * M * N * Kd))
 
     def forward(self, vis_feats, vis_pe, input_ids, token_type_ids, attention_mask, masked_pos, train, want_mlm, want_vqa):
         """Runs embeddings + encoder (+ heads' forward up to the logits).  Returns the _State."""

@@ -264,6 +264,8 @@ class PreTrainedBertModel(nn.Module):
             p.grad = None
             if hasattr(p, "_vlp_engine"):
                 del p._vlp_engine
+            if new.__dict__["_engine"] is not None:
+                p._vlp_owner = new.__dict__["_engine"]
         return new
 
     def state_dict(self, *args, **kwargs):
@@ -460,6 +462,8 @@ class BertForPreTrainingLossMask(PreTrainedBertModel):
             self.ans_classifier = nn.Sequential(nn.Linear(config.hidden_size, config.hidden_size * 2), nn.ReLU(),
                                                 nn.Linear(config.hidden_size * 2, self.num_answers))
         self.__dict__["_engine"] = Engine(self)
+        for prm in self.parameters():          # lets optimizers / DDP find the engine before the first forward packs
+            prm._vlp_owner = self.__dict__["_engine"]
 
     @property
     def engine(self):

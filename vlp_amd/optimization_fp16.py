@@ -1,0 +1,201 @@
+"""Drop-in for `pytorch_pretrained_bert.optimization_fp16` + the apex pieces it wraps, on MI355X.
+
+The reference trains fp16 with `FP16_Optimizer_State(FusedAdam(groups, lr, bias_correction=False,
+max_grad_norm=1.0), dynamic_loss_scale=True)` (run_img2txt_dist.py:411-420), `.backward(loss)` (:571),
+per-step `param_group['lr'] = ...` (:580-583), `.step()` / `.zero_grad()` (:584-585).  apex is CUDA-only and
+absent here; this module restates that contract on the flat buffers of vlp_amd.engine.Engine:
+
+  per param group (weight-decay group / no-decay group):
+      vlp_sumsq          -> grad L2 norm (still x loss scale) + inf/nan flag            [apex _compute_grad_norm]
+      vlp_adam_hyper     -> clip folded into the unscale factor, skip flag             [FusedAdam.step scalar logic]
+      vlp_fused_adam     -> fp32 master, m, v update + fp16 model copy in one pass     [fused_adam_cuda.adam]
+  vlp_loss_scale_update  -> dynamic loss scale bookkeeping                               [FP16_Optimizer._update_scale]
+
+Every scalar decision stays on the device: a training step issues no host synchronisation
+(`cur_scale`, `overflow` are read back lazily, only when inspected).
+"""
+import torch
+
+from . import _lib as K
+from .engine import is_no_decay
+
+
+class FusedAdam(object):
+    """Hyper-parameter holder with apex.optimizers.FusedAdam's constructor.  It only works wrapped in
+    FP16_Optimizer_State (exactly how the reference uses it)."""
+
+    def __init__(self, params, lr=1e-3, bias_correction=True, betas=(0.9, 0.999), eps=1e-8, eps_inside_sqrt=False,
+                 weight_decay=0., max_grad_norm=0., amsgrad=False):
+        if amsgrad:
+            raise RuntimeError("FusedAdam does not support the AMSGrad variant.")
+        params = list(params)
+        if len(params) == 0:
+            raise ValueError("optimizer got an empty parameter list")
+        if not isinstance(params[0], dict):
+            params = [{"params": params}]
+        self.defaults = dict(lr=lr, bias_correction=bias_correction, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+        self.param_groups = []
+        for g in params:
+            g = dict(g)
+            g["params"] = list(g["params"])
+            for k, v in self.defaults.items():
+                g.setdefault(k, v)
+            self.param_groups.append(g)
+        self.eps_mode = 0 if eps_inside_sqrt else 1
+        self.state = {}
+
+    def step(self, *a, **k):
+        raise NotImplementedError("vlp_amd.FusedAdam is driven by FP16_Optimizer_State.step() (the only way the reference uses it)")
+
+    def zero_grad(self):
+        pass
+
+    def state_dict(self):
+        return {"param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups], "state": self.state}
+
+    def load_state_dict(self, sd):
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update(s)
+        self.state = sd.get("state", {})
+
+
+class FP16_Optimizer_State(object):
+    """apex FP16_Optimizer (FusedAdam flavour) + the state_dict extensions of the reference's subclass
+    (optimization_fp16.py:17-80)."""
+
+    def __init__(self, init_optimizer, static_loss_scale=1.0, dynamic_loss_scale=False, dynamic_loss_args=None, verbose=True):
+        if not isinstance(init_optimizer, FusedAdam):
+            raise TypeError("FP16_Optimizer_State expects a vlp_amd.optimization_fp16.FusedAdam")
+        self.optimizer = init_optimizer
+        self.param_groups = init_optimizer.param_groups
+        eng = None
+        for g in self.param_groups:
+            for p in g["params"]:
+                eng = eng or getattr(p, "_vlp_engine", None) or getattr(p, "_vlp_owner", None)
+        if eng is None:
+            raise RuntimeError("FP16_Optimizer_State: parameters do not belong to a vlp_amd model")
+        eng.pack()
+        self.engine = eng
+        # map the caller's param groups onto the engine's two flat buffers
+        name_of = {id(p): n for n, p in eng._params.items()}
+        self._group_key = []
+        for g in self.param_groups:
+            names = [name_of[id(p)] for p in g["params"]]
+            kinds = {is_no_decay(n) for n in names}
+            if len(kinds) != 1:
+                raise RuntimeError("FP16_Optimizer_State: a param group mixes decay / no-decay parameters; use the reference's two groups "
+                                   "(run_img2txt_dist.py:394-401)")
+            key = "nodecay" if kinds.pop() else "decay"
+            if set(names) != set(eng.names[key]):
+                raise RuntimeError("FP16_Optimizer_State: group does not cover the model's whole %s set" % key)
+            self._group_key.append(key)
+        if sorted(self._group_key) != ["decay", "nodecay"]:
+            raise RuntimeError("FP16_Optimizer_State: expected exactly one decay and one no-decay group")
+        dev = eng.device
+        self.fp32_groups_flat = [eng.flat[k].float() for k in self._group_key]      # master weights
+        self._m = [torch.zeros_like(t) for t in self.fp32_groups_flat]
+        self._v = [torch.zeros_like(t) for t in self.fp32_groups_flat]
+        self._sumsq = [torch.zeros(2, device=dev) for _ in self._group_key]
+        self._hyper = [torch.zeros(3, device=dev) for _ in self._group_key]
+        self._partial = torch.zeros(2048, device=dev)
+        self._ovf = torch.zeros(1, device=dev)
+        self.dynamic_loss_scale = bool(dynamic_loss_scale)
+        if dynamic_loss_scale:
+            args = dynamic_loss_args or {}
+            init, factor, window = args.get("init_scale", 2 ** 16), args.get("scale_factor", 2), args.get("scale_window", 1000)
+        else:
+            init, factor, window = static_loss_scale, 2, 1000
+        # {cur_scale, cur_iter, last_overflow_iter, scale_factor, scale_window, dynamic, skipped, -}
+        self._scale_state = torch.tensor([init, 0, -1, factor, window, 1.0 if dynamic_loss_scale else 0.0, 0, 0], device=dev, dtype=torch.float32)
+        self.verbose = verbose
+        self._nstep = 0
+
+    # ---- lazily synchronised views of the device-side state -------------------------------------------
+    @property
+    def cur_scale(self):
+        return float(self._scale_state[0])
+
+    @property
+    def cur_iter(self):
+        return int(self._scale_state[1])
+
+    @property
+    def last_overflow_iter(self):
+        return int(self._scale_state[2])
+
+    @property
+    def scale_factor(self):
+        return float(self._scale_state[3])
+
+    @property
+    def scale_window(self):
+        return int(self._scale_state[4])
+
+    @property
+    def overflow(self):
+        return bool(self._ovf[0] != 0)
+
+    @property
+    def skipped_steps(self):
+        return int(self._scale_state[6])
+
+    # ---- the train-loop contract -------------------------------------------------------------------------
+    def backward(self, loss):
+        """apex: scaled_loss = loss.float() * cur_scale; scaled_loss.backward()   (run_img2txt_dist.py:571)"""
+        (loss.float() * self._scale_state[0]).backward()
+
+    def zero_grad(self, set_grads_to_None=True):
+        self.engine.zero_grad()
+
+    def step(self, closure=None):
+        eng = self.engine
+        for i, key in enumerate(self._group_key):
+            K.sumsq(eng.gflat[key], eng.sizes[key], self._sumsq[i], self._partial)
+        # apex skips the whole step when ANY group overflowed
+        torch.maximum(self._sumsq[0][1:2], self._sumsq[1][1:2], out=self._ovf)
+        for i, key in enumerate(self._group_key):
+            g = self.param_groups[i]
+            b1, b2 = g["betas"]
+            if g["bias_correction"]:
+                t = self._nstep + 1
+                step_size = g["lr"] * (1 - b2 ** t) ** 0.5 / (1 - b1 ** t)
+            else:
+                step_size = g["lr"]
+            K.adam_hyper(self._sumsq[i], self._ovf, self._scale_state, g["max_grad_norm"], step_size, self._hyper[i])
+            K.fused_adam(self.fp32_groups_flat[i], self._m[i], self._v[i], eng.gflat[key], eng.flat[key], eng.sizes[key], self._hyper[i],
+                         b1=b1, b2=b2, eps=g["eps"], decay=g["weight_decay"], eps_inside_sqrt=(self.optimizer.eps_mode == 0))
+        K.loss_scale_update(self._scale_state, self._ovf)
+        self._nstep += 1
+
+    # ---- checkpointing (optimization_fp16.py:17-80) ----------------------------------------------------------
+    def state_dict(self):
+        sd = {"dynamic_loss_scale": self.dynamic_loss_scale, "cur_scale": self.cur_scale, "cur_iter": self.cur_iter}
+        if self.dynamic_loss_scale:
+            sd.update(last_overflow_iter=self.last_overflow_iter, scale_factor=self.scale_factor, scale_window=self.scale_window)
+        inner = self.optimizer.state_dict()
+        inner["exp_avg"] = [t.clone() for t in self._m]
+        inner["exp_avg_sq"] = [t.clone() for t in self._v]
+        inner["step"] = self._nstep
+        inner["group_keys"] = list(self._group_key)
+        sd["optimizer_state_dict"] = inner
+        sd["fp32_groups_flat"] = [t.clone() for t in self.fp32_groups_flat]
+        return sd
+
+    def load_state_dict(self, sd):
+        self.dynamic_loss_scale = sd["dynamic_loss_scale"]
+        st = self._scale_state.cpu()
+        st[0], st[1] = sd["cur_scale"], sd["cur_iter"]
+        if sd["dynamic_loss_scale"]:
+            st[2], st[3], st[4], st[5] = sd["last_overflow_iter"], sd["scale_factor"], sd["scale_window"], 1.0
+        self._scale_state.copy_(st)
+        inner = sd["optimizer_state_dict"]
+        self.optimizer.load_state_dict(inner)
+        for cur, saved in zip(self._m, inner["exp_avg"]):
+            cur.copy_(saved)
+        for cur, saved in zip(self._v, inner["exp_avg_sq"]):
+            cur.copy_(saved)
+        self._nstep = inner.get("step", 0)
+        for cur, saved in zip(self.fp32_groups_flat, sd["fp32_groups_flat"]):
+            cur.data.copy_(saved.data)
+        for i, key in enumerate(self._group_key):       # refresh the fp16 model copy from the restored masters
+            self.engine.flat[key].copy_(self.fp32_groups_flat[i])
