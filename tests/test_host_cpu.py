@@ -1,0 +1,173 @@
+"""CPU: host logic and the C-ABI boundary (no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from vlp_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "vlp_hip.h")).read()
+    declared = set(re.findall(r"\b(vlp_[a-z0-9_]+)\s*\(", header))
+    declared -= {"vlp_status"}
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), "libvlp_hip.so does not export %s" % name
+    assert declared == set(_lib.SYMBOLS.keys()), declared ^ set(_lib.SYMBOLS.keys())
+    assert lib.vlp_version() == 1
+    # exported symbols visible to a plain dynamic loader (what a cgo/JNI/ctypes binding would see)
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (vlp_[a-z0-9_]+)", out))
+    assert declared <= exported
+
+
+def test_ctypes_structs_match_c_layout(tmp_path):
+    """sizeof/offsetof of every argument struct, as seen by gcc, equal the ctypes mirror."""
+    from vlp_amd import _lib
+    structs = {"vlp_gemm_nt_args": _lib.GemmNtArgs, "vlp_gemm_tn_args": _lib.GemmTnArgs, "vlp_colsum_args": _lib.ColsumArgs,
+               "vlp_attn_fwd_args": _lib.AttnFwdArgs, "vlp_attn_bwd_args": _lib.AttnBwdArgs, "vlp_layernorm_fwd_args": _lib.LayerNormFwdArgs,
+               "vlp_layernorm_bwd_args": _lib.LayerNormBwdArgs, "vlp_embed_fwd_args": _lib.EmbedFwdArgs, "vlp_embed_bwd_args": _lib.EmbedBwdArgs,
+               "vlp_mlm_loss_fwd_args": _lib.MlmLossFwdArgs, "vlp_mlm_loss_bwd_args": _lib.MlmLossBwdArgs,
+               "vlp_fused_adam_args": _lib.FusedAdamArgs, "vlp_bert_adam_args": _lib.BertAdamArgs}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vlp_hip.h"', "int main(void) {"]
+    for cname, st in structs.items():
+        lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        for fname, _ in st._fields_:
+            lines.append('printf(" %%zu", offsetof(%s, %s));' % (cname, fname))
+        lines.append('printf("\\n");')
+    lines.append("return 0; }")
+    src = os.path.join(tmp_path, "layout.c")
+    open(src, "w").write("\n".join(lines))
+    exe = os.path.join(tmp_path, "layout")
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    for line in out:
+        parts = line.split()
+        st = structs[parts[0]]
+        assert int(parts[1]) == ctypes.sizeof(st), parts[0]
+        offs = [int(x) for x in parts[2:]]
+        assert offs == [getattr(st, f).offset for f, _ in st._fields_], parts[0]
+
+
+def test_no_cpu_fallback():
+    from vlp_amd import _lib
+    x = torch.zeros(8, 64, dtype=torch.half)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.gemm_nt(x, x, x, 8, 8, 64)
+    from vlp_amd.modeling import BertConfig, BertForPreTrainingLossMask
+    m = BertForPreTrainingLossMask(BertConfig(128, num_hidden_layers=1, type_vocab_size=6), enable_butd=True, len_vis_input=100,
+                                   allow_random_fc7=True)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m.engine.pack()
+    # product code never imports the oracle
+    for root, _, files in os.walk(os.path.join(ROOT, "vlp_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# checker", ""), f
+
+
+def test_model_surface_matches_reference_contract():
+    """Class / kwarg / state_dict-key contract of SURVEY.md 8(b)."""
+    import inspect
+    from oracle import vlp_oracle as O
+    from vlp_amd import modeling as M
+    cfg = M.BertConfig(512, num_hidden_layers=2, type_vocab_size=6)
+    assert M.BertConfig.from_dict(cfg.to_dict()).to_json_string() == cfg.to_json_string()
+    for tasks in ("img2txt", "vqa2"):
+        m = M.BertForPreTrainingLossMask(cfg, num_labels=2, enable_butd=True, len_vis_input=100, tasks=tasks, allow_random_fc7=True)
+        keys = set(m.state_dict().keys())
+        assert keys == set(O.init_params(vocab_size=512, layers=2, tasks=tasks).keys()) | {"cls.predictions.decoder.weight"}
+        assert m.cls.predictions.decoder.weight is m.bert.embeddings.word_embeddings.weight        # tied
+        names = [n for n, _ in m.named_parameters()]
+        assert len(names) == 18 + 16 * 2 + (4 if tasks == "vqa2" else 0)
+    sig = inspect.signature(M.BertForPreTrainingLossMask.forward)
+    assert list(sig.parameters)[1:] == ["vis_feats", "vis_pe", "input_ids", "token_type_ids", "attention_mask", "masked_lm_labels", "ans_labels",
+                                        "next_sentence_label", "masked_pos", "masked_weights", "task_idx", "vis_masked_pos",
+                                        "mask_image_regions", "drop_worst_ratio", "vqa_inference"]
+    with pytest.raises(Exception, match="Cannot find Detectron fc7 weights"):
+        M.BertForPreTrainingLossMask(cfg, enable_butd=True, len_vis_input=100)
+    with pytest.raises(NotImplementedError):
+        M.BertForPreTrainingLossMask(cfg, enable_butd=False, allow_random_fc7=True)
+
+
+def test_from_pretrained_resizes_tables(tmp_path):
+    from vlp_amd import modeling as M
+    cfg = M.BertConfig(300, num_hidden_layers=1, type_vocab_size=2, max_position_embeddings=64)
+    open(os.path.join(tmp_path, "bert_config.json"), "w").write(cfg.to_json_string())
+    src = M.BertForPreTrainingLossMask(cfg, enable_butd=True, len_vis_input=100, allow_random_fc7=True)
+    sd = src.state_dict()
+    sd["bert.embeddings.LayerNorm.gamma"] = sd.pop("bert.embeddings.LayerNorm.weight")     # TF-era names are renamed
+    sd["bert.embeddings.LayerNorm.beta"] = sd.pop("bert.embeddings.LayerNorm.bias")
+    torch.save(sd, os.path.join(tmp_path, "pytorch_model.bin"))
+    m = M.BertForPreTrainingLossMask.from_pretrained(str(tmp_path), num_labels=2, type_vocab_size=6, max_position_embeddings=100,
+                                                     drop_prob=0.2, enable_butd=True, len_vis_input=100, tasks="img2txt", allow_random_fc7=True)
+    assert m.config.type_vocab_size == 6 and m.config.hidden_dropout_prob == 0.2
+    tt, old = m.bert.embeddings.token_type_embeddings.weight.data, src.bert.embeddings.token_type_embeddings.weight.data
+    assert torch.equal(tt[:2], old) and torch.equal(tt[4], old[0]) and torch.equal(tt[5], old[1])
+    pe, po = m.bert.embeddings.position_embeddings.weight.data, src.bert.embeddings.position_embeddings.weight.data
+    assert pe.shape[0] == 100 and torch.equal(pe[:64], po) and torch.equal(pe[64:100], po[:36])
+    assert m.missing_keys == []
+    # random init path of the train script: state_dict={}
+    m2 = M.BertForPreTrainingLossMask.from_pretrained(str(tmp_path), state_dict={}, enable_butd=True, len_vis_input=100, allow_random_fc7=True)
+    assert len(m2.missing_keys) == len(m2.state_dict())
+
+
+def test_engine_layout_and_buckets():
+    from vlp_amd import modeling as M
+    from vlp_amd.engine import is_no_decay
+    cfg = M.BertConfig(512, num_hidden_layers=3, type_vocab_size=6)
+    m = M.BertForPreTrainingLossMask(cfg, enable_butd=True, len_vis_input=100, tasks="img2txt", allow_random_fc7=True)
+    decay, nodecay, buckets = m.engine._ordered_names(m)
+    names = [n for n, _ in m.named_parameters()]
+    assert sorted(decay + nodecay) == sorted(names)
+    assert all(not is_no_decay(n) for n in decay) and all(is_no_decay(n) for n in nodecay)
+    # same split as the train script's two groups (run_img2txt_dist.py:395-401)
+    nd = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
+    assert set(nodecay) == {n for n in names if any(x in n for x in nd)}
+    # buckets tile the decay list in backward-completion order: head, layers last..first, embeddings/regions
+    assert buckets[0][0] == 0 and buckets[-1][1] == len(decay) and all(a[1] == b[0] for a, b in zip(buckets, buckets[1:]))
+    assert decay[buckets[1][0]].startswith("bert.encoder.layer.2.") and decay[buckets[3][0]].startswith("bert.encoder.layer.0.")
+    i = decay.index("bert.encoder.layer.1.attention.self.query.weight")
+    assert decay[i + 1].endswith("key.weight") and decay[i + 2].endswith("value.weight")          # packed QKV
+
+
+def test_entry_script_arguments_match_reference():
+    from vlp_amd import run_img2txt_dist as R
+    ours = {a.dest: a.default for a in R.build_parser()._actions if a.dest != "help"}
+    ref_py = "/root/reference/vlp/run_img2txt_dist.py"
+    if os.path.exists(ref_py):
+        live = "\n".join(l for l in open(ref_py).read().splitlines() if not l.lstrip().startswith("#"))
+        flags = set(re.findall(r"add_argument\(\s*['\"]--([a-z_0-9]+)['\"]", live))
+        assert flags <= set(ours), flags - set(ours)
+    args = R.derive_args(R.build_parser().parse_args(["--enable_butd", "--fp16", "--max_len_b", "64", "--output_dir", "/tmp/x"]))
+    assert args.max_seq_length == 167 and args.dist_url == "file:///tmp/x/nonexistent_file"
+    with pytest.raises(AssertionError):
+        R.derive_args(R.build_parser().parse_args([]))          # enable_butd is mandatory, as in the reference (:199)
+
+
+def test_synthetic_batch_contract():
+    from vlp_amd import synthetic as S
+    b = S.make_batch(6, max_len_b=20, s2s_prob=0.5, seed=3)
+    L, Nv = 123, 100
+    assert b.input_ids.shape == (6, L) and b.input_mask.shape == (6, L, L) and b.img.shape == (6, 100, 2048) and b.vis_pe.shape == (6, 100, 1607)
+    for i in range(6):
+        n_tok = int((b.input_ids[i] != 0).sum())
+        n_b = n_tok - Nv - 3
+        m = b.input_mask[i]
+        assert (m[:, :Nv + 2] == 1).all() or int(b.task_idx[i]) == 0
+        if int(b.task_idx[i]) == 3:        # seq2seq: lower-triangular text block, padding rows see only the visual block
+            blk = m[Nv + 2:Nv + 3 + n_b, Nv + 2:Nv + 3 + n_b]
+            assert torch.equal(blk, torch.tril(torch.ones_like(blk)))
+            assert int(m[-1, Nv + 2:].sum()) == 0 or n_b == 20
+        else:                              # bidirectional: every row sees every non-pad column
+            assert torch.equal(m[0], (torch.arange(L) < n_tok).long())
+        w = b.masked_weights[i].bool()
+        assert ((b.masked_pos[i][w] >= Nv + 2) & (b.masked_pos[i][w] < n_tok)).all()
