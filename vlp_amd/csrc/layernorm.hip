@@ -91,16 +91,18 @@ extern "C" int vlp_layernorm_fwd(const vlp_layernorm_fwd_args* a, void* stream) 
 // backward.  Each wave walks rows (grid-stride) keeping per-column partial sums of dgamma / dbeta in
 // registers; partials [nwaves][2][H] go to the workspace and a second kernel reduces them.
 // ---------------------------------------------------------------------------------------------
-#define LNB_BLOCKS 256
+#define LNB_BLOCKS 512
+#define LNB_THREADS 512
+#define LNB_WAVES 8
 
 template <int MAXJ>
-__global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(
+__global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(
     const f16* __restrict__ dy, int64_t lddy, const f16* __restrict__ x, int64_t ldx, const f16* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, f16* __restrict__ dx, int64_t lddx,
     f16* __restrict__ dxd, int64_t lddxd, float* __restrict__ part, int M, int H, DropCtx dyd, DropCtx outd) {
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * LN_WAVES;
+    const int wave = blockIdx.x * LNB_WAVES + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * LNB_WAVES;
     const int nch = H >> 3;
     const float invH = 1.f / (float)H;
     float g[MAXJ][8], dg[MAXJ][8], db[MAXJ][8];
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(
         }
     }
     // block-level reduction of the 4 waves' column partials through LDS, one partial row per block
-    extern __shared__ float lnb_sh[];      // [LN_WAVES][2H]
+    extern __shared__ float lnb_sh[];      // [LNB_WAVES][2H]
     {
         float* sg = lnb_sh + (threadIdx.x >> 6) * 2 * H;
 #pragma unroll
@@ -173,10 +175,10 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(
     }
     __syncthreads();
     float* dst = part + (int64_t)blockIdx.x * 2 * H;
-    for (int i = threadIdx.x; i < 2 * H; i += LN_THREADS) {
+    for (int i = threadIdx.x; i < 2 * H; i += LNB_THREADS) {
         float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < LN_WAVES; ++w) t += lnb_sh[w * 2 * H + i];
+        for (int w = 0; w < LNB_WAVES; ++w) t += lnb_sh[w * 2 * H + i];
         dst[i] = t;
     }
 }
@@ -206,7 +208,7 @@ extern "C" int64_t vlp_layernorm_bwd_workspace_bytes(int32_t H) {
 
 extern "C" int vlp_layernorm_bwd(const vlp_layernorm_bwd_args* a, void* stream) {
     VLP_CHECK_ARG(a && a->dy && a->x && a->gamma && a->mean && a->rstd && a->dx && a->dgamma && a->dbeta, "vlp_layernorm_bwd: null operand");
-    VLP_CHECK_ARG(a->M > 0 && a->H > 0 && a->H % 8 == 0 && a->H <= 4096, "vlp_layernorm_bwd: bad H=%d", a->H);
+    VLP_CHECK_ARG(a->M > 0 && a->H > 0 && a->H % 8 == 0 && a->H <= 2048, "vlp_layernorm_bwd: H=%d must be a multiple of 8 and <= 2048", a->H);
     VLP_CHECK_ARG(a->lddy % 8 == 0 && a->ldx % 8 == 0 && a->lddx % 8 == 0, "vlp_layernorm_bwd: leading dims");
     VLP_CHECK_ARG(((uintptr_t)a->dy | (uintptr_t)a->x | (uintptr_t)a->dx | (uintptr_t)a->gamma) % 16 == 0, "vlp_layernorm_bwd: alignment");
     if (a->dx_drop) VLP_CHECK_ARG(a->lddxd % 8 == 0 && (uintptr_t)a->dx_drop % 16 == 0 && a->out_drop_p > 0.f, "vlp_layernorm_bwd: dx_drop needs out_drop_p > 0");
@@ -214,22 +216,22 @@ extern "C" int vlp_layernorm_bwd(const vlp_layernorm_bwd_args* a, void* stream) 
     if (!a->workspace || a->workspace_bytes < need) return vlp_set_error(VLP_ERR_WORKSPACE, "vlp_layernorm_bwd: workspace %lld < %lld", (long long)a->workspace_bytes, (long long)need);
     DropCtx dyd = make_drop(a->dy_drop_p, a->dy_seed, a->dy_stream);
     DropCtx outd = make_drop(a->out_drop_p, a->out_seed, a->out_stream);
-    int blocks = cdiv(a->M, LN_WAVES);
+    int blocks = cdiv(a->M, LNB_WAVES);
     if (blocks > LNB_BLOCKS) blocks = LNB_BLOCKS;
     hipStream_t s = (hipStream_t)stream;
     float* part = (float*)a->workspace;
-    const size_t lnb_smem = (size_t)LN_WAVES * 2 * a->H * sizeof(float);   // <= 128 KiB at H = 4096
+    const size_t lnb_smem = (size_t)LNB_WAVES * 2 * a->H * sizeof(float);   // <= 128 KiB at H = 2048
     static bool lnb_attr = false;
     if (!lnb_attr) {
-        hipFuncSetAttribute((const void*)layernorm_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 1024 * 4);
-        hipFuncSetAttribute((const void*)layernorm_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 4096 * 4);
+        hipFuncSetAttribute((const void*)layernorm_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * 1024 * 4);
+        hipFuncSetAttribute((const void*)layernorm_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * 2048 * 4);
         lnb_attr = true;
     }
     if (a->H <= 1024)
-        hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(LN_THREADS), lnb_smem, s, (const f16*)a->dy, a->lddy, (const f16*)a->x, a->ldx,
+        hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(LNB_THREADS), lnb_smem, s, (const f16*)a->dy, a->lddy, (const f16*)a->x, a->ldx,
                            (const f16*)a->gamma, a->mean, a->rstd, (f16*)a->dx, a->lddx, (f16*)a->dx_drop, a->lddxd, part, a->M, a->H, dyd, outd);
     else
-        hipLaunchKernelGGL(layernorm_bwd_kernel<8>, dim3(blocks), dim3(LN_THREADS), lnb_smem, s, (const f16*)a->dy, a->lddy, (const f16*)a->x, a->ldx,
+        hipLaunchKernelGGL(layernorm_bwd_kernel<8>, dim3(blocks), dim3(LNB_THREADS), lnb_smem, s, (const f16*)a->dy, a->lddy, (const f16*)a->x, a->ldx,
                            (const f16*)a->gamma, a->mean, a->rstd, (f16*)a->dx, a->lddx, (f16*)a->dx_drop, a->lddxd, part, a->M, a->H, dyd, outd);
     VLP_CHECK_LAUNCH("vlp_layernorm_bwd");
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * a->H, 64)), dim3(1024), 0, s, part, blocks, a->H, (f16*)a->dgamma,

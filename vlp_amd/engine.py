@@ -43,8 +43,10 @@ class _State(object):
 
 
 class Engine(object):
-    GEMM_NT_VARIANT = 1      # LDS-DMA staging (faster on the measured shapes; profiles/r01_microbench_kernels.json)
-    GEMM_TN_VARIANT = 1      # ds_read_b64_tr_b16 fragment reads
+    GEMM_NT_VARIANT = None   # None -> autotune per (M, N, K) on first use among NT_CANDIDATES; or force an int
+    NT_CANDIDATES = (1, 2, 4, 9, 10, 11, 12)   # LDS-DMA variants (+8 = XCD-aware tile order); see include/vlp_hip.h
+    GEMM_TN_VARIANT = 9      # ds_read_b64_tr_b16 fragment reads + XCD-aware tile order
+    _nt_choice = {}          # shared across engines of one process: (M, N, K) -> variant
 
     def __init__(self, model):
         self._model = weakref.ref(model)
@@ -267,14 +269,40 @@ class Engine(object):
     # ------------------------------------------------------------------------------------------
     # forward
     # ------------------------------------------------------------------------------------------
+    def _nt_variant(self, x, w, y, M, N, Kd, kw):
+        """One-time choice of the GEMM staging/tiling variant for this problem size: every candidate computes the
+        same result, so the real call is simply timed with each (3 launches) the first time a shape is seen."""
+        if self.GEMM_NT_VARIANT is not None:
+            return self.GEMM_NT_VARIANT
+        key = (M, N, Kd)
+        v = Engine._nt_choice.get(key)
+        if v is not None:
+            return v
+        best, best_t = self.NT_CANDIDATES[0], float("inf")
+        if M * N >= 128 * 128 * 8:          # tiny problems: not worth timing
+            for cand in self.NT_CANDIDATES:
+                K.gemm_nt(x, w, y, M, N, Kd, variant=cand, **kw)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    K.gemm_nt(x, w, y, M, N, Kd, variant=cand, **kw)
+                e1.record()
+                e1.synchronize()
+                t = e0.elapsed_time(e1)
+                if t < best_t:
+                    best, best_t = cand, t
+        Engine._nt_choice[key] = best
+        return best
+
     def _nt(self, x, w, y, M, N, Kd, **kw):
+        v = self._nt_variant(x, w, y, M, N, Kd, kw)
         if self.prof is None:
-            K.gemm_nt(x, w, y, M, N, Kd, variant=self.GEMM_NT_VARIANT, **kw)
+            K.gemm_nt(x, w, y, M, N, Kd, variant=v, **kw)
             return
         # events are recorded on torch's current stream == the stream handed to the C ABI
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        K.gemm_nt(x, w, y, M, N, Kd, variant=self.GEMM_NT_VARIANT, **kw)
+        K.gemm_nt(x, w, y, M, N, Kd, variant=v, **kw)
         e1.record()
         self.prof.append((e0, e1, 2.0 * M * N * Kd))
 
@@ -402,8 +430,9 @@ class Engine(object):
     # ------------------------------------------------------------------------------------------
     # backward
     # ------------------------------------------------------------------------------------------
-    def _tn(self, a, b, c, M, N, Kd, ws, beta, **kw):
-        K.gemm_tn(a, b, c, M, N, Kd, beta=beta, workspace=ws["tn_ws"], variant=self.GEMM_TN_VARIANT, **kw)
+    def _tn(self, a, b, c, M, N, Kd, ws, beta, bias=None, **kw):
+        """wgrad GEMM; `bias` (the Linear's bias gradient = column sums of dY) is fused into the same launch."""
+        K.gemm_tn(a, b, c, M, N, Kd, beta=beta, workspace=ws["tn_ws"], variant=self.GEMM_TN_VARIANT, bias_out=bias, **kw)
 
     def _bucket_done(self, idx):
         if self.grad_ready_hook is not None:
@@ -438,11 +467,9 @@ class Engine(object):
         if task == "vqa2":
             NA, NAp = model.num_answers, ws["NAp"]
             K.bce_loss_bwd(ws["vq_logits"], NAp, st_labels(st), st_labels(st).stride(0), B, NA, gscale, ws["vq_dlogits"], NAp)
-            self._tn(ws["vq_dlogits"], ws["vq_a1"], self.G("ans_classifier.2.weight"), B, NA, 2 * H, ws, beta)
-            K.colsum(ws["vq_dlogits"], self.G("ans_classifier.2.bias"), B, NA, beta=beta, workspace=ws["cs_ws"])
+            self._tn(ws["vq_dlogits"], ws["vq_a1"], self.G("ans_classifier.2.weight"), B, NA, 2 * H, ws, beta, bias=self.G("ans_classifier.2.bias"))
             self._nt(ws["vq_dlogits"], sh["a2T"], ws["vq_dz1"], B, 2 * H, NAp, mul_src=ws["vq_a1"], mul_mode=K.MUL_RELU_MASK)
-            self._tn(ws["vq_dz1"], ws["vq_e"], self.G("ans_classifier.0.weight"), B, 2 * H, H, ws, beta)
-            K.colsum(ws["vq_dz1"], self.G("ans_classifier.0.bias"), B, 2 * H, beta=beta, workspace=ws["cs_ws"])
+            self._tn(ws["vq_dz1"], ws["vq_e"], self.G("ans_classifier.0.weight"), B, 2 * H, H, ws, beta, bias=self.G("ans_classifier.0.bias"))
             self._nt(ws["vq_dz1"], sh["a0T"], ws["vq_de"], B, H, 2 * H)
             K.vqa_mul_bwd(x_last, ws["vq_de"], dx, B, L, Nv, H)
             if beta == 0:
@@ -452,14 +479,12 @@ class Engine(object):
             R, Vp = B * P, ws["Vp"]
             K.mlm_loss_bwd(ws["logits"], Vp, st_labels(st), ws["lse_ce"], ws["coef"], gscale, ws["dlogits"], Vp, R, V)
             # tied decoder (modeling.py:445-448): dE[V,H] = dlogits^T . t ; the embedding scatter adds to it later
-            self._tn(ws["dlogits"], ws["tln"], self.G(E + "word_embeddings.weight"), R, V, H, ws, beta)
-            K.colsum(ws["dlogits"], self.G(C + "bias"), R, V, beta=beta, workspace=ws["cs_ws"])
+            self._tn(ws["dlogits"], ws["tln"], self.G(E + "word_embeddings.weight"), R, V, H, ws, beta, bias=self.G(C + "bias"))
             self._nt(ws["dlogits"], sh["ET"], ws["dtln"], R, H, Vp)
             K.layernorm_bwd(ws["dtln"], ws["tg"], self.P(C + "transform.LayerNorm.weight"), ws["tstat"][0], ws["tstat"][1], ws["dtg"],
                             self.G(C + "transform.LayerNorm.weight"), self.G(C + "transform.LayerNorm.bias"), R, H, ws["ln_ws"], beta=beta)
             K.gelu_bwd(ws["dtg"], ws["tz"], ws["dtz"], R * H)
-            self._tn(ws["dtz"], ws["sel"], self.G(C + "transform.dense.weight"), R, H, H, ws, beta)
-            K.colsum(ws["dtz"], self.G(C + "transform.dense.bias"), R, H, beta=beta, workspace=ws["cs_ws"])
+            self._tn(ws["dtz"], ws["sel"], self.G(C + "transform.dense.weight"), R, H, H, ws, beta, bias=self.G(C + "transform.dense.bias"))
             self._nt(ws["dtz"], sh["tT"], ws["dsel"], R, H, H)
             K.scatter_add_rows(ws["dsel"], H, masked_pos.contiguous(), dx, H, B, P, L, H)
         self._bucket_done(0)
@@ -478,25 +503,21 @@ class Engine(object):
                             self.G(Ln + "output.LayerNorm.weight"), self.G(Ln + "output.LayerNorm.bias"), M, H, ws["ln_ws"], beta=beta,
                             dx_drop=dd, out_drop=(p, seed, 16 * i + 3))
             dy = dpre_d if p > 0 else dpre
-            self._tn(dy, a["g"], self.G(Ln + "output.dense.weight"), M, H, I, ws, beta)
-            K.colsum(dy, self.G(Ln + "output.dense.bias"), M, H, beta=beta, workspace=ws["cs_ws"])
+            self._tn(dy, a["g"], self.G(Ln + "output.dense.weight"), M, H, I, ws, beta, bias=self.G(Ln + "output.dense.bias"))
             self._nt(dy, s["w2T"], dz, M, I, H, mul_src=a["z"], mul_mode=K.MUL_GELU_GRAD)      # dG * gelu'(z)
             # BertIntermediate (modeling.py:340-343)
-            self._tn(dz, a["x1"], self.G(Ln + "intermediate.dense.weight"), M, I, H, ws, beta)
-            K.colsum(dz, self.G(Ln + "intermediate.dense.bias"), M, I, beta=beta, workspace=ws["cs_ws"])
+            self._tn(dz, a["x1"], self.G(Ln + "intermediate.dense.weight"), M, I, H, ws, beta, bias=self.G(Ln + "intermediate.dense.bias"))
             self._nt(dz, s["w1T"], dx, M, H, I, residual=dpre)                                  # + residual path of LN2's input
             # BertSelfOutput: LN(dropout(dense(ctx)) + x)   (modeling.py:313-317)
             K.layernorm_bwd(dx, a["pre1"], self.P(Ln + "attention.output.LayerNorm.weight"), a["st1"][0], a["st1"][1], dpre,
                             self.G(Ln + "attention.output.LayerNorm.weight"), self.G(Ln + "attention.output.LayerNorm.bias"), M, H, ws["ln_ws"],
                             beta=beta, dx_drop=dd, out_drop=(p, seed, 16 * i + 2))
             dy = dpre_d if p > 0 else dpre
-            self._tn(dy, a["ctx"], self.G(Ln + "attention.output.dense.weight"), M, H, H, ws, beta)
-            K.colsum(dy, self.G(Ln + "attention.output.dense.bias"), M, H, beta=beta, workspace=ws["cs_ws"])
+            self._tn(dy, a["ctx"], self.G(Ln + "attention.output.dense.weight"), M, H, H, ws, beta, bias=self.G(Ln + "attention.output.dense.bias"))
             self._nt(dy, s["oT"], dctx, M, H, H)
             # BertSelfAttention (modeling.py:268-303)
             K.attn_bwd(a["qkv"], ws["maskb"], a["ctx"], dctx, a["lse"], dqkv, ws["delta"], B, L, A, scale, dropout_p=pa, seed=seed, rng_stream=16 * i + 1)
-            self._tn(dqkv, x_in, self.G(Ln + "attention.self.query.weight"), M, 3 * H, H, ws, beta)     # packed [3H, H] gradient
-            K.colsum(dqkv, self.G(Ln + "attention.self.query.bias"), M, 3 * H, beta=beta, workspace=ws["cs_ws"])
+            self._tn(dqkv, x_in, self.G(Ln + "attention.self.query.weight"), M, 3 * H, H, ws, beta, bias=self.G(Ln + "attention.self.query.bias"))     # packed [3H, H] gradient
             self._nt(dqkv, s["qkvT"], dx, M, H, 3 * H, residual=dpre)
             self._bucket_done(NL - i)
 
@@ -511,11 +532,9 @@ class Engine(object):
         K.copy2d(ws["dwpe_pad"], PE_PAD, False, self.G("vis_pe_embed.0.weight"), PE_DIM, H, PE_DIM, PE_DIM, beta=beta)
         K.colsum(ws["d_vispe_h"], self.G("vis_pe_embed.0.bias"), Mv, H, beta=beta, workspace=ws["cs_ws"])
         # vis_embed: Linear(2048,2048)+ReLU -> Linear(2048,H)+ReLU+Dropout
-        self._tn(ws["d_vis_h"], ws["h1"], self.G("vis_embed.2.weight"), Mv, H, 2048, ws, beta)
-        K.colsum(ws["d_vis_h"], self.G("vis_embed.2.bias"), Mv, H, beta=beta, workspace=ws["cs_ws"])
+        self._tn(ws["d_vis_h"], ws["h1"], self.G("vis_embed.2.weight"), Mv, H, 2048, ws, beta, bias=self.G("vis_embed.2.bias"))
         self._nt(ws["d_vis_h"], sh["v2T"], ws["dz1v"], Mv, 2048, H, mul_src=ws["h1"], mul_mode=K.MUL_RELU_MASK)
-        self._tn(ws["dz1v"], img, self.G("vis_embed.0.weight"), Mv, 2048, 2048, ws, beta)
-        K.colsum(ws["dz1v"], self.G("vis_embed.0.bias"), Mv, 2048, beta=beta, workspace=ws["cs_ws"])
+        self._tn(ws["dz1v"], img, self.G("vis_embed.0.weight"), Mv, 2048, 2048, ws, beta, bias=self.G("vis_embed.0.bias"))
         self._bucket_done(NL + 1)
         self.grads_dirty = True
         if self.post_backward_hook is not None:
