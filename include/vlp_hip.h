@@ -86,7 +86,8 @@ typedef struct {
     int32_t M, N, K;
     int32_t beta;                        /* 0 or 1 */
     void* workspace; int64_t workspace_bytes;
-    int32_t variant;                     /* 0 = ds_read_u16 fragment gathers, 1 = ds_read_b64_tr_b16; +8 = XCD-aware tile order */
+    int32_t variant;                     /* 0 = ds_read_u16 fragment gathers, 1 = ds_read_b64_tr_b16 (register-staged), 2 = ds_read_b64_tr_b16 +
+                                            LDS-DMA staging with a transpose-read swizzle; +8 = XCD-aware tile order */
     int32_t splits;                      /* 0 = choose automatically */
     void* bias_out;                      /* optional [N] fp16: (+)= column sums of A, i.e. the bias gradient of the same
                                             Linear, fused into the k-tile-0 workgroups (replaces a separate vlp_colsum) */

@@ -140,7 +140,7 @@ def test_gemm_nt_rejects_bad_args():
 # =====================================================================================================
 # TN GEMM (wgrad), colsum
 # =====================================================================================================
-@pytest.mark.parametrize("variant", [0, 1, 9])
+@pytest.mark.parametrize("variant", [0, 1, 9, 2, 10])
 @pytest.mark.parametrize("M,N,K,splits", [(64, 128, 128, 1), (1000, 256, 384, 1), (1000, 256, 384, 4), (192, 1000, 768, 1),
                                           (2000, 768, 768, 0), (333, 72, 64, 2)])
 def test_gemm_tn(variant, M, N, K, splits, gen):
@@ -169,7 +169,7 @@ def K_ws(M, N, Kd):
     return K.gemm_tn_workspace_bytes(M, N, Kd)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_gemm_tn_asymmetric(variant):
     """dY = I-like selector against an asymmetric X: dW[n,k] must equal X[n,k] for n < M."""
     M, N, Kd = 128, 128, 128

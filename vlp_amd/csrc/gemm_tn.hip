@@ -194,6 +194,164 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(GemmTnParams p) 
     }
 }
 
+// =================================================================================================
+// VARIANT 2: LDS-DMA staging (global_load_lds_dwordx4) for the transpose-read kernel.
+// LDS tiles are [64 m][128 cols], 256-B rows, lane-linear as the DMA writes them; the 16-B chunk c of row r sits at
+// physical chunk c ^ swz(r), swz(r) = 2*((r&3) | ((r>>3)&1)<<2) (applied to the per-lane SOURCE address).  A
+// ds_read_b64_tr_b16 half-wave touches 8 rows (r&3 x two 8-row groups) x 32 contiguous bytes: with this swizzle the eight
+// 32-B segments fall on eight different 32-B bank groups -> conflict-free, for BOTH operands because both use the natural
+// column order here (lane i of a 16-group receives column 16*t + i).  The price is an epilogue of 4-element (not
+// 16-element) runs per lane: 16-B fp32 slab stores, 8-B fp16 stores.  Partial stages (M % 64, only the last stage of the
+// last split) are zero-filled through registers into the same image.
+// =================================================================================================
+DEVFN int tn_swz(int r) { return ((r & 3) | (((r >> 3) & 1) << 2)) << 1; }
+
+__global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_glds_kernel(GemmTnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    f16* smem = reinterpret_cast<f16*>(smem_raw);
+    constexpr int PITCH = 128;
+    constexpr int TILE = TN_BM * PITCH;   // halfs (16 KiB)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wid >> 1, wk = wid & 1;
+    const int g = lane >> 4, li = lane & 15;
+
+    int bid = blockIdx.x;
+    if (p.xcd_remap) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int split = bid % p.splits;
+    const int ktile = (bid / p.splits) % p.tiles_k;
+    const int ntile = bid / (p.splits * p.tiles_k);
+    const int n0 = ntile * TN_BN;
+    const int k0 = ktile * TN_BK;
+    const int m_begin = split * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+    const int nstages = (m_end - m_begin + TN_BM - 1) / TN_BM;
+
+    // staging: pass i covers rows 16*i .. 16*i+15; thread -> (row = 16*i + tid/16, physical chunk = tid%16)
+    const int srow = tid >> 4, sp = tid & 15;
+    int acol[4], bcol[4];
+    // column offsets (halfs) of the logical chunk this thread fetches in pass i, clamped in-bounds (columns past N / K only
+    // feed output rows / columns that are never stored)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = sp ^ tn_swz(srow + 16 * i);
+        acol[i] = min(n0 + c * 8, (int)p.lda - 8);
+        bcol[i] = min(k0 + c * 8, (int)p.ldb - 8);
+    }
+
+    f32x4 acc[4][4];   // [tn][tk]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = (p.bias_out != nullptr) && ktile == 0 && wk == 0;
+    f32x4 bacc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) bacc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f16x8 ones = (f16x8){(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
+
+    auto stage = [&](int st, int buf) {
+        f16* as = smem + buf * 2 * TILE;
+        f16* bs = as + TILE;
+        const int mbase = m_begin + st * TN_BM;
+        if (mbase + TN_BM <= m_end) {            // full stage (wave-uniform): LDS-DMA
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = mbase + srow + 16 * i;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.A + (int64_t)m * p.lda + acol[i]),
+                                                 (__attribute__((address_space(3))) void*)(as + (16 * i + 4 * wid) * PITCH), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.B + (int64_t)m * p.ldb + bcol[i]),
+                                                 (__attribute__((address_space(3))) void*)(bs + (16 * i + 4 * wid) * PITCH), 16, 0, 0);
+            }
+        } else {                                  // ragged tail: through registers with zero fill, same LDS image
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = srow + 16 * i;
+                const int m = mbase + r;
+                u32x4 av = (u32x4){0, 0, 0, 0}, bv = (u32x4){0, 0, 0, 0};
+                if (m < m_end) {
+                    av = *reinterpret_cast<const u32x4*>(p.A + (int64_t)m * p.lda + acol[i]);
+                    bv = *reinterpret_cast<const u32x4*>(p.B + (int64_t)m * p.ldb + bcol[i]);
+                }
+                *reinterpret_cast<u32x4*>(as + r * PITCH + sp * 8) = av;
+                *reinterpret_cast<u32x4*>(bs + r * PITCH + sp * 8) = bv;
+            }
+        }
+    };
+    auto compute = [&](int buf) {
+        const f16* as = smem + buf * 2 * TILE;   // dY tile [m][n]
+        const f16* bs = as + TILE;               // X tile  [m][k]
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) {
+            const int r0 = ms * 32 + 8 * g + (li >> 2);     // this lane's piece row (first read); second read: +4 (same swizzle)
+            const int sw = tn_swz(r0);
+            f16x8 xf[4], yf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int cx = wk * 64 + 16 * t + 4 * (li & 3), cy = wn * 64 + 16 * t + 4 * (li & 3);
+                const f16* px = bs + r0 * PITCH + (((cx >> 3) ^ sw) << 3) + (cx & 4);
+                const f16* py = as + r0 * PITCH + (((cy >> 3) ^ sw) << 3) + (cy & 4);
+                f16x4 x0 = lds_tr_read(px), x1 = lds_tr_read(px + 4 * PITCH);
+                f16x4 y0 = lds_tr_read(py), y1 = lds_tr_read(py + 4 * PITCH);
+                xf[t] = (f16x8){x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+                yf[t] = (f16x8){y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
+            }
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tk = 0; tk < 4; ++tk)
+                    acc[tn][tk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[tk], yf[tn], acc[tn][tk], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) bacc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, yf[tn], bacc[tn], 0, 0, 0);
+            }
+        }
+    };
+
+    if (nstages > 0) {
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int st = 0; st < nstages; ++st) {
+            const int buf = st & 1;
+            if (st + 1 < nstages) stage(st + 1, buf ^ 1);
+            compute(buf);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    // epilogue: lane owns row n (per tn) and, per tk, 4 consecutive k at k0 + wk*64 + 16*tk + 4*g
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+        const int n = n0 + wn * 64 + 16 * tn + li;
+        if (n >= p.N) continue;
+        if (do_bias && g == 0) {
+            if (p.splits > 1) p.bias_slab[(int64_t)split * p.N + n] = bacc[tn][0];
+            else p.bias_out[n] = (f16)(p.beta ? (float)p.bias_out[n] + bacc[tn][0] : bacc[tn][0]);
+        }
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk) {
+            const int kc = k0 + wk * 64 + 16 * tk + 4 * g;
+            if (kc >= p.K) continue;
+            if (p.splits > 1) {
+                *reinterpret_cast<f32x4*>(p.slab + ((int64_t)split * p.N + n) * p.K + kc) = acc[tn][tk];
+            } else {
+                f16* dst = p.C + (int64_t)n * p.ldc + kc;
+                f16x4 o;
+                if (p.beta) o = ld4(dst);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (f16)(p.beta ? (float)o[j] + acc[tn][tk][j] : acc[tn][tk][j]);
+                st4(dst, o);
+            }
+        }
+    }
+}
+
 // out[n,k] = (beta ? out : 0) + sum_s slab[s][n][k]
 __global__ void gemm_tn_reduce_kernel(const float* slab, f16* C, int64_t ldc, int N, int K, int splits, int beta) {
     const int64_t total8 = (int64_t)N * (K / 8);
@@ -280,7 +438,12 @@ extern "C" int vlp_gemm_tn(const vlp_gemm_tn_args* a, void* stream) {
     dim3 grid(p.tiles_k * p.tiles_n * splits), block(TN_THREADS);
     const size_t smem = 2 * 2 * TN_BM * TN_PITCH * sizeof(f16);   // 68 KiB
     hipStream_t s = (hipStream_t)stream;
-    if ((a->variant & 7) == 1) {
+    if ((a->variant & 7) == 2) {
+        const size_t smem2 = 2 * 2 * TN_BM * 128 * sizeof(f16);   // 64 KiB
+        static bool attr2 = false;
+        if (!attr2) { hipFuncSetAttribute((const void*)gemm_tn_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2); attr2 = true; }
+        hipLaunchKernelGGL(gemm_tn_glds_kernel, grid, block, smem2, s, p);
+    } else if ((a->variant & 7) == 1) {
         static bool attr1 = false;
         if (!attr1) { hipFuncSetAttribute((const void*)gemm_tn_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr1 = true; }
         hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, block, smem, s, p);

@@ -45,8 +45,11 @@ class _State(object):
 class Engine(object):
     GEMM_NT_VARIANT = None   # None -> autotune per (M, N, K) on first use among NT_CANDIDATES; or force an int
     NT_CANDIDATES = (1, 2, 4, 9, 10, 11, 12)   # LDS-DMA variants (+8 = XCD-aware tile order); see include/vlp_hip.h
-    GEMM_TN_VARIANT = 9      # ds_read_b64_tr_b16 fragment reads + XCD-aware tile order
+    GEMM_TN_VARIANT = 2      # ds_read_b64_tr_b16 fragment reads + LDS-DMA staging
+    TN_SPLITS = None         # None -> autotune the split-M factor per (M, N, K) among TN_SPLIT_CANDIDATES
+    TN_SPLIT_CANDIDATES = (0, 2, 4, 8, 16)
     _nt_choice = {}          # shared across engines of one process: (M, N, K) -> variant
+    _tn_choice = {}          # (M, N, K) -> splits
 
     def __init__(self, model):
         self._model = weakref.ref(model)
@@ -430,9 +433,37 @@ class Engine(object):
     # ------------------------------------------------------------------------------------------
     # backward
     # ------------------------------------------------------------------------------------------
+    def _tn_splits(self, a, b, c, M, N, Kd, ws):
+        if self.TN_SPLITS is not None:
+            return self.TN_SPLITS
+        key = (M, N, Kd)
+        sp = Engine._tn_choice.get(key)
+        if sp is not None:
+            return sp
+        best, best_t = 0, float("inf")
+        if M >= 1024:
+            scratch = torch.empty(N, Kd, device=c.device, dtype=torch.float16)   # never time into the live gradient buffer
+            if True:
+                for cand in self.TN_SPLIT_CANDIDATES:
+                    if cand > 1 and M // cand < 128:
+                        continue
+                    K.gemm_tn(a, b, scratch, M, N, Kd, beta=0, workspace=ws["tn_ws"], variant=self.GEMM_TN_VARIANT, splits=cand)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(3):
+                        K.gemm_tn(a, b, scratch, M, N, Kd, beta=0, workspace=ws["tn_ws"], variant=self.GEMM_TN_VARIANT, splits=cand)
+                    e1.record()
+                    e1.synchronize()
+                    t = e0.elapsed_time(e1)
+                    if t < best_t:
+                        best, best_t = cand, t
+        Engine._tn_choice[key] = best
+        return best
+
     def _tn(self, a, b, c, M, N, Kd, ws, beta, bias=None, **kw):
         """wgrad GEMM; `bias` (the Linear's bias gradient = column sums of dY) is fused into the same launch."""
-        K.gemm_tn(a, b, c, M, N, Kd, beta=beta, workspace=ws["tn_ws"], variant=self.GEMM_TN_VARIANT, bias_out=bias, **kw)
+        sp = self._tn_splits(a, b, c, M, N, Kd, ws)
+        K.gemm_tn(a, b, c, M, N, Kd, beta=beta, workspace=ws["tn_ws"], variant=self.GEMM_TN_VARIANT, bias_out=bias, splits=sp, **kw)
 
     def _bucket_done(self, idx):
         if self.grad_ready_hook is not None:
