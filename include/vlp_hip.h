@@ -127,6 +127,7 @@ int vlp_attn_fwd(const vlp_attn_fwd_args* a, void* stream);
 typedef struct {
     const void* qkv; int64_t ld_qkv;
     const uint8_t* mask;
+    const uint8_t* mask_t;               /* [B, Lp, Lp] key-major copy of the byte mask (vlp_mask_pack's second output) */
     const void* ctx; int64_t ld_ctx;     /* forward output */
     const void* dctx; int64_t ld_dctx;   /* [B*L, H] gradient of ctx */
     const float* lse;
@@ -140,7 +141,8 @@ int vlp_attn_bwd(const vlp_attn_bwd_args* a, void* stream);
 
 /* int64 [B,L,L] 0/1 (seq2seq_loader.py:292-304) -> uint8 [B,L,Lp]: 1 attend, 0 masked, 2 for the padding
  * columns >= L (excluded from the softmax). */
-int vlp_mask_pack(const int64_t* mask, uint8_t* out, int32_t B, int32_t L, int32_t Lp, void* stream);
+/* out_t (optional, [B,Lp,Lp]): out_t[b][key][q] = the same flag, 2 wherever key >= L or q >= L (used by vlp_attn_bwd). */
+int vlp_mask_pack(const int64_t* mask, uint8_t* out, uint8_t* out_t, int32_t B, int32_t L, int32_t Lp, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm, TF style (eps inside sqrt, biased variance, fp32 statistics): modeling.py:174-192 /

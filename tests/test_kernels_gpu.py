@@ -225,7 +225,8 @@ def test_attention_fwd_bwd(B, L, Nv, heads, gen):
     mask = _mask(B, L, Nv, gc).to(DEV)
     Lp = (L + 31) // 32 * 32
     mb = torch.empty(B, L, Lp, device=DEV, dtype=torch.uint8)
-    K.mask_pack(mask, mb, B, L, Lp)
+    mt = torch.empty(B, Lp, Lp, device=DEV, dtype=torch.uint8)
+    K.mask_pack(mask, mb, B, L, Lp, out_t=mt)
     assert torch.equal(mb[:, :, :L].long(), mask) and (Lp == L or int(mb[:, :, L:].min()) == 2)
     ctx = torch.zeros(B * L, H, device=DEV, dtype=torch.half)
     lse = torch.zeros(B, heads, L, device=DEV)
@@ -241,7 +242,7 @@ def test_attention_fwd_bwd(B, L, Nv, heads, gen):
     dctx = h16(B * L, H, gen=gen)
     dqkv = torch.zeros(B * L, 3 * H, device=DEV, dtype=torch.half)
     delta = torch.zeros(B, heads, L, device=DEV)
-    K.attn_bwd(qkv, mb, ctx, dctx, lse, dqkv, delta, B, L, heads, 0.125)
+    K.attn_bwd(qkv, mb, mt, ctx, dctx, lse, dqkv, delta, B, L, heads, 0.125)
     ref.backward(dctx.double())
     g = q64.grad
     for i, name in enumerate(("dq", "dk", "dv")):
@@ -258,7 +259,8 @@ def test_attention_dropout_exact_mask(gen):
     mask = _mask(B, L, Nv, gc).to(DEV)
     Lp = (L + 31) // 32 * 32
     mb = torch.empty(B, L, Lp, device=DEV, dtype=torch.uint8)
-    K.mask_pack(mask, mb, B, L, Lp)
+    mt = torch.empty(B, Lp, Lp, device=DEV, dtype=torch.uint8)
+    K.mask_pack(mask, mb, B, L, Lp, out_t=mt)
     ctx = torch.zeros(B * L, H, device=DEV, dtype=torch.half)
     lse = torch.zeros(B, heads, L, device=DEV)
     K.attn_fwd(qkv, mb, ctx, lse, B, L, heads, 0.125, dropout_p=p, seed=seed, rng_stream=stream)
@@ -270,7 +272,7 @@ def test_attention_dropout_exact_mask(gen):
     dctx = h16(B * L, H, gen=gen)
     dqkv = torch.zeros(B * L, 3 * H, device=DEV, dtype=torch.half)
     delta = torch.zeros(B, heads, L, device=DEV)
-    K.attn_bwd(qkv, mb, ctx, dctx, lse, dqkv, delta, B, L, heads, 0.125, dropout_p=p, seed=seed, rng_stream=stream)
+    K.attn_bwd(qkv, mb, mt, ctx, dctx, lse, dqkv, delta, B, L, heads, 0.125, dropout_p=p, seed=seed, rng_stream=stream)
     ref.backward(dctx.double())
     assert rel(dqkv.float(), q64.grad) < 5e-3
 

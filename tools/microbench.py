@@ -74,6 +74,8 @@ def main():
     Lp = (L + 31) // 32 * 32
     mb = torch.ones(B, L, Lp, device=DEV, dtype=torch.uint8)
     mb[:, :, L:] = 2
+    mt = torch.full((B, Lp, Lp), 2, device=DEV, dtype=torch.uint8)
+    mt[:, :L, :L] = 1
     ctx, dctx = torch.empty(M, H, device=DEV, dtype=torch.half), r(M, H)
     lse, delta = torch.empty(B, A, L, device=DEV), torch.empty(B, A, L, device=DEV)
     dqkv = torch.empty_like(qkv)
@@ -81,7 +83,7 @@ def main():
     for p in (0.0, 0.1):
         us = timeit(lambda: K.attn_fwd(qkv, mb, ctx, lse, B, L, A, 0.125, dropout_p=p, seed=1))
         res["attn_fwd/p%.1f" % p] = {"us": us, "tflops": fl / us / 1e6}
-        us = timeit(lambda: K.attn_bwd(qkv, mb, ctx, dctx, lse, dqkv, delta, B, L, A, 0.125, dropout_p=p, seed=1))
+        us = timeit(lambda: K.attn_bwd(qkv, mb, mt, ctx, dctx, lse, dqkv, delta, B, L, A, 0.125, dropout_p=p, seed=1))
         res["attn_bwd/p%.1f" % p] = {"us": us, "tflops": 2.5 * fl / us / 1e6}
     # ---- memory-bound kernels
     x = r(M, H)

@@ -46,7 +46,7 @@ class AttnFwdArgs(C.Structure):
 
 
 class AttnBwdArgs(C.Structure):
-    _fields_ = [("qkv", vp), ("ld_qkv", i64), ("mask", vp), ("ctx", vp), ("ld_ctx", i64), ("dctx", vp), ("ld_dctx", i64),
+    _fields_ = [("qkv", vp), ("ld_qkv", i64), ("mask", vp), ("mask_t", vp), ("ctx", vp), ("ld_ctx", i64), ("dctx", vp), ("ld_dctx", i64),
                 ("lse", vp), ("dqkv", vp), ("ld_dqkv", i64), ("delta", vp),
                 ("B", i32), ("L", i32), ("heads", i32), ("scale", f32),
                 ("dropout_p", f32), ("seed", u64), ("rng_stream", u32)]
@@ -112,7 +112,7 @@ SYMBOLS = {
     "vlp_colsum": (C.c_int, [C.POINTER(ColsumArgs), vp]),
     "vlp_attn_fwd": (C.c_int, [C.POINTER(AttnFwdArgs), vp]),
     "vlp_attn_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), vp]),
-    "vlp_mask_pack": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+    "vlp_mask_pack": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
     "vlp_layernorm_fwd": (C.c_int, [C.POINTER(LayerNormFwdArgs), vp]),
     "vlp_layernorm_bwd_workspace_bytes": (i64, [i32]),
     "vlp_layernorm_bwd": (C.c_int, [C.POINTER(LayerNormBwdArgs), vp]),
@@ -224,16 +224,16 @@ def attn_fwd(qkv, mask, ctx, lse, B, L, heads, scale, dropout_p=0.0, seed=0, rng
     _check(load().vlp_attn_fwd(C.byref(a), stream_ptr()))
 
 
-def attn_bwd(qkv, mask, ctx, dctx, lse, dqkv, delta, B, L, heads, scale, dropout_p=0.0, seed=0, rng_stream=0):
-    _req_cuda(qkv, mask, ctx, dctx, lse, dqkv, delta)
-    a = AttnBwdArgs(ptr(qkv), qkv.stride(0), ptr(mask), ptr(ctx), ctx.stride(0), ptr(dctx), dctx.stride(0), ptr(lse),
+def attn_bwd(qkv, mask, mask_t, ctx, dctx, lse, dqkv, delta, B, L, heads, scale, dropout_p=0.0, seed=0, rng_stream=0):
+    _req_cuda(qkv, mask, mask_t, ctx, dctx, lse, dqkv, delta)
+    a = AttnBwdArgs(ptr(qkv), qkv.stride(0), ptr(mask), ptr(mask_t), ptr(ctx), ctx.stride(0), ptr(dctx), dctx.stride(0), ptr(lse),
                     ptr(dqkv), dqkv.stride(0), ptr(delta), B, L, heads, scale, dropout_p, seed, rng_stream)
     _check(load().vlp_attn_bwd(C.byref(a), stream_ptr()))
 
 
-def mask_pack(mask_i64, out_u8, B, L, Lp):
-    _req_cuda(mask_i64, out_u8)
-    _check(load().vlp_mask_pack(ptr(mask_i64), ptr(out_u8), B, L, Lp, stream_ptr()))
+def mask_pack(mask_i64, out_u8, B, L, Lp, out_t=None):
+    _req_cuda(mask_i64, out_u8, out_t)
+    _check(load().vlp_mask_pack(ptr(mask_i64), ptr(out_u8), ptr(out_t), B, L, Lp, stream_ptr()))
 
 
 def layernorm_fwd(x, gamma, beta, y, M, H, mean=None, rstd=None, eps=1e-5, dropout_p=0.0, seed=0, rng_stream=0, ldx=None, ldy=None):

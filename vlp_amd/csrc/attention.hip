@@ -6,17 +6,18 @@
 // and the autograd backward of all of it.  The [B,heads,L,L] score/probability tensors the reference
 // materialises four times per layer never leave registers here.
 //
-// L <= 256 (the reference runs L = 123 or 167), head_dim = 64: one workgroup owns one (batch, head),
-// the whole K (and V / K^T / Q^T / dO^T as needed) of that head sits in LDS, each wave walks 16-row
-// tiles.  All contractions run on v_mfma_f32_16x16x32_f16.  The kernels compute TRANSPOSED products
-// (S^T = K.Q^T, O^T = V^T.P^T, dQ^T = K^T.dS^T, ...) so that, in the MFMA C/D layout
-// (col = lane&15, row = 4*(lane>>4)+reg), a lane owns one query (or key) column: softmax row
-// statistics are lane-local, a C/D tile can be re-used *in registers* as the B operand of the next MFMA
-// (P^T / dS^T tiles feed PV / dQ / dK / dV directly, no LDS round trip), and outputs are 4 consecutive
-// head-dim values per lane (8-byte stores).  The k-slot order of such a re-used tile pair (t, t+1) is
-// keys {16t+4g+e, 16(t+1)+4g+e}; the other operand is gathered in the same slot order from an LDS image
-// stored [head_dim][key] (8-byte ds_read_b64 x2), which is legal because a contraction is invariant
-// under a consistent permutation of its index.
+// L <= 256 (the reference runs L = 123 or 167), head_dim = 64: one workgroup owns one (batch, head), the
+// operands of that head sit in LDS as ROW-MAJOR [row][64] tiles (128-B rows, 16-B chunk c of row r stored
+// at chunk c ^ (r & 7)), each wave walks 16-row tiles.  All contractions run on v_mfma_f32_16x16x32_f16.
+// The kernels compute TRANSPOSED products (S^T = K.Q^T, O^T = V^T.P^T, dQ^T = K^T.dS^T, ...) so that, in the
+// MFMA C/D layout (col = lane&15, row = 4*(lane>>4)+reg), a lane owns one query (or key) column: softmax row
+// statistics are lane-local, a C/D tile is re-used *in registers* as the B operand of the next MFMA (P^T / dS^T
+// tiles feed PV / dQ / dK / dV directly, no LDS round trip), and outputs are 4 consecutive head-dim values per
+// lane (8-byte stores).  The k-slot order of such a re-used tile pair (t, t+1) is rows {16t+4g+e, 16(t+1)+4g+e};
+// the other operand (V^T, K^T, Q^T, dO^T) is gathered in that same slot order straight from the row-major tile
+// with the CDNA4 LDS transpose read ds_read_b64_tr_b16 (two per fragment) -- no transposed copy is ever built.
+// With the (r & 7) chunk swizzle both access patterns are bank-conflict free: ds_read_b128 row fragments
+// (16 rows x one chunk) and transpose reads (8 rows x 32 contiguous bytes per half-wave).
 #include "common.h"
 
 #define HD 64            // head dim
@@ -28,6 +29,7 @@ DEVFN int swzk(int r) { return r & 7; }
 struct AttnParams {
     const f16* qkv; int64_t ld_qkv;
     const uint8_t* mask;
+    const uint8_t* mask_t;                 // [B][Lp][Lp] transposed byte mask (key-major), backward only
     f16* ctx; int64_t ld_ctx;              // fwd out / bwd in
     const f16* dctx; int64_t ld_dctx;
     float* lse;
@@ -48,19 +50,20 @@ DEVFN void stage_rowmajor(f16* dst, const f16* src, int64_t ld, int L, int Lp, i
         *reinterpret_cast<u32x4*>(dst + r * HD + ((c ^ swzk(r)) << 3)) = v;
     }
 }
-// transposed: dst[dd][pitch] = src[key][dd]; keys >= L are zero.  lane <-> key so the 16-bit LDS writes
-// of one instruction fall on consecutive addresses.
-DEVFN void stage_transposed(f16* dst, int pitch, const f16* src, int64_t ld, int L, int Lp, int tid) {
-    const int nkb = Lp / 64 + ((Lp % 64) ? 1 : 0);
-    for (int idx = tid; idx < nkb * 64 * 8; idx += ATT_THREADS) {
-        const int key = (idx & 63) + 64 * (idx / 512);
-        const int c = (idx >> 6) & 7;
-        if (key >= Lp) continue;
-        f16x8 v = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        if (key < L) v = ld8(src + (int64_t)key * ld + c * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dst[(c * 8 + e) * pitch + key] = v[e];
-    }
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+DEVFN f16x4 lds_tr_read(const f16* p) {
+    fp16x4_t t = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(p));
+    return __builtin_bit_cast(f16x4, t);
+}
+// MFMA A-operand fragment of the TRANSPOSE of a row-major swizzled tile: the lane receives column col0 + (lane&15) for the
+// 8 k-slots {r_first + 4g + e, r_second + 4g + e} (e = 0..3): two ds_read_b64_tr_b16; lane s of a 16-lane group supplies
+// the 8-byte piece (row + (s>>2), cols col0 + 4*(s&3) .. +3).
+DEVFN f16x8 tr_frag(const f16* tile, int r_first, int r_second, int col0, int g, int li) {
+    const int ra = r_first + 4 * g + (li >> 2), rb = r_second + 4 * g + (li >> 2);
+    const int c = col0 + 4 * (li & 3);
+    const f16x4 a = lds_tr_read(tile + ra * HD + (((c >> 3) ^ (ra & 7)) << 3) + (c & 4));
+    const f16x4 b = lds_tr_read(tile + rb * HD + (((c >> 3) ^ (rb & 7)) << 3) + (c & 4));
+    return (f16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
 // additive mask term for 4 consecutive keys of one query row.  Mask bytes (vlp_mask_pack): 1 = attend (+0),
@@ -81,9 +84,8 @@ template <int NT>   // NT = LP / 16 key tiles (4, 8, 12 or 16)
 __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int LP = NT * 16;
-    constexpr int VP = LP + 8;                 // V^T row pitch (halfs); (2*VP/16) is odd -> conflict-free b64 reads
     f16* Ks = reinterpret_cast<f16*>(smem_raw);            // [LP][64] swizzled
-    f16* Vt = Ks + LP * HD;                                // [64][VP]
+    f16* Vs = Ks + LP * HD;                                // [LP][64] swizzled
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(AttnParams p) 
     const f16* vbase = qbase + 2 * p.H;
 
     stage_rowmajor(Ks, kbase, p.ld_qkv, L, LP, tid);
-    stage_transposed(Vt, VP, vbase, p.ld_qkv, L, LP, tid);
+    stage_rowmajor(Vs, vbase, p.ld_qkv, L, LP, tid);
     __syncthreads();
 
     const int nqt = (L + 15) / 16;
@@ -165,13 +167,9 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(AttnParams p) 
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const f16* vrow = Vt + (n * 16 + li) * VP + 4 * g;
 #pragma unroll
-            for (int u = 0; u < NT / 2; ++u) {
-                f16x4 v0 = ld4(vrow + 32 * u), v1 = ld4(vrow + 32 * u + 16);
-                f16x8 vf = (f16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[u], o, 0, 0, 0);
-            }
+            for (int u = 0; u < NT / 2; ++u)
+                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(Vs, 32 * u, 32 * u + 16, 16 * n, g, li), pf[u], o, 0, 0, 0);
             if (q < L) {
                 f16x4 ov = (f16x4){(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
                 st4(p.ctx + ((int64_t)b * L + q) * p.ld_ctx + h * HD + n * 16 + 4 * g, ov);
@@ -187,10 +185,8 @@ template <int NT>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int LP = NT * 16;
-    constexpr int TP = LP + 8;
     f16* Ks = reinterpret_cast<f16*>(smem_raw);     // [LP][64] swizzled
     f16* Vs = Ks + LP * HD;                         // [LP][64] swizzled
-    f16* Kt = Vs + LP * HD;                         // [64][TP]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
@@ -202,7 +198,6 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams 
 
     stage_rowmajor(Ks, kbase, p.ld_qkv, L, LP, tid);
     stage_rowmajor(Vs, vbase, p.ld_qkv, L, LP, tid);
-    stage_transposed(Kt, TP, kbase, p.ld_qkv, L, LP, tid);
     __syncthreads();
 
     const int nqt = (L + 15) / 16;
@@ -258,13 +253,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams 
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const f16* krow = Kt + (n * 16 + li) * TP + 4 * g;
 #pragma unroll
-            for (int u = 0; u < NT / 2; ++u) {
-                f16x4 k0 = ld4(krow + 32 * u), k1 = ld4(krow + 32 * u + 16);
-                f16x8 kf = (f16x8){k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
-                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, dsf[u], o, 0, 0, 0);
-            }
+            for (int u = 0; u < NT / 2; ++u)
+                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(Ks, 32 * u, 32 * u + 16, 16 * n, g, li), dsf[u], o, 0, 0, 0);
             if (q < L) {
                 f16x4 ov = (f16x4){(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
                 st4(p.dqkv + ((int64_t)b * L + q) * p.ld_dqkv + h * HD + n * 16 + 4 * g, ov);
@@ -275,15 +266,18 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams 
 
 // =================================================================================================
 // backward, part 2: dK, dV.  Each wave owns a 16-key tile (column per lane) and walks all queries.
+// Q and dO of the head are LDS-resident (row-major, swizzled): they serve both as MFMA A operands of the score / dP
+// recomputation (row fragments, ds_read_b128) and, through transpose reads, as the Q^T / dO^T operands of dK^T / dV^T.
+// The byte mask is read from its key-major copy so that a lane fetches 4 queries of its key with one dword load; all
+// loads of a key tile are issued before its query loop.
 // =================================================================================================
 template <int NT>
 __global__ __launch_bounds__(ATT_THREADS, 3) void attn_bwd_dkv_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int LP = NT * 16;
-    constexpr int TP = LP + 8;
-    f16* Qt = reinterpret_cast<f16*>(smem_raw);     // [64][TP]  Q^T
-    f16* dOt = Qt + HD * TP;                        // [64][TP]  dO^T
-    float* lse_s = reinterpret_cast<float*>(dOt + HD * TP);   // [LP]
+    f16* Qs = reinterpret_cast<f16*>(smem_raw);     // [LP][64] swizzled
+    f16* dOs = Qs + LP * HD;                        // [LP][64] swizzled
+    float* lse_s = reinterpret_cast<float*>(dOs + LP * HD);   // [LP]
     float* dl_s = lse_s + LP;                                  // [LP]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -295,8 +289,8 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_bwd_dkv_kernel(AttnParams
     const f16* vbase = qbase + 2 * p.H;
     const f16* dobase = p.dctx + (int64_t)b * L * p.ld_dctx + h * HD;
 
-    stage_transposed(Qt, TP, qbase, p.ld_qkv, L, LP, tid);
-    stage_transposed(dOt, TP, dobase, p.ld_dctx, L, LP, tid);
+    stage_rowmajor(Qs, qbase, p.ld_qkv, L, LP, tid);
+    stage_rowmajor(dOs, dobase, p.ld_dctx, L, LP, tid);
     for (int i = tid; i < LP; i += ATT_THREADS) {
         const int64_t stat = ((int64_t)b * p.heads + h) * L + min(i, L - 1);
         lse_s[i] = p.lse[stat];
@@ -314,58 +308,59 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_bwd_dkv_kernel(AttnParams
             kf[ks] = ld8(kbase + (int64_t)kc * p.ld_qkv + ks * 32 + g * 8);
             vf[ks] = ld8(vbase + (int64_t)kc * p.ld_qkv + ks * 32 + g * 8);
         }
+        // mask bytes of this key for queries 16*qt + 4g .. +3 (rows >= L / keys >= L hold 2 = excluded); the words of the
+        // next query-tile pair are fetched one iteration ahead
+        const uint8_t* mtr = p.mask_t + ((int64_t)b * p.Lp + min(key, p.Lp - 1)) * p.Lp + 4 * g;
+        auto mload = [&](int qt) -> uint32_t { return (qt * 16 < p.Lp) ? *reinterpret_cast<const uint32_t*>(mtr + 16 * qt) : 0x02020202u; };
+        uint32_t mcur[2] = {mload(0), mload(1)};
+        const uint32_t rk_row0 = 0;
+        (void)rk_row0;
         f32x4 dk[4], dv[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) { dk[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
 #pragma unroll 1
         for (int u = 0; u < NT / 2; ++u) {       // query tile pair (2u, 2u+1)
+            int gq = g;                          // opaque copy: keeps address math inside the loop (no LICM + spills)
+            asm volatile("" : "+v"(gq));
+            uint32_t mnext[2] = {0x02020202u, 0x02020202u};
+            if (u + 1 < NT / 2) { mnext[0] = mload(2 * u + 2); mnext[1] = mload(2 * u + 3); }
             f16x8 pdf, dsf;                      // B operands: rows = queries (pair slots), col = key
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int qt = 2 * u + half;
-                // S tile: rows = queries 16qt + 4g + reg, col = key.  A = Q rows, B = K rows (NT form)
-                const int qa = min(qt * 16 + li, L - 1);      // A-operand row of this lane
-                const f16* qrow = qbase + (int64_t)qa * p.ld_qkv;
-                const f16* dorow = dobase + (int64_t)qa * p.ld_dctx;
+                // S tile: rows = queries 16qt + 4g + reg, col = key.  A = Q rows (LDS), B = K rows (registers)
+                const int qa = qt * 16 + li;
                 f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld8(qrow + ks * 32 + g * 8), kf[ks], s, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld8(dorow + ks * 32 + g * 8), vf[ks], dp, 0, 0, 0);
+                    const int off = qa * HD + (((ks * 4 + gq) ^ swzk(qa)) << 3);
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld8(Qs + off), kf[ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld8(dOs + off), vf[ks], dp, 0, 0, 0);
                 }
-                const int q0 = qt * 16 + 4 * g;
+                const int q0 = qt * 16 + 4 * gq;
                 const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_s + q0);
                 const f32x4 dl4 = *reinterpret_cast<const f32x4*>(dl_s + q0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int q = q0 + r;
-                    float pr = 0.f, dsv = 0.f, pd = 0.f;
-                    if (q < L && key < L) {
-                        const bool on = p.mask[((int64_t)b * L + q) * p.Lp + key] == 1;
-                        pr = __expf(s[r] * p.scale + (on ? 0.f : -10000.f) - lse4[r]);
-                        float mult = 1.f;
-                        if (p.drop.thresh)
-                            mult = drop_mult(p.drop, drop_rowkey(p.drop, ((uint64_t)b * p.heads + h) * (uint64_t)L + (uint64_t)q), (uint32_t)key);
-                        pd = pr * mult;
-                        dsv = pr * (dp[r] * mult - dl4[r]) * p.scale;
-                    }
-                    pdf[half * 4 + r] = (f16)pd;
-                    dsf[half * 4 + r] = (f16)dsv;
+                    const uint32_t mv = (mcur[half] >> (8 * r)) & 0xffu;
+                    const float madd = mv == 1u ? 0.f : (mv == 0u ? -10000.f : -INFINITY);
+                    const float pr = __expf(s[r] * p.scale + madd - lse4[r]);     // excluded (padding) -> exp(-inf) = 0
+                    float mult = 1.f;
+                    if (p.drop.thresh)
+                        mult = drop_mult(p.drop, drop_rowkey(p.drop, ((uint64_t)b * p.heads + h) * (uint64_t)L + (uint64_t)(q0 + r)), (uint32_t)key);
+                    pdf[half * 4 + r] = (f16)(pr * mult);
+                    dsf[half * 4 + r] = (f16)(pr * (dp[r] * mult - dl4[r]) * p.scale);
                 }
             }
-            // dV^T += dO^T . Pd ; dK^T += Q^T . dS   (rows = head-dim, col = key)
+            // dV^T += dO^T . Pd ; dK^T += Q^T . dS   (rows = head-dim, col = key); transposed operands by ds_read_b64_tr_b16
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                const f16* dorow = dOt + (n * 16 + li) * TP + 4 * g + 32 * u;
-                const f16* qrow = Qt + (n * 16 + li) * TP + 4 * g + 32 * u;
-                f16x4 a0 = ld4(dorow), a1 = ld4(dorow + 16);
-                f16x4 c0 = ld4(qrow), c1 = ld4(qrow + 16);
-                f16x8 dof = (f16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                f16x8 qf = (f16x8){c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-                dv[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(dof, pdf, dv[n], 0, 0, 0);
-                dk[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf, dsf, dk[n], 0, 0, 0);
+                dv[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(dOs, 32 * u, 32 * u + 16, 16 * n, gq, li), pdf, dv[n], 0, 0, 0);
+                dk[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(Qs, 32 * u, 32 * u + 16, 16 * n, gq, li), dsf, dk[n], 0, 0, 0);
             }
+            mcur[0] = mnext[0];
+            mcur[1] = mnext[1];
         }
         if (key < L) {
             f16* drow = p.dqkv + ((int64_t)b * L + key) * p.ld_dqkv + h * HD;
@@ -405,7 +400,7 @@ extern "C" int vlp_attn_fwd(const vlp_attn_fwd_args* a, void* stream) {
     p.scale = a->scale;
     p.drop = make_drop(a->dropout_p, a->seed, a->rng_stream);
     const int LP = lp_of(a->L);
-    const size_t smem = (size_t)LP * HD * 2 + (size_t)HD * (LP + 8) * 2;
+    const size_t smem = (size_t)2 * LP * HD * 2;
     dim3 grid(a->B * a->heads), block(ATT_THREADS);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_FWD(NT_)                                                                                              \
@@ -424,11 +419,12 @@ extern "C" int vlp_attn_bwd(const vlp_attn_bwd_args* a, void* stream) {
     VLP_CHECK_ARG(a != nullptr, "vlp_attn_bwd: null args");
     int rc = attn_common_check("vlp_attn_bwd", a->qkv, a->ld_qkv, a->mask, a->B, a->L, a->heads);
     if (rc) return rc;
-    VLP_CHECK_ARG(a->ctx && a->dctx && a->lse && a->dqkv && a->delta, "vlp_attn_bwd: null operand");
+    VLP_CHECK_ARG(a->ctx && a->dctx && a->lse && a->dqkv && a->delta && a->mask_t, "vlp_attn_bwd: null operand");
+    VLP_CHECK_ARG((uintptr_t)a->mask_t % 4 == 0, "vlp_attn_bwd: mask_t alignment");
     VLP_CHECK_ARG(a->ld_ctx % 8 == 0 && a->ld_dctx % 8 == 0 && a->ld_dqkv % 4 == 0, "vlp_attn_bwd: leading dims");
     VLP_CHECK_ARG(((uintptr_t)a->ctx | (uintptr_t)a->dctx) % 16 == 0 && (uintptr_t)a->dqkv % 8 == 0, "vlp_attn_bwd: alignment");
     AttnParams p = {};
-    p.qkv = (const f16*)a->qkv; p.ld_qkv = a->ld_qkv; p.mask = a->mask;
+    p.qkv = (const f16*)a->qkv; p.ld_qkv = a->ld_qkv; p.mask = a->mask; p.mask_t = a->mask_t;
     p.ctx = (f16*)a->ctx; p.ld_ctx = a->ld_ctx;
     p.dctx = (const f16*)a->dctx; p.ld_dctx = a->ld_dctx;
     p.lse = (float*)a->lse; p.dqkv = (f16*)a->dqkv; p.ld_dqkv = a->ld_dqkv; p.delta = a->delta;
@@ -437,8 +433,8 @@ extern "C" int vlp_attn_bwd(const vlp_attn_bwd_args* a, void* stream) {
     p.scale = a->scale;
     p.drop = make_drop(a->dropout_p, a->seed, a->rng_stream);
     const int LP = lp_of(a->L);
-    const size_t smem_dq = (size_t)2 * LP * HD * 2 + (size_t)HD * (LP + 8) * 2;
-    const size_t smem_dkv = (size_t)2 * HD * (LP + 8) * 2 + (size_t)2 * LP * 4;
+    const size_t smem_dq = (size_t)2 * LP * HD * 2;
+    const size_t smem_dkv = (size_t)2 * LP * HD * 2 + (size_t)2 * LP * 4;
     dim3 grid(a->B * a->heads), block(ATT_THREADS);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_BWD(NT_)                                                                                              \
@@ -458,21 +454,31 @@ extern "C" int vlp_attn_bwd(const vlp_attn_bwd_args* a, void* stream) {
     return VLP_OK;
 }
 
-// int64 [B,L,L] -> uint8 [B,L,Lp]  (1 attend, 0 masked, 2 = padding column)
-__global__ void mask_pack_kernel(const int64_t* mask, uint8_t* out, int L, int Lp, int64_t rows) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows * Lp; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / Lp;
-        const int c = (int)(i % Lp);
-        out[i] = c < L ? (mask[r * L + c] != 0 ? 1 : 0) : 2;
+// int64 [B,L,L] -> uint8 [B,L,Lp]  (1 attend, 0 masked, 2 = padding column) and, optionally, the key-major copy
+// [B,Lp,Lp] (out_t[b][key][q]; 2 wherever key >= L or q >= L)
+__global__ void mask_pack_kernel(const int64_t* mask, uint8_t* out, uint8_t* out_t, int L, int Lp, int B) {
+    const int64_t n1 = (int64_t)B * L * Lp, n2 = out_t ? (int64_t)B * Lp * Lp : 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < n1) {
+            const int64_t r = i / Lp;
+            const int c = (int)(i % Lp);
+            out[i] = c < L ? (mask[r * L + c] != 0 ? 1 : 0) : 2;
+        } else {
+            const int64_t j = i - n1;
+            const int q = (int)(j % Lp);
+            const int key = (int)((j / Lp) % Lp);
+            const int64_t b = j / ((int64_t)Lp * Lp);
+            out_t[j] = (q < L && key < L) ? (mask[(b * L + q) * L + key] != 0 ? 1 : 0) : 2;
+        }
     }
 }
-extern "C" int vlp_mask_pack(const int64_t* mask, uint8_t* out, int32_t B, int32_t L, int32_t Lp, void* stream) {
+extern "C" int vlp_mask_pack(const int64_t* mask, uint8_t* out, uint8_t* out_t, int32_t B, int32_t L, int32_t Lp, void* stream) {
     VLP_CHECK_ARG(mask && out && B > 0 && L > 0, "vlp_mask_pack: bad args");
     VLP_CHECK_ARG(Lp == (L + 31) / 32 * 32, "vlp_mask_pack: Lp must be roundup32(L)");
-    const int64_t rows = (int64_t)B * L;
-    int blocks = (int)((rows * Lp + 255) / 256);
+    const int64_t total = (int64_t)B * L * Lp + (out_t ? (int64_t)B * Lp * Lp : 0);
+    int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(mask_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mask, out, L, Lp, rows);
+    hipLaunchKernelGGL(mask_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mask, out, out_t, L, Lp, B);
     VLP_CHECK_LAUNCH("vlp_mask_pack");
     return VLP_OK;
 }

@@ -196,6 +196,7 @@ class Engine(object):
 
         ws = {"Lp": _ru(L, 32)}
         ws["maskb"] = torch.empty(B, L, ws["Lp"], device=dev, dtype=torch.uint8)
+        ws["maskt"] = torch.empty(B, ws["Lp"], ws["Lp"], device=dev, dtype=torch.uint8)
         ws["img16"], ws["vpe_in"], ws["wpe_pad"] = h(Mv, 2048), h(Mv, PE_PAD), h(H, PE_PAD)
         ws["h1"], ws["vis_h"], ws["vispe_h"] = h(Mv, 2048), h(Mv, H), h(Mv, H)
         ws["emb_pre"], ws["x0"] = h(M, H), h(M, H)
@@ -341,7 +342,7 @@ class Engine(object):
         if attention_mask.dim() == 2:       # modeling.py:818-819
             attention_mask = attention_mask[:, None, :].expand(B, L, L)
         attention_mask = attention_mask.to(torch.long).contiguous()
-        K.mask_pack(attention_mask, ws["maskb"], B, L, ws["Lp"])
+        K.mask_pack(attention_mask, ws["maskb"], B, L, ws["Lp"], out_t=ws["maskt"] if train or torch.is_grad_enabled() else None)
         vf = vis_feats.reshape(Mv, 2048)
         if vf.dtype == torch.float32:
             K.copy2d(vf.contiguous(), 2048, True, ws["img16"], 2048, Mv, 2048, 2048)
@@ -547,7 +548,7 @@ class Engine(object):
             self._tn(dy, a["ctx"], self.G(Ln + "attention.output.dense.weight"), M, H, H, ws, beta, bias=self.G(Ln + "attention.output.dense.bias"))
             self._nt(dy, s["oT"], dctx, M, H, H)
             # BertSelfAttention (modeling.py:268-303)
-            K.attn_bwd(a["qkv"], ws["maskb"], a["ctx"], dctx, a["lse"], dqkv, ws["delta"], B, L, A, scale, dropout_p=pa, seed=seed, rng_stream=16 * i + 1)
+            K.attn_bwd(a["qkv"], ws["maskb"], ws["maskt"], a["ctx"], dctx, a["lse"], dqkv, ws["delta"], B, L, A, scale, dropout_p=pa, seed=seed, rng_stream=16 * i + 1)
             self._tn(dqkv, x_in, self.G(Ln + "attention.self.query.weight"), M, 3 * H, H, ws, beta, bias=self.G(Ln + "attention.self.query.bias"))     # packed [3H, H] gradient
             self._nt(dqkv, s["qkvT"], dx, M, H, 3 * H, residual=dpre)
             self._bucket_done(NL - i)
