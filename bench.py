@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL + the DDP wrapper even for one rank (path check)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,7 +109,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
 
     from vlp_amd import synthetic as S
@@ -123,7 +127,7 @@ def main():
     model = BertForPreTrainingLossMask(cfg, num_labels=2, enable_butd=True, len_vis_input=100, tasks="img2txt", allow_random_fc7=True)
     model.half().to(dev)
     eng = model.engine
-    if world > 1:
+    if use_dist:
         model = DDP(model, device_ids=[local_rank], output_device=local_rank, find_unused_parameters=True)
     named = list(model.named_parameters())
     no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
@@ -141,7 +145,7 @@ def main():
     for i in range(args.warmup):
         lt = one(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     if not args.no_kernel_events:
         eng.prof = []
@@ -150,11 +154,11 @@ def main():
     for i in range(args.steps):
         lt = one(args.warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
@@ -190,7 +194,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

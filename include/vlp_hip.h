@@ -222,6 +222,15 @@ int vlp_copy2d(const void* src, int64_t lds, int32_t src_f32, void* dst, int64_t
  * (weight shadows W^T for the dgrad GEMMs; zero padding keeps K % 64 == 0). */
 int vlp_transpose(const void* src, int64_t lds, void* dst, int64_t ldd, int32_t rows, int32_t cols,
                   int32_t rows_pad, void* stream);
+/* Batched form: n independent transposes in one launch.  descs / tile_start live in DEVICE memory; tile_start[i] is the
+ * index of matrix i's first 64x64 tile in the concatenated list (tiles = ceil(rows_pad/64) * ceil(cols/64) per matrix),
+ * total_tiles their sum.  Requirements per matrix: lds, ldd multiples of 8, 16-byte aligned bases. */
+typedef struct {
+    const void* src; void* dst;
+    int64_t lds, ldd;
+    int32_t rows, cols, rows_pad, reserved;
+} vlp_transpose_desc;
+int vlp_transpose_batched(const vlp_transpose_desc* descs_dev, const int32_t* tile_start_dev, int32_t n, int32_t total_tiles, void* stream);
 /* out[i,:] = src[(i / P) * L + pos[i], :]   (gather_seq_out_by_pos, modeling.py:1068-1069) */
 int vlp_gather_rows(const void* src, int64_t lds, const int64_t* pos, void* out, int64_t ldo,
                     int32_t B, int32_t P, int32_t L, int32_t H, void* stream);

@@ -369,6 +369,18 @@ def test_copy2d_transpose_gather_scatter(gen):
     wt = torch.full((200, 320), 5.0, device=DEV, dtype=torch.half)
     K.transpose(w, 200, wt, 320, 300, 200, 320)
     assert torch.equal(wt[:, :300], w.t()) and float(wt[:, 300:].abs().max()) == 0
+    # batched form: several shapes (ragged, padded) in one launch
+    mats = [h16(300, 200, gen=gen), h16(768, 2304, gen=gen), h16(1000, 64, gen=gen), h16(5, 3129 + 7, gen=gen)[:, :3128]]
+    items, outs = [], []
+    for m_ in mats:
+        r_, c_ = m_.shape
+        rp = (r_ + 63) // 64 * 64
+        o_ = torch.full((c_, rp), 3.0, device=DEV, dtype=torch.half)
+        items.append((m_, m_.stride(0), o_, rp, r_, c_, rp))
+        outs.append(o_)
+    K.transpose_batched(K.make_transpose_batch(items, DEV))
+    for m_, o_ in zip(mats, outs):
+        assert torch.equal(o_[:, :m_.shape[0]], m_.t()) and float(o_[:, m_.shape[0]:].abs().max() if o_.shape[1] > m_.shape[0] else 0) == 0
     B, P, L, H = 4, 3, 20, 64
     h = h16(B * L, H, gen=gen)
     pos = torch.randint(0, L, (B, P), device=DEV, generator=gen)

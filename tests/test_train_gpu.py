@@ -156,3 +156,20 @@ def test_entry_script_synthetic(tmp_path):
     assert os.path.exists(os.path.join(out, "model.1.bin")) and os.path.exists(os.path.join(out, "opt.json"))
     sd = torch.load(os.path.join(out, "model.1.bin"))
     assert "bert.encoder.layer.1.output.LayerNorm.bias" in sd and sd["bert.embeddings.word_embeddings.weight"].shape == (28996, 768)
+
+
+def test_bench_through_torchrun_and_rccl_world1():
+    """The launch line the driver uses for N > 1, with N = 1: RCCL process group, parameter broadcast, bucketed
+    ReduceOp.AVG all-reduce hooks fired from the fused backward, barrier + max-over-ranks timing."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--layers", "2",
+           "--batch", "8", "--force-dist", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["final_loss"] == out["config"]["final_loss"]

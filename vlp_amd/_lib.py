@@ -79,6 +79,10 @@ class EmbedBwdArgs(C.Structure):
                 ("drop_p", f32), ("seed", u64), ("vis_stream", u32), ("vispe_stream", u32)]
 
 
+class TransposeDesc(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("lds", i64), ("ldd", i64), ("rows", i32), ("cols", i32), ("rows_pad", i32), ("reserved", i32)]
+
+
 class MlmLossFwdArgs(C.Structure):
     _fields_ = [("logits", vp), ("ld_logits", i64), ("labels", vp), ("weights", vp), ("loss", vp), ("lse", vp), ("coef", vp),
                 ("row_loss", vp), ("B", i32), ("P", i32), ("V", i32), ("drop_worst_ratio", f32)]
@@ -120,6 +124,7 @@ SYMBOLS = {
     "vlp_embed_bwd": (C.c_int, [C.POINTER(EmbedBwdArgs), vp]),
     "vlp_copy2d": (C.c_int, [vp, i64, i32, vp, i64, i32, i32, i32, i32, vp]),
     "vlp_transpose": (C.c_int, [vp, i64, vp, i64, i32, i32, i32, vp]),
+    "vlp_transpose_batched": (C.c_int, [vp, vp, i32, i32, vp]),
     "vlp_gather_rows": (C.c_int, [vp, i64, vp, vp, i64, i32, i32, i32, i32, vp]),
     "vlp_scatter_add_rows": (C.c_int, [vp, i64, vp, vp, i64, i32, i32, i32, i32, vp]),
     "vlp_vqa_mul_fwd": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
@@ -280,6 +285,28 @@ def copy2d(src, lds, src_f32, dst, ldd, rows, cols_src, cols_dst, beta=0):
 def transpose(src, lds, dst, ldd, rows, cols, rows_pad):
     _req_cuda(src, dst)
     _check(load().vlp_transpose(ptr(src), lds, ptr(dst), ldd, rows, cols, rows_pad, stream_ptr()))
+
+
+def make_transpose_batch(items, device):
+    """items: [(src, lds, dst, ldd, rows, cols, rows_pad)] -> (descs_dev, tile_start_dev, n, total_tiles).  The descriptor
+    table is built once (pointers of the flat parameter buffers and shadows are stable) and reused every step."""
+    import numpy as np
+    arr = (TransposeDesc * len(items))()
+    starts, tot = [], 0
+    for i, (src, lds, dst, ldd, rows, cols, rows_pad) in enumerate(items):
+        _req_cuda(src, dst)
+        arr[i] = TransposeDesc(src.data_ptr(), dst.data_ptr(), lds, ldd, rows, cols, rows_pad, 0)
+        starts.append(tot)
+        tot += ((rows_pad + 63) // 64) * ((cols + 63) // 64)
+    raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+    descs = torch.from_numpy(raw).to(device)
+    ts = torch.tensor(starts, dtype=torch.int32, device=device)
+    return descs, ts, len(items), tot
+
+
+def transpose_batched(batch):
+    descs, ts, n, tot = batch
+    _check(load().vlp_transpose_batched(ptr(descs), ptr(ts), n, tot, stream_ptr()))
 
 
 def gather_rows(src, lds, pos, out, ldo, B, P, L, H):

@@ -368,3 +368,54 @@ extern "C" int vlp_gelu_bwd(const void* dy, const void* z, void* dz, int64_t n, 
     VLP_CHECK_LAUNCH("vlp_gelu_bwd");
     return VLP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// batched transposes (all weight shadows W^T of a step in ONE launch).  64x64 tiles, 16-byte global accesses on both
+// sides; grid.x walks the concatenated tile list, `tile_start[i]` = first tile of matrix i.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const vlp_transpose_desc* __restrict__ descs, const int32_t* __restrict__ tile_start, int n) {
+    __shared__ f16 tile[64][72];
+    // locate the matrix of this tile (n is small: linear scan by one lane, broadcast through LDS-free readfirstlane)
+    int mi = 0;
+    const int t = blockIdx.x;
+    while (mi + 1 < n && tile_start[mi + 1] <= t) ++mi;
+    const vlp_transpose_desc d = descs[mi];
+    const f16* src = (const f16*)d.src;
+    f16* dst = (f16*)d.dst;
+    const int tiles_c = (d.cols + 63) / 64;
+    const int lt = t - tile_start[mi];
+    const int r0 = (lt / tiles_c) * 64, c0 = (lt % tiles_c) * 64;
+    const int tr = threadIdx.x >> 3, tc = (threadIdx.x & 7) * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = r0 + tr + 32 * i, c = c0 + tc;
+        f16x8 v = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (r < d.rows) {
+            if (c + 8 <= d.cols) v = ld8(src + (int64_t)r * d.lds + c);
+            else
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (c + e < d.cols) v[e] = src[(int64_t)r * d.lds + c + e];
+        }
+        *reinterpret_cast<f16x8*>(&tile[tr + 32 * i][tc]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = c0 + tr + 32 * i;         // output row
+        const int r = r0 + tc;                  // output column start
+        if (c >= d.cols || r >= d.rows_pad) continue;
+        f16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = tile[tc + e][tr + 32 * i];
+        if (r + 8 <= d.rows_pad) st8(dst + (int64_t)c * d.ldd + r, v);
+        else
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (r + e < d.rows_pad) dst[(int64_t)c * d.ldd + r + e] = v[e];
+    }
+}
+extern "C" int vlp_transpose_batched(const vlp_transpose_desc* descs_dev, const int32_t* tile_start_dev, int32_t n, int32_t total_tiles, void* stream) {
+    VLP_CHECK_ARG(descs_dev && tile_start_dev && n > 0 && total_tiles > 0, "vlp_transpose_batched: bad args");
+    hipLaunchKernelGGL(transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, descs_dev, tile_start_dev, n);
+    VLP_CHECK_LAUNCH("vlp_transpose_batched");
+    return VLP_OK;
+}

@@ -352,11 +352,21 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_glds_kernel(GemmTnParam
     }
 }
 
-// out[n,k] = (beta ? out : 0) + sum_s slab[s][n][k]
-__global__ void gemm_tn_reduce_kernel(const float* slab, f16* C, int64_t ldc, int N, int K, int splits, int beta) {
+// out[n,k] = (beta ? out : 0) + sum_s slab[s][n][k]; the tail of the grid reduces the fused bias partials [s][N]
+__global__ void gemm_tn_reduce_kernel(const float* slab, f16* C, int64_t ldc, int N, int K, int splits, int beta,
+                                      const float* bias_slab, f16* bias_out, int main_blocks) {
+    if ((int)blockIdx.x >= main_blocks) {
+        const int n = ((int)blockIdx.x - main_blocks) * blockDim.x + threadIdx.x;
+        if (n < N) {
+            float s = 0.f;
+            for (int sp = 0; sp < splits; ++sp) s += bias_slab[(int64_t)sp * N + n];
+            bias_out[n] = (f16)(beta ? (float)bias_out[n] + s : s);
+        }
+        return;
+    }
     const int64_t total8 = (int64_t)N * (K / 8);
     const int64_t stride = (int64_t)N * K;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)main_blocks * blockDim.x) {
         const int n = (int)(i / (K / 8));
         const int k = (int)(i % (K / 8)) * 8;
         const float* s = slab + (int64_t)n * K + k;
@@ -377,14 +387,6 @@ __global__ void gemm_tn_reduce_kernel(const float* slab, f16* C, int64_t ldc, in
         for (int j = 0; j < 8; ++j) o[j] = (f16)(beta ? (float)o[j] + v[j] : v[j]);
         st8(dst, o);
     }
-}
-
-__global__ void gemm_tn_bias_reduce_kernel(const float* slab, f16* out, int N, int splits, int beta) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    float s = 0.f;
-    for (int sp = 0; sp < splits; ++sp) s += slab[(int64_t)sp * N + n];
-    out[n] = (f16)(beta ? (float)out[n] + s : s);
 }
 
 static int choose_splits(int M, int N, int K) {
@@ -457,12 +459,10 @@ extern "C" int vlp_gemm_tn(const vlp_gemm_tn_args* a, void* stream) {
         const int64_t total8 = (int64_t)a->N * (a->K / 8);
         int blocks = (int)((total8 + 255) / 256);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, p.C, p.ldc, a->N, a->K, splits, a->beta);
+        const int bias_blocks = a->bias_out ? cdiv(a->N, 256) : 0;
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(blocks + bias_blocks), dim3(256), 0, s, p.slab, p.C, p.ldc, a->N, a->K, splits, a->beta,
+                           p.bias_slab, p.bias_out, blocks);
         VLP_CHECK_LAUNCH("vlp_gemm_tn_reduce");
-        if (a->bias_out) {
-            hipLaunchKernelGGL(gemm_tn_bias_reduce_kernel, dim3(cdiv(a->N, 256)), dim3(256), 0, s, p.bias_slab, p.bias_out, a->N, splits, a->beta);
-            VLP_CHECK_LAUNCH("vlp_gemm_tn_bias_reduce");
-        }
     }
     return VLP_OK;
 }

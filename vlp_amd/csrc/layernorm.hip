@@ -91,7 +91,7 @@ extern "C" int vlp_layernorm_fwd(const vlp_layernorm_fwd_args* a, void* stream) 
 // backward.  Each wave walks rows (grid-stride) keeping per-column partial sums of dgamma / dbeta in
 // registers; partials [nwaves][2][H] go to the workspace and a second kernel reduces them.
 // ---------------------------------------------------------------------------------------------
-#define LNB_BLOCKS 512
+#define LNB_BLOCKS 256
 #define LNB_THREADS 512
 #define LNB_WAVES 8
 

@@ -251,24 +251,29 @@ class Engine(object):
         return sh
 
     def _refresh_shadows(self):
-        model = self._model()
-        cfg = model.config
-        H, I, V = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
+        """All W^T shadows of the step in one batched launch (descriptor table cached: buffer addresses are stable)."""
         sh = self._shadows()
-        for i, s in enumerate(sh["layers"]):
-            L = "bert.encoder.layer.%d." % i
-            K.transpose(self.P(L + "attention.self.query.weight"), H, s["qkvT"], 3 * H, 3 * H, H, 3 * H)   # packed [3H, H] -> [H, 3H]
-            K.transpose(self.P(L + "attention.output.dense.weight"), H, s["oT"], H, H, H, H)
-            K.transpose(self.P(L + "intermediate.dense.weight"), H, s["w1T"], I, I, H, I)
-            K.transpose(self.P(L + "output.dense.weight"), I, s["w2T"], H, H, I, H)
-        K.transpose(self.P("vis_embed.2.weight"), 2048, sh["v2T"], H, H, 2048, H)
-        if model.tasks == "vqa2":
-            NA = model.num_answers
-            K.transpose(self.P("ans_classifier.2.weight"), 2 * H, sh["a2T"], _ru(NA, 64), NA, 2 * H, _ru(NA, 64))
-            K.transpose(self.P("ans_classifier.0.weight"), H, sh["a0T"], 2 * H, 2 * H, H, 2 * H)
-        else:
-            K.transpose(self.P("bert.embeddings.word_embeddings.weight"), H, sh["ET"], _ru(V, 64), V, H, _ru(V, 64))
-            K.transpose(self.P("cls.predictions.transform.dense.weight"), H, sh["tT"], H, H, H, H)
+        if "batch" not in sh:
+            model = self._model()
+            cfg = model.config
+            H, I, V = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
+            items = []
+            for i, s in enumerate(sh["layers"]):
+                L = "bert.encoder.layer.%d." % i
+                items.append((self.P(L + "attention.self.query.weight"), H, s["qkvT"], 3 * H, 3 * H, H, 3 * H))   # packed [3H, H] -> [H, 3H]
+                items.append((self.P(L + "attention.output.dense.weight"), H, s["oT"], H, H, H, H))
+                items.append((self.P(L + "intermediate.dense.weight"), H, s["w1T"], I, I, H, I))
+                items.append((self.P(L + "output.dense.weight"), I, s["w2T"], H, H, I, H))
+            items.append((self.P("vis_embed.2.weight"), 2048, sh["v2T"], H, H, 2048, H))
+            if model.tasks == "vqa2":
+                NA = model.num_answers
+                items.append((self.P("ans_classifier.2.weight"), 2 * H, sh["a2T"], _ru(NA, 64), NA, 2 * H, _ru(NA, 64)))
+                items.append((self.P("ans_classifier.0.weight"), H, sh["a0T"], 2 * H, 2 * H, H, 2 * H))
+            else:
+                items.append((self.P("bert.embeddings.word_embeddings.weight"), H, sh["ET"], _ru(V, 64), V, H, _ru(V, 64)))
+                items.append((self.P("cls.predictions.transform.dense.weight"), H, sh["tT"], H, H, H, H))
+            sh["batch"] = K.make_transpose_batch(items, self.device)
+        K.transpose_batched(sh["batch"])
 
     # ------------------------------------------------------------------------------------------
     # forward
