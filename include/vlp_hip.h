@@ -67,7 +67,8 @@ typedef struct {
     float dropout_p; uint64_t seed; uint32_t rng_stream;
     int32_t variant;                     /* 0 = register-staged 128x128 tiles, 1 = LDS-DMA (global_load_lds) double-buffered,
                                             2 = LDS-DMA single buffer (4 workgroups/CU), 3 = LDS-DMA 256x128 tile, 8 waves,
-                                            4 = 256x128 single buffer; +8 = XCD-aware tile order */
+                                            4 = 256x128 single buffer, 5 = 256x256 tile (16 waves, double-buffered);
+                                            +8 = XCD-aware tile order */
 } vlp_gemm_nt_args;
 int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream);
 
@@ -87,7 +88,9 @@ typedef struct {
     int32_t beta;                        /* 0 or 1 */
     void* workspace; int64_t workspace_bytes;
     int32_t variant;                     /* 0 = ds_read_u16 fragment gathers, 1 = ds_read_b64_tr_b16 (register-staged), 2 = ds_read_b64_tr_b16 +
-                                            LDS-DMA staging with a transpose-read swizzle; +8 = XCD-aware tile order */
+                                            LDS-DMA staging with a transpose-read swizzle, 128x128 tile; 3 / 4 / 5 = the same with
+                                            256x128 / 128x256 / 256x256 (n x k) tiles; +8 = XCD-aware tile order,
+                                            +16 = split-major tile order (with +8: one XCD per row range) */
     int32_t splits;                      /* 0 = choose automatically */
     void* bias_out;                      /* optional [N] fp16: (+)= column sums of A, i.e. the bias gradient of the same
                                             Linear, fused into the k-tile-0 workgroups (replaces a separate vlp_colsum) */

@@ -65,7 +65,7 @@ def gen():
 # =====================================================================================================
 # NT GEMM
 # =====================================================================================================
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 9, 10, 12])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 9, 10, 12, 13])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (1000, 768, 768), (77, 1000, 192), (256, 2304, 768)])
 def test_gemm_nt_plain(variant, M, N, K, gen):
     Kd = K
@@ -92,7 +92,7 @@ def test_gemm_nt_asymmetric_identity(variant):
     assert torch.equal(y, w.t().contiguous())
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5])
 def test_gemm_nt_epilogues(variant, gen):
     M, N, Kd = 200, 384, 256
     x, w = h16(M, Kd, gen=gen), h16(N, Kd, scale=0.06, gen=gen)
@@ -140,7 +140,7 @@ def test_gemm_nt_rejects_bad_args():
 # =====================================================================================================
 # TN GEMM (wgrad), colsum
 # =====================================================================================================
-@pytest.mark.parametrize("variant", [0, 1, 9, 2, 10])
+@pytest.mark.parametrize("variant", [0, 1, 9, 2, 10, 26, 3, 4, 5])
 @pytest.mark.parametrize("M,N,K,splits", [(64, 128, 128, 1), (1000, 256, 384, 1), (1000, 256, 384, 4), (192, 1000, 768, 1),
                                           (2000, 768, 768, 0), (333, 72, 64, 2)])
 def test_gemm_tn(variant, M, N, K, splits, gen):
@@ -169,7 +169,7 @@ def K_ws(M, N, Kd):
     return K.gemm_tn_workspace_bytes(M, N, Kd)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 def test_gemm_tn_asymmetric(variant):
     """dY = I-like selector against an asymmetric X: dW[n,k] must equal X[n,k] for n < M."""
     M, N, Kd = 128, 128, 128

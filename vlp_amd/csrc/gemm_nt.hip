@@ -20,7 +20,6 @@
 #include "common.h"
 
 #define BM 128
-#define BN 128
 #define BK 64
 
 struct GemmNtParams {
@@ -46,20 +45,21 @@ DEVFN int swz_w(int r) { return (((r >> 4) & 3) << 1) | ((r >> 1) & 1); }
 // VARIANT 0: register-staged, double-buffered   1: LDS-DMA, double-buffered   2: LDS-DMA, single buffer (32 KiB -> up to
 // 4 workgroups per CU; overlap comes from co-resident workgroups instead of an in-block pipeline)
 // BM_T: rows of the block tile (128 -> 4 waves 2x2, 256 -> 8 waves 4x2); the wave tile is always 64x64.
-template <int VARIANT, int BM_T>
-__global__ __launch_bounds__(BM_T * 2, (VARIANT == 2 ? 4 : 2)) void gemm_nt_kernel(GemmNtParams p) {
+template <int VARIANT, int BM_T, int BN_T>
+__global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, ((VARIANT == 2 || BN_T == 256) ? 4 : 2)) void gemm_nt_kernel(GemmNtParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     f16* smem = reinterpret_cast<f16*>(smem_raw);
-    constexpr int T = BM_T * 2;           // threads
+    constexpr int WN_ = BN_T / 64;        // waves along n
+    constexpr int T = (BM_T / 64) * WN_ * 64;   // threads
     constexpr int RPP = T / 8;            // tile rows covered per staging pass
-    constexpr int XP = BM_T / RPP;        // passes for the X tile (4)
-    constexpr int WP = BN / RPP;          // passes for the W tile (4 or 2)
-    constexpr int XT = BM_T * BK, WT = BN * BK;      // halfs
-    // layout: [buf][ X tile BM_T*64 | W tile 128*64 ]
+    constexpr int XP = BM_T / RPP;        // passes for the X tile
+    constexpr int WP = BN_T / RPP;        // passes for the W tile
+    constexpr int XT = BM_T * BK, WT = BN_T * BK;      // halfs
+    // layout: [buf][ X tile BM_T*64 | W tile BN_T*64 ]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / WN_, wn = wid % WN_;
     const int g = lane >> 4, li = lane & 15;
 
     int bid = blockIdx.x;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(BM_T * 2, (VARIANT == 2 ? 4 : 2)) void gemm_nt_kern
     }
     const int tile_m = bid / p.tiles_n;
     const int tile_n = bid % p.tiles_n;
-    const int m0 = tile_m * BM_T, n0 = tile_n * BN;
+    const int m0 = tile_m * BM_T, n0 = tile_n * BN_T;
 
     // ---- staging geometry: thread -> (row, physical chunk) per pass ------------------------------
     const int srow = tid >> 3;        // 0..RPP-1 (+RPP*i)
@@ -297,22 +297,23 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
     p.act = a->act; p.mulmode = a->mul_mode;
     p.alpha = a->alpha;
     p.drop = make_drop(a->dropout_p, a->seed, a->rng_stream);
-    p.tiles_n = cdiv(a->N, BN);
     hipStream_t s = (hipStream_t)stream;
-#define LAUNCH_NT(V, BMT, NBUF)                                                                                         \
+#define LAUNCH_NT(V, BMT, BNT, NBUF)                                                                                    \
     do {                                                                                                                \
-        const size_t smem = (size_t)(NBUF) * ((BMT) + BN) * BK * sizeof(f16);                                           \
+        const size_t smem = (size_t)(NBUF) * ((BMT) + (BNT)) * BK * sizeof(f16);                                        \
         static bool attr = false;                                                                                       \
-        if (!attr) { hipFuncSetAttribute((const void*)gemm_nt_kernel<V, BMT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; } \
-        hipLaunchKernelGGL((gemm_nt_kernel<V, BMT>), dim3(cdiv(a->M, (BMT)) * p.tiles_n), dim3((BMT) * 2), smem, s, p);   \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<V, BMT, BNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; } \
+        p.tiles_n = cdiv(a->N, (BNT));                                                                                  \
+        hipLaunchKernelGGL((gemm_nt_kernel<V, BMT, BNT>), dim3(cdiv(a->M, (BMT)) * p.tiles_n), dim3(((BMT) / 64) * ((BNT) / 64) * 64), smem, s, p); \
     } while (0)
     p.xcd_remap = (a->variant & 8) ? 1 : 0;
     switch (a->variant & 7) {
-        case 0: LAUNCH_NT(0, 128, 2); break;
-        case 2: LAUNCH_NT(2, 128, 1); break;
-        case 3: LAUNCH_NT(1, 256, 2); break;
-        case 4: LAUNCH_NT(2, 256, 1); break;
-        default: LAUNCH_NT(1, 128, 2); break;
+        case 0: LAUNCH_NT(0, 128, 128, 2); break;
+        case 2: LAUNCH_NT(2, 128, 128, 1); break;
+        case 3: LAUNCH_NT(1, 256, 128, 2); break;
+        case 4: LAUNCH_NT(2, 256, 128, 1); break;
+        case 5: LAUNCH_NT(1, 256, 256, 2); break;
+        default: LAUNCH_NT(1, 128, 128, 2); break;
     }
 #undef LAUNCH_NT
     VLP_CHECK_LAUNCH("vlp_gemm_nt");

@@ -30,7 +30,7 @@ struct GemmTnParams {
     float* bias_slab;            // [splits][N] fp32 (when splits > 1 and bias_out)
     f16* bias_out;               // [N] or NULL: column sums of A (bias gradient), fused
     int M, N, K, beta, splits, rows_per_split;
-    int tiles_k, tiles_n, xcd_remap;
+    int tiles_k, tiles_n, xcd_remap, split_major;
 };
 
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -59,9 +59,16 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(GemmTnParams p) 
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const int split = bid % p.splits;
-    const int ktile = (bid / p.splits) % p.tiles_k;
-    const int ntile = bid / (p.splits * p.tiles_k);
+    int split, ktile, ntile;
+    if (p.split_major) {      // order (split, n-tile, k-tile): with xcd_remap one XCD works on ONE row range -> its co-resident
+        ktile = bid % p.tiles_k;                       // workgroups share the few dY / X panels of that range in the XCD's L2
+        ntile = (bid / p.tiles_k) % p.tiles_n;
+        split = bid / (p.tiles_k * p.tiles_n);
+    } else {
+        split = bid % p.splits;
+        ktile = (bid / p.splits) % p.tiles_k;
+        ntile = bid / (p.splits * p.tiles_k);
+    }
     const int n0 = ntile * TN_BN;
     const int k0 = ktile * TN_BK;
     const int m_begin = split * p.rows_per_split;
@@ -206,15 +213,21 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(GemmTnParams p) 
 // =================================================================================================
 DEVFN int tn_swz(int r) { return ((r & 3) | (((r >> 3) & 1) << 2)) << 1; }
 
-__global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_glds_kernel(GemmTnParams p) {
+// BN_T x BK_T output tile (each 128 or 256); one wave per 64x64 sub-tile -> 4, 8 or 16 waves.
+template <int BN_T, int BK_T>
+__global__ __launch_bounds__((BN_T / 64) * (BK_T / 64) * 64, ((BN_T / 64) * (BK_T / 64) >= 16 ? 4 : 2)) void gemm_tn_glds_kernel(GemmTnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     f16* smem = reinterpret_cast<f16*>(smem_raw);
-    constexpr int PITCH = 128;
-    constexpr int TILE = TN_BM * PITCH;   // halfs (16 KiB)
+    constexpr int WK_ = BK_T / 64;
+    constexpr int T = (BN_T / 64) * WK_ * 64;            // threads
+    constexpr int ATILE = TN_BM * BN_T, BTILE = TN_BM * BK_T;   // halfs
+    constexpr int ACH = BN_T / 8, BCH = BK_T / 8;        // 16-B chunks per tile row (16 or 32)
+    constexpr int AP = TN_BM * ACH / T, BP = TN_BM * BCH / T;   // staging passes
+    constexpr int ARP = T / ACH, BRP = T / BCH;          // tile rows covered per pass
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wid >> 1, wk = wid & 1;
+    const int wn = wid / WK_, wk = wid % WK_;
     const int g = lane >> 4, li = lane & 15;
 
     int bid = blockIdx.x;
@@ -222,26 +235,30 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_glds_kernel(GemmTnParam
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const int split = bid % p.splits;
-    const int ktile = (bid / p.splits) % p.tiles_k;
-    const int ntile = bid / (p.splits * p.tiles_k);
-    const int n0 = ntile * TN_BN;
-    const int k0 = ktile * TN_BK;
+    int split, ktile, ntile;
+    if (p.split_major) {
+        ktile = bid % p.tiles_k;
+        ntile = (bid / p.tiles_k) % p.tiles_n;
+        split = bid / (p.tiles_k * p.tiles_n);
+    } else {
+        split = bid % p.splits;
+        ktile = (bid / p.splits) % p.tiles_k;
+        ntile = bid / (p.splits * p.tiles_k);
+    }
+    const int n0 = ntile * BN_T;
+    const int k0 = ktile * BK_T;
     const int m_begin = split * p.rows_per_split;
     const int m_end = min(p.M, m_begin + p.rows_per_split);
     const int nstages = (m_end - m_begin + TN_BM - 1) / TN_BM;
 
-    // staging: pass i covers rows 16*i .. 16*i+15; thread -> (row = 16*i + tid/16, physical chunk = tid%16)
-    const int srow = tid >> 4, sp = tid & 15;
-    int acol[4], bcol[4];
-    // column offsets (halfs) of the logical chunk this thread fetches in pass i, clamped in-bounds (columns past N / K only
-    // feed output rows / columns that are never stored)
+    // staging: pass i covers tile rows ARP*i .. ; thread -> (row = ARP*i + tid/ACH, physical chunk = tid%ACH).  The swizzle acts on
+    // the low 4 bits of the chunk index (one 256-byte bank row), so 512-byte rows behave like two independent 256-byte halves.
+    const int arow = tid / ACH, apc = tid % ACH, brow = tid / BCH, bpc = tid % BCH;
+    int acol[AP], bcol[BP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = sp ^ tn_swz(srow + 16 * i);
-        acol[i] = min(n0 + c * 8, (int)p.lda - 8);
-        bcol[i] = min(k0 + c * 8, (int)p.ldb - 8);
-    }
+    for (int i = 0; i < AP; ++i) acol[i] = min(n0 + (apc ^ tn_swz(arow + ARP * i)) * 8, (int)p.lda - 8);
+#pragma unroll
+    for (int i = 0; i < BP; ++i) bcol[i] = min(k0 + (bpc ^ tn_swz(brow + BRP * i)) * 8, (int)p.ldb - 8);
 
     f32x4 acc[4][4];   // [tn][tk]
 #pragma unroll
@@ -255,36 +272,38 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_glds_kernel(GemmTnParam
     const f16x8 ones = (f16x8){(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
 
     auto stage = [&](int st, int buf) {
-        f16* as = smem + buf * 2 * TILE;
-        f16* bs = as + TILE;
+        f16* as = smem + buf * (ATILE + BTILE);
+        f16* bs = as + ATILE;
         const int mbase = m_begin + st * TN_BM;
-        if (mbase + TN_BM <= m_end) {            // full stage (wave-uniform): LDS-DMA
+        if (mbase + TN_BM <= m_end) {            // full stage (wave-uniform): LDS-DMA, 64 lanes = 1 KiB contiguous in LDS
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = mbase + srow + 16 * i;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.A + (int64_t)m * p.lda + acol[i]),
-                                                 (__attribute__((address_space(3))) void*)(as + (16 * i + 4 * wid) * PITCH), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.B + (int64_t)m * p.ldb + bcol[i]),
-                                                 (__attribute__((address_space(3))) void*)(bs + (16 * i + 4 * wid) * PITCH), 16, 0, 0);
-            }
+            for (int i = 0; i < AP; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.A + (int64_t)(mbase + arow + ARP * i) * p.lda + acol[i]),
+                                                 (__attribute__((address_space(3))) void*)(as + (ARP * i) * BN_T + wid * 512), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < BP; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.B + (int64_t)(mbase + brow + BRP * i) * p.ldb + bcol[i]),
+                                                 (__attribute__((address_space(3))) void*)(bs + (BRP * i) * BK_T + wid * 512), 16, 0, 0);
         } else {                                  // ragged tail: through registers with zero fill, same LDS image
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = srow + 16 * i;
-                const int m = mbase + r;
-                u32x4 av = (u32x4){0, 0, 0, 0}, bv = (u32x4){0, 0, 0, 0};
-                if (m < m_end) {
-                    av = *reinterpret_cast<const u32x4*>(p.A + (int64_t)m * p.lda + acol[i]);
-                    bv = *reinterpret_cast<const u32x4*>(p.B + (int64_t)m * p.ldb + bcol[i]);
-                }
-                *reinterpret_cast<u32x4*>(as + r * PITCH + sp * 8) = av;
-                *reinterpret_cast<u32x4*>(bs + r * PITCH + sp * 8) = bv;
+            for (int i = 0; i < AP; ++i) {
+                const int r = arow + ARP * i, m = mbase + r;
+                u32x4 v = (u32x4){0, 0, 0, 0};
+                if (m < m_end) v = *reinterpret_cast<const u32x4*>(p.A + (int64_t)m * p.lda + acol[i]);
+                *reinterpret_cast<u32x4*>(as + r * BN_T + apc * 8) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < BP; ++i) {
+                const int r = brow + BRP * i, m = mbase + r;
+                u32x4 v = (u32x4){0, 0, 0, 0};
+                if (m < m_end) v = *reinterpret_cast<const u32x4*>(p.B + (int64_t)m * p.ldb + bcol[i]);
+                *reinterpret_cast<u32x4*>(bs + r * BK_T + bpc * 8) = v;
             }
         }
     };
     auto compute = [&](int buf) {
-        const f16* as = smem + buf * 2 * TILE;   // dY tile [m][n]
-        const f16* bs = as + TILE;               // X tile  [m][k]
+        const f16* as = smem + buf * (ATILE + BTILE);   // dY tile [m][n]
+        const f16* bs = as + ATILE;                     // X tile  [m][k]
 #pragma unroll
         for (int ms = 0; ms < 2; ++ms) {
             const int r0 = ms * 32 + 8 * g + (li >> 2);     // this lane's piece row (first read); second read: +4 (same swizzle)
@@ -293,10 +312,10 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_glds_kernel(GemmTnParam
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int cx = wk * 64 + 16 * t + 4 * (li & 3), cy = wn * 64 + 16 * t + 4 * (li & 3);
-                const f16* px = bs + r0 * PITCH + (((cx >> 3) ^ sw) << 3) + (cx & 4);
-                const f16* py = as + r0 * PITCH + (((cy >> 3) ^ sw) << 3) + (cy & 4);
-                f16x4 x0 = lds_tr_read(px), x1 = lds_tr_read(px + 4 * PITCH);
-                f16x4 y0 = lds_tr_read(py), y1 = lds_tr_read(py + 4 * PITCH);
+                const f16* px = bs + r0 * BK_T + (((cx >> 3) ^ sw) << 3) + (cx & 4);
+                const f16* py = as + r0 * BN_T + (((cy >> 3) ^ sw) << 3) + (cy & 4);
+                f16x4 x0 = lds_tr_read(px), x1 = lds_tr_read(px + 4 * BK_T);
+                f16x4 y0 = lds_tr_read(py), y1 = lds_tr_read(py + 4 * BN_T);
                 xf[t] = (f16x8){x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
                 yf[t] = (f16x8){y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
             }
@@ -431,29 +450,41 @@ extern "C" int vlp_gemm_tn(const vlp_gemm_tn_args* a, void* stream) {
     p.tiles_k = cdiv(a->K, TN_BK);
     p.tiles_n = cdiv(a->N, TN_BN);
     p.xcd_remap = (a->variant & 8) ? 1 : 0;
+    p.split_major = (a->variant & 16) ? 1 : 0;
     if (splits > 1) {
         const int64_t need = (int64_t)splits * a->N * a->K * (int64_t)sizeof(float) + (a->bias_out ? (int64_t)splits * a->N * (int64_t)sizeof(float) : 0);
         if (!a->workspace || a->workspace_bytes < need)
             return vlp_set_error(VLP_ERR_WORKSPACE, "vlp_gemm_tn: workspace %lld < %lld bytes", (long long)a->workspace_bytes, (long long)need);
         VLP_CHECK_ARG((uintptr_t)a->workspace % 16 == 0, "vlp_gemm_tn: workspace must be 16-byte aligned");
     }
-    dim3 grid(p.tiles_k * p.tiles_n * splits), block(TN_THREADS);
-    const size_t smem = 2 * 2 * TN_BM * TN_PITCH * sizeof(f16);   // 68 KiB
     hipStream_t s = (hipStream_t)stream;
-    if ((a->variant & 7) == 2) {
-        const size_t smem2 = 2 * 2 * TN_BM * 128 * sizeof(f16);   // 64 KiB
-        static bool attr2 = false;
-        if (!attr2) { hipFuncSetAttribute((const void*)gemm_tn_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2); attr2 = true; }
-        hipLaunchKernelGGL(gemm_tn_glds_kernel, grid, block, smem2, s, p);
-    } else if ((a->variant & 7) == 1) {
-        static bool attr1 = false;
-        if (!attr1) { hipFuncSetAttribute((const void*)gemm_tn_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr1 = true; }
-        hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, block, smem, s, p);
-    } else {
-        static bool attr0 = false;
-        if (!attr0) { hipFuncSetAttribute((const void*)gemm_tn_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr0 = true; }
-        hipLaunchKernelGGL(gemm_tn_kernel<0>, grid, block, smem, s, p);
+    const int base = a->variant & 7;
+#define LAUNCH_TN_GLDS(BNT, BKT)                                                                                        \
+    do {                                                                                                                \
+        const size_t smem2 = (size_t)2 * TN_BM * ((BNT) + (BKT)) * sizeof(f16);                                         \
+        static bool attr = false;                                                                                       \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<BNT, BKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2); attr = true; } \
+        p.tiles_k = cdiv(a->K, (BKT)); p.tiles_n = cdiv(a->N, (BNT));                                                   \
+        hipLaunchKernelGGL((gemm_tn_glds_kernel<BNT, BKT>), dim3(p.tiles_k * p.tiles_n * splits), dim3(((BNT) / 64) * ((BKT) / 64) * 64), smem2, s, p); \
+    } while (0)
+    if (base == 2) LAUNCH_TN_GLDS(128, 128);
+    else if (base == 3) LAUNCH_TN_GLDS(256, 128);
+    else if (base == 4) LAUNCH_TN_GLDS(128, 256);
+    else if (base == 5) LAUNCH_TN_GLDS(256, 256);
+    else {
+        dim3 grid(p.tiles_k * p.tiles_n * splits), block(TN_THREADS);
+        const size_t smem = 2 * 2 * TN_BM * TN_PITCH * sizeof(f16);   // 68 KiB
+        if (base == 1) {
+            static bool attr1 = false;
+            if (!attr1) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr1 = true; }
+            hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, block, smem, s, p);
+        } else {
+            static bool attr0 = false;
+            if (!attr0) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr0 = true; }
+            hipLaunchKernelGGL(gemm_tn_kernel<0>, grid, block, smem, s, p);
+        }
     }
+#undef LAUNCH_TN_GLDS
     VLP_CHECK_LAUNCH("vlp_gemm_tn");
     if (splits > 1) {
         const int64_t total8 = (int64_t)a->N * (a->K / 8);

@@ -44,7 +44,7 @@ class _State(object):
 
 class Engine(object):
     GEMM_NT_VARIANT = None   # None -> autotune per (M, N, K) on first use among NT_CANDIDATES; or force an int
-    NT_CANDIDATES = (1, 2, 4, 9, 10, 11, 12)   # LDS-DMA variants (+8 = XCD-aware tile order); see include/vlp_hip.h
+    NT_CANDIDATES = (1, 2, 4, 5, 9, 10, 11, 12, 13)   # LDS-DMA variants (+8 = XCD-aware tile order); see include/vlp_hip.h
     GEMM_TN_VARIANT = 2      # ds_read_b64_tr_b16 fragment reads + LDS-DMA staging
     TN_SPLITS = None         # None -> autotune the split-M factor per (M, N, K) among TN_SPLIT_CANDIDATES
     TN_SPLIT_CANDIDATES = (0, 2, 4, 8, 16)
@@ -289,17 +289,20 @@ class Engine(object):
             return v
         best, best_t = self.NT_CANDIDATES[0], float("inf")
         if M * N >= 128 * 128 * 8:          # tiny problems: not worth timing
-            for cand in self.NT_CANDIDATES:
-                K.gemm_nt(x, w, y, M, N, Kd, variant=cand, **kw)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(3):
+            for rnd in range(2):              # two interleaved rounds, best-of: robust against clock / neighbour noise
+                for cand in self.NT_CANDIDATES:
+                    if cand & 7 == 5 and N < 1024:
+                        continue                  # 256-wide n tiles leave most CUs idle on narrow outputs
                     K.gemm_nt(x, w, y, M, N, Kd, variant=cand, **kw)
-                e1.record()
-                e1.synchronize()
-                t = e0.elapsed_time(e1)
-                if t < best_t:
-                    best, best_t = cand, t
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(4):
+                        K.gemm_nt(x, w, y, M, N, Kd, variant=cand, **kw)
+                    e1.record()
+                    e1.synchronize()
+                    t = e0.elapsed_time(e1)
+                    if t < best_t:
+                        best, best_t = cand, t
         Engine._nt_choice[key] = best
         return best
 
