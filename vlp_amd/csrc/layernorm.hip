@@ -114,8 +114,26 @@ __global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(
 #pragma unroll
         for (int e = 0; e < 8; ++e) { g[j][e] = (float)gv[e]; dg[j][e] = 0.f; db[j][e] = 0.f; }
     }
+    // software pipeline: the raw 16-byte vectors (and statistics) of the NEXT row are requested before the current row is
+    // reduced, so two rows of HBM traffic are in flight per wave
+    f16x8 xc[MAXJ], dc[MAXJ], xn[MAXJ], dn[MAXJ];
+    float mu_c = 0.f, rs_c = 0.f, mu_n = 0.f, rs_n = 0.f;
+    auto fetch = [&](int row, f16x8 (&X)[MAXJ], f16x8 (&D)[MAXJ], float& m_, float& r_) {
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int c = lane + 64 * j;
+            if (c < nch) {
+                X[j] = ld8(x + (int64_t)row * ldx + c * 8);
+                D[j] = ld8(dy + (int64_t)row * lddy + c * 8);
+            }
+        }
+        m_ = mean[row];
+        r_ = rstd[row];
+    };
+    if (wave < M) fetch(wave, xc, dc, mu_c, rs_c);
     for (int row = wave; row < M; row += nwaves) {
-        const float mu = mean[row], rs = rstd[row];
+        if (row + nwaves < M) fetch(row + nwaves, xn, dn, mu_n, rs_n);
+        const float mu = mu_c, rs = rs_c;
         const uint32_t rk_dy = dyd.thresh ? drop_rowkey(dyd, (uint64_t)row) : 0u;
         const uint32_t rk_out = outd.thresh ? drop_rowkey(outd, (uint64_t)row) : 0u;
         float xh[MAXJ][8], d[MAXJ][8];
@@ -124,8 +142,7 @@ __global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(
         for (int j = 0; j < MAXJ; ++j) {
             const int c = lane + 64 * j;
             if (c < nch) {
-                f16x8 xv = ld8(x + (int64_t)row * ldx + c * 8);
-                f16x8 dv = ld8(dy + (int64_t)row * lddy + c * 8);
+                const f16x8 xv = xc[j], dv = dc[j];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float dd = (float)dv[e];
@@ -159,6 +176,10 @@ __global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(
                 if (dxd) st8(dxd + (int64_t)row * lddxd + c * 8, od);
             }
         }
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) { xc[j] = xn[j]; dc[j] = dn[j]; }
+        mu_c = mu_n;
+        rs_c = rs_n;
     }
     // block-level reduction of the 4 waves' column partials through LDS, one partial row per block
     extern __shared__ float lnb_sh[];      // [LNB_WAVES][2H]

@@ -212,6 +212,7 @@ class Engine(object):
         if P > 0:
             R = B * P
             ws.update(sel=h(R, H), tz=h(R, H), tg=h(R, H), tln=h(R, H), tstat=(f(R), f(R)), logits=h(R, Vp), dlogits=h(R, Vp),
+                      dlT=h(Vp, _ru(R, 64)),
                       lse_ce=f(R), coef=f(R), row_loss=f(R), dtln=h(R, H), dtg=h(R, H), dtz=h(R, H), dsel=h(R, H))
         ws["loss"] = f(260)
         if model.tasks == "vqa2":
@@ -246,7 +247,7 @@ class Engine(object):
             NAp = _ru(model.num_answers, 64)
             sh.update(a2T=h(2 * H, NAp), a0T=h(H, 2 * H))
         else:
-            sh.update(ET=h(H, _ru(V, 64)), tT=h(H, H))
+            sh.update(tT=h(H, H))
         self._shadow = sh
         return sh
 
@@ -270,7 +271,6 @@ class Engine(object):
                 items.append((self.P("ans_classifier.2.weight"), 2 * H, sh["a2T"], _ru(NA, 64), NA, 2 * H, _ru(NA, 64)))
                 items.append((self.P("ans_classifier.0.weight"), H, sh["a0T"], 2 * H, 2 * H, H, 2 * H))
             else:
-                items.append((self.P("bert.embeddings.word_embeddings.weight"), H, sh["ET"], _ru(V, 64), V, H, _ru(V, 64)))
                 items.append((self.P("cls.predictions.transform.dense.weight"), H, sh["tT"], H, H, H, H))
             sh["batch"] = K.make_transpose_batch(items, self.device)
         K.transpose_batched(sh["batch"])
@@ -520,7 +520,12 @@ class Engine(object):
             K.mlm_loss_bwd(ws["logits"], Vp, st_labels(st), ws["lse_ce"], ws["coef"], gscale, ws["dlogits"], Vp, R, V)
             # tied decoder (modeling.py:445-448): dE[V,H] = dlogits^T . t ; the embedding scatter adds to it later
             self._tn(ws["dlogits"], ws["tln"], self.G(E + "word_embeddings.weight"), R, V, H, ws, beta, bias=self.G(C + "bias"))
-            self._nt(ws["dlogits"], sh["ET"], ws["dtln"], R, H, Vp)
+            # dgrad through the tied decoder: dt[R,H] = dlogits[R,V] . E[V,H].  As an NT GEMM this is 12 workgroups walking
+            # K = 29056; instead transpose dlogits (11 MB) and contract over the vocabulary rows with the split-M wgrad kernel,
+            # reading E in place (no E^T shadow).
+            Rp = _ru(R, 64)
+            K.transpose(ws["dlogits"], Vp, ws["dlT"], Rp, R, Vp, Rp)
+            self._tn(ws["dlT"], self.P(E + "word_embeddings.weight"), ws["dtln"], V, R, H, ws, 0)
             K.layernorm_bwd(ws["dtln"], ws["tg"], self.P(C + "transform.LayerNorm.weight"), ws["tstat"][0], ws["tstat"][1], ws["dtg"],
                             self.G(C + "transform.LayerNorm.weight"), self.G(C + "transform.LayerNorm.bias"), R, H, ws["ln_ws"], beta=beta)
             K.gelu_bwd(ws["dtg"], ws["tz"], ws["dtz"], R * H)
