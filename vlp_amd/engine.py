@@ -46,6 +46,7 @@ class Engine(object):
     GEMM_NT_VARIANT = None   # None -> autotune per (M, N, K) on first use among NT_CANDIDATES; or force an int
     NT_CANDIDATES = (1, 2, 4, 5, 9, 10, 11, 12, 13)   # LDS-DMA variants (+8 = XCD-aware tile order); see include/vlp_hip.h
     GEMM_TN_VARIANT = 2      # ds_read_b64_tr_b16 fragment reads + LDS-DMA staging
+    WGRAD_SIDE_STREAM = True # weight-gradient GEMMs of the encoder layers on a second HIP stream, concurrent with the dgrad chain
     TN_SPLITS = None         # None -> autotune the split-M factor per (M, N, K) among TN_SPLIT_CANDIDATES
     TN_SPLIT_CANDIDATES = (0, 2, 4, 8, 16)
     _nt_choice = {}          # shared across engines of one process: (M, N, K) -> variant
@@ -222,6 +223,10 @@ class Engine(object):
         # backward scratch (shared by all layers)
         ws.update(dx=h(M, H), dx_alt=h(M, H), dpre=h(M, H), dpre_d=h(M, H), dz=h(M, I), dctx=h(M, H), dqkv=h(M, 3 * H),
                   delta=f(B, A, L), d_vis_h=h(Mv, H), d_vispe_h=h(Mv, H), dz1v=h(Mv, 2048), dwpe_pad=h(H, PE_PAD), acc32=f(64 * 8 * H))
+        # dY operands of the weight-gradient GEMMs, double-buffered by layer parity: the wgrads of layer i run on a side stream
+        # while the main stream already works on layer i-1
+        ws["dyset"] = [{"dpre2": h(M, H), "dpre2_d": h(M, H), "dpre1": h(M, H), "dpre1_d": h(M, H), "dz": h(M, I), "dqkv": h(M, 3 * H)}
+                       for _ in range(2)]
         tn_bytes = max(K.gemm_tn_workspace_bytes(M, I, H), K.gemm_tn_workspace_bytes(Mv, 2048, 2048), K.gemm_tn_workspace_bytes(M, 3 * H, H))
         ws["tn_ws"] = torch.empty(tn_bytes, device=dev, dtype=torch.uint8)
         ws["cs_ws"] = torch.empty(max(K.colsum_workspace_bytes(M, I), K.colsum_workspace_bytes(B * max(P, 1), Vp)), device=dev, dtype=torch.uint8)
@@ -535,36 +540,75 @@ class Engine(object):
         self._bucket_done(0)
 
         # ---- encoder layers, last to first ----------------------------------------------------------------
-        dpre, dpre_d, dz, dctx, dqkv = ws["dpre"], ws["dpre_d"], ws["dz"], ws["dctx"], ws["dqkv"]
+        # The dgrad chain (LN-bwd -> dgrad GEMMs -> attention-bwd) is the critical path; the four weight-gradient GEMMs of a
+        # layer only consume its dY tensors.  They are issued on a side stream (ordered after their producers by
+        # wait_stream) so that they co-run with the next kernels of the chain; dY buffers alternate by layer parity and the
+        # main stream waits for the side stream's event before it reuses a set.
+        dctx = ws["dctx"]
         scale = 1.0 / math.sqrt(H // A)
+        main = torch.cuda.current_stream()
+        use_side = self.WGRAD_SIDE_STREAM
+        if use_side and getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._side_done = [None, None]
+        side = self._side if use_side else None
+
+        def on_side(fn):
+            if not use_side:
+                fn()
+                return
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                fn()
+
+        if use_side:
+            side.wait_stream(main)          # head wgrads above ran on main; order the side stream after them (tn_ws reuse)
         for i in reversed(range(NL)):
             Ln = "bert.encoder.layer.%d." % i
             a = ws["layers"][i]
             s = sh["layers"][i]
             x_in = ws["layers"][i - 1]["x2"] if i > 0 else ws["x0"]
+            ds = ws["dyset"][i & 1]
+            if use_side and self._side_done[i & 1] is not None:
+                main.wait_event(self._side_done[i & 1])       # wgrads of layer i+2 have finished reading this set
             # BertOutput: LN(dropout(dense(g)) + x1)   (modeling.py:353-357)
-            dd = dpre_d if p > 0 else None
+            dpre = ds["dpre2"]
             K.layernorm_bwd(dx, a["pre2"], self.P(Ln + "output.LayerNorm.weight"), a["st2"][0], a["st2"][1], dpre,
                             self.G(Ln + "output.LayerNorm.weight"), self.G(Ln + "output.LayerNorm.bias"), M, H, ws["ln_ws"], beta=beta,
-                            dx_drop=dd, out_drop=(p, seed, 16 * i + 3))
-            dy = dpre_d if p > 0 else dpre
-            self._tn(dy, a["g"], self.G(Ln + "output.dense.weight"), M, H, I, ws, beta, bias=self.G(Ln + "output.dense.bias"))
-            self._nt(dy, s["w2T"], dz, M, I, H, mul_src=a["z"], mul_mode=K.MUL_GELU_GRAD)      # dG * gelu'(z)
+                            dx_drop=ds["dpre2_d"] if p > 0 else None, out_drop=(p, seed, 16 * i + 3))
+            dy2 = ds["dpre2_d"] if p > 0 else dpre
+            on_side(lambda: self._tn(dy2, a["g"], self.G(Ln + "output.dense.weight"), M, H, I, ws, beta, bias=self.G(Ln + "output.dense.bias")))
+            self._nt(dy2, s["w2T"], ds["dz"], M, I, H, mul_src=a["z"], mul_mode=K.MUL_GELU_GRAD)      # dG * gelu'(z)
             # BertIntermediate (modeling.py:340-343)
-            self._tn(dz, a["x1"], self.G(Ln + "intermediate.dense.weight"), M, I, H, ws, beta, bias=self.G(Ln + "intermediate.dense.bias"))
-            self._nt(dz, s["w1T"], dx, M, H, I, residual=dpre)                                  # + residual path of LN2's input
+            on_side(lambda: self._tn(ds["dz"], a["x1"], self.G(Ln + "intermediate.dense.weight"), M, I, H, ws, beta,
+                                     bias=self.G(Ln + "intermediate.dense.bias")))
+            self._nt(ds["dz"], s["w1T"], dx, M, H, I, residual=dpre)                            # + residual path of LN2's input
             # BertSelfOutput: LN(dropout(dense(ctx)) + x)   (modeling.py:313-317)
+            dpre = ds["dpre1"]
             K.layernorm_bwd(dx, a["pre1"], self.P(Ln + "attention.output.LayerNorm.weight"), a["st1"][0], a["st1"][1], dpre,
                             self.G(Ln + "attention.output.LayerNorm.weight"), self.G(Ln + "attention.output.LayerNorm.bias"), M, H, ws["ln_ws"],
-                            beta=beta, dx_drop=dd, out_drop=(p, seed, 16 * i + 2))
-            dy = dpre_d if p > 0 else dpre
-            self._tn(dy, a["ctx"], self.G(Ln + "attention.output.dense.weight"), M, H, H, ws, beta, bias=self.G(Ln + "attention.output.dense.bias"))
-            self._nt(dy, s["oT"], dctx, M, H, H)
+                            beta=beta, dx_drop=ds["dpre1_d"] if p > 0 else None, out_drop=(p, seed, 16 * i + 2))
+            dy1 = ds["dpre1_d"] if p > 0 else dpre
+            on_side(lambda: self._tn(dy1, a["ctx"], self.G(Ln + "attention.output.dense.weight"), M, H, H, ws, beta,
+                                     bias=self.G(Ln + "attention.output.dense.bias")))
+            self._nt(dy1, s["oT"], dctx, M, H, H)
             # BertSelfAttention (modeling.py:268-303)
+            dqkv = ds["dqkv"]
             K.attn_bwd(a["qkv"], ws["maskb"], ws["maskt"], a["ctx"], dctx, a["lse"], dqkv, ws["delta"], B, L, A, scale, dropout_p=pa, seed=seed, rng_stream=16 * i + 1)
-            self._tn(dqkv, x_in, self.G(Ln + "attention.self.query.weight"), M, 3 * H, H, ws, beta, bias=self.G(Ln + "attention.self.query.bias"))     # packed [3H, H] gradient
+
+            def last_wgrad():
+                self._tn(dqkv, x_in, self.G(Ln + "attention.self.query.weight"), M, 3 * H, H, ws, beta,
+                         bias=self.G(Ln + "attention.self.query.bias"))     # packed [3H, H] gradient
+                self._bucket_done(NL - i)          # the layer's gradient slice is complete in this stream's order
+                if use_side:
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    self._side_done[i & 1] = ev
+            on_side(last_wgrad)
             self._nt(dqkv, s["qkvT"], dx, M, H, 3 * H, residual=dpre)
-            self._bucket_done(NL - i)
+        if use_side:
+            main.wait_stream(side)          # all layer wgrads (and their bucket hand-offs) precede the rest of backward
+        dpre = ws["dpre"]
 
         # ---- embeddings -------------------------------------------------------------------------------------
         K.layernorm_bwd(dx, ws["emb_pre"], self.P(E + "LayerNorm.weight"), ws["stat0"][0], ws["stat0"][1], dpre,
