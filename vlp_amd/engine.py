@@ -17,6 +17,7 @@ PyTorch is used for memory (torch.empty), streams and the autograd hand-off only
 fallback: every compute step is a HIP kernel.
 """
 import math
+import os
 import weakref
 
 import torch
@@ -46,7 +47,10 @@ class Engine(object):
     GEMM_NT_VARIANT = None   # None -> autotune per (M, N, K) on first use among NT_CANDIDATES; or force an int
     NT_CANDIDATES = (1, 2, 4, 5, 9, 10, 11, 12, 13)   # LDS-DMA variants (+8 = XCD-aware tile order); see include/vlp_hip.h
     GEMM_TN_VARIANT = 2      # ds_read_b64_tr_b16 fragment reads + LDS-DMA staging
-    WGRAD_SIDE_STREAM = True # weight-gradient GEMMs of the encoder layers on a second HIP stream, concurrent with the dgrad chain
+    # weight-gradient GEMMs of the encoder layers on a second HIP stream, concurrent with the dgrad chain: +1.5-2 % step
+    # throughput on one MI355X (4706 vs 4637 samples/s); off by default so that per-kernel timings (bench.py roofline,
+    # rocprofv3) are single-kernel measurements.  VLP_WGRAD_SIDE_STREAM=1 turns it on.
+    WGRAD_SIDE_STREAM = os.environ.get("VLP_WGRAD_SIDE_STREAM", "0") == "1"
     TN_SPLITS = None         # None -> autotune the split-M factor per (M, N, K) among TN_SPLIT_CANDIDATES
     TN_SPLIT_CANDIDATES = (0, 2, 4, 8, 16)
     _nt_choice = {}          # shared across engines of one process: (M, N, K) -> variant
@@ -294,6 +298,7 @@ class Engine(object):
             return v
         best, best_t = self.NT_CANDIDATES[0], float("inf")
         if M * N >= 128 * 128 * 8:          # tiny problems: not worth timing
+            torch.cuda.synchronize()        # nothing else (e.g. side-stream wgrads) may run while candidates are timed
             for rnd in range(2):              # two interleaved rounds, best-of: robust against clock / neighbour noise
                 for cand in self.NT_CANDIDATES:
                     if cand & 7 == 5 and N < 1024:
@@ -456,6 +461,7 @@ class Engine(object):
             return sp
         best, best_t = 0, float("inf")
         if M >= 1024:
+            torch.cuda.synchronize()
             scratch = torch.empty(N, Kd, device=c.device, dtype=torch.float16)   # never time into the live gradient buffer
             if True:
                 for cand in self.TN_SPLIT_CANDIDATES:
