@@ -127,6 +127,22 @@ typedef struct {
 } vlp_attn_fwd_args;
 int vlp_attn_fwd(const vlp_attn_fwd_args* a, void* stream);
 
+/* Inference form of the same kernel for incremental decoding (modeling.py:1189-1253 with BertSelfAttention's history path
+ * :273-277): Lq new query rows per sequence attend to Lk cached + new key/value rows that live in a separate K/V cache
+ * (a TRUE K/V cache: the reference re-projects K and V over the whole history every step).  Row (b, i) of q is at
+ * q + (b*q_rows_per_batch + i)*ld_q (+ 64*head); rows of k / v likewise with kv_rows_per_batch and ld_kv.
+ * mask: bytes [B, Lq, roundup32(Lk)] as produced by vlp_mask_pack on the [B, Lq, Lk] slice of the attention mask.
+ * ctx [B*Lq, heads*64].  No dropout, no statistics. */
+typedef struct {
+    const void* q; int64_t ld_q; int64_t q_rows_per_batch;
+    const void* k; const void* v; int64_t ld_kv; int64_t kv_rows_per_batch;
+    const uint8_t* mask;
+    void* ctx; int64_t ld_ctx;
+    int32_t B, Lq, Lk, heads;
+    float scale;
+} vlp_attn_decode_args;
+int vlp_attn_decode(const vlp_attn_decode_args* a, void* stream);
+
 typedef struct {
     const void* qkv; int64_t ld_qkv;
     const uint8_t* mask;
@@ -194,6 +210,8 @@ typedef struct {
     const void* vis_h; const void* vispe_h;                 /* [B*Nv, H] */
     void* pre;                                              /* [B*L, H] out */
     int32_t B, L, Nv, H, vocab, type_vocab;
+    const int64_t* position_ids;                            /* [B,L] or NULL (= 0..L-1); incremental decoding passes them (:856-865) */
+    int32_t max_pos;                                        /* rows of pos_emb */
 } vlp_embed_fwd_args;
 int vlp_embed_fwd(const vlp_embed_fwd_args* a, void* stream);
 
@@ -240,6 +258,15 @@ int vlp_gather_rows(const void* src, int64_t lds, const int64_t* pos, void* out,
 /* dst[(i / P) * L + pos[i], :] += src[i, :]   (backward of the gather; fp16 packed atomics) */
 int vlp_scatter_add_rows(const void* src, int64_t lds, const int64_t* pos, void* dst, int64_t ldd,
                          int32_t B, int32_t P, int32_t L, int32_t H, void* stream);
+/* Incremental decoding helpers (modeling.py:1189-1253):
+ *   vlp_mask_pack_rect: [B, Lq, Lk] slice of the int64 attention mask (element strides given) -> bytes [B, Lq, roundup32(Lk)];
+ *   vlp_kv_append: cache[b, start + i, 0:2H] = qkv_new[b*T + i, H:3H]  (K | V of the new tokens into the K/V cache [B, Lcap, 2H]);
+ *   vlp_argmax_rows: ids[r*ids_stride] = argmax_v logits[r, v] (first maximum), vals[r*vals_stride] = max  (greedy token choice :1228). */
+int vlp_mask_pack_rect(const int64_t* mask, int64_t batch_stride, int64_t row_stride, uint8_t* out, int32_t B, int32_t Lq, int32_t Lk,
+                       int32_t Lkp, void* stream);
+int vlp_kv_append(const void* qkv_new, int64_t ld, void* cache, int32_t Lcap, int32_t B, int32_t T, int32_t start, int32_t H, void* stream);
+int vlp_argmax_rows(const void* logits, int64_t ld, int32_t rows, int32_t V, int64_t* ids, int64_t ids_stride, float* vals, int64_t vals_stride,
+                    void* stream);
 /* VQA fusion (modeling.py:1044,1138): out[b,:] = h[b,0,:] * h[b,Nv+1,:]; backward adds into dh rows. */
 int vlp_vqa_mul_fwd(const void* h, void* out, int32_t B, int32_t L, int32_t Nv, int32_t H, void* stream);
 int vlp_vqa_mul_bwd(const void* h, const void* dout, void* dh, int32_t B, int32_t L, int32_t Nv, int32_t H, void* stream);

@@ -37,6 +37,12 @@ CASES = {
                          dict(batch_size=2, max_len_b=64, vocab_size=2048, max_pred=3, s2s_prob=0.75, seed=104)),
 }
 
+# greedy decoding cases (BertForSeq2SeqDecoder, modeling.py:1189-1253): (model kwargs, B, T, input seed)
+DECODE_CASES = {
+    "decode_2l_T12": (dict(vocab_size=1024, layers=2, tasks="img2txt", seed=21, std=0.05), 3, 12, 204),
+    "decode_12l_T20": (dict(vocab_size=2048, layers=12, tasks="img2txt", seed=22, std=0.04), 2, 20, 202),
+}
+
 GRAD_SAMPLES = [
     "bert.embeddings.word_embeddings.weight", "bert.embeddings.position_embeddings.weight",
     "bert.embeddings.token_type_embeddings.weight", "bert.embeddings.LayerNorm.weight",
@@ -121,9 +127,58 @@ def run_reference_case(mk, bk):
     return out
 
 
+def decode_inputs(B, T, seed, Nv=100):
+    """Seeded inputs of a greedy decoding call, shaped like seq2seq_loader.Preprocess4Seq2seqDecoder's output
+    (seq2seq_loader.py:383-486): [CLS] + Nv placeholders + [SEP] as input_ids, segment 4 | 5, causal mask on the target part."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(B, Nv, 2048, generator=g).abs()
+    vis_pe = torch.rand(B, Nv, 1607, generator=g)
+    in_len, out_len = Nv + 2, Nv + 2 + T
+    input_ids = torch.tensor([[S.CLS_ID] + [S.UNK_ID] * Nv + [S.SEP_ID]] * B)
+    token_type = torch.tensor([[4] * in_len + [5] * T] * B)
+    pos = torch.arange(out_len).unsqueeze(0).expand(B, -1).contiguous()
+    am = torch.zeros(B, out_len, out_len, dtype=torch.long)
+    am[:, :, :in_len] = 1
+    am[:, in_len:, in_len:] = torch.tril(torch.ones(T, T, dtype=torch.long))
+    return img, vis_pe, input_ids, token_type, pos, am
+
+
+def decode_fingerprint(p, inp):
+    keys = sorted(p.keys())
+    fp = [float(p[k].double().abs().sum()) for k in keys[:8]]
+    fp += [float(inp[0].double().sum()), float(inp[1].double().sum())]
+    return np.asarray(fp, dtype=np.float64)
+
+
+def run_reference_decode_case(mk, B, T, seed):
+    p = O.init_params(vocab_size=mk["vocab_size"], layers=mk["layers"], tasks=mk["tasks"], seed=mk["seed"], std=mk["std"])
+    dec = ref_loader.build_reference_model(dict(vocab_size=mk["vocab_size"], num_hidden_layers=mk["layers"]), seed=0, decoder=True,
+                                           mask_word_id=S.MASK_ID, eos_id=S.SEP_ID)
+    sd = dict(p)
+    sd["cls.predictions.decoder.weight"] = p["bert.embeddings.word_embeddings.weight"]
+    missing, unexpected = dec.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    dec.eval()
+    inp = decode_inputs(B, T, seed)
+    top2 = []
+    dec.cls.predictions.register_forward_hook(lambda m, i, o: top2.append(torch.topk(o.detach()[:, -1, :], 2, dim=-1).values))
+    with torch.no_grad():
+        ids, probs = dec(*inp, task_idx=None, sample_mode="greedy")
+    t2 = torch.stack(top2, dim=1)                               # [B, T, 2]
+    return {"fingerprint": decode_fingerprint(p, inp), "ids": ids.numpy(), "probs": probs.float().numpy(),
+            "margin": (t2[..., 0] - t2[..., 1]).float().numpy()}
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(GOLDEN_DIR, exist_ok=True)
+    for name, (mk, B, T, seed) in DECODE_CASES.items():
+        out = run_reference_decode_case(mk, B, T, seed)
+        path = os.path.join(GOLDEN_DIR, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("%s: ids[0]=%s min margin=%.4f -> %s" % (name, out["ids"][0], out["margin"].min(), path))
+    if "--decode-only" in sys.argv:
+        return
     for name, (mk, bk) in CASES.items():
         out = run_reference_case(mk, bk)
         path = os.path.join(GOLDEN_DIR, name + ".npz")

@@ -69,7 +69,13 @@ class LayerNormBwdArgs(C.Structure):
 class EmbedFwdArgs(C.Structure):
     _fields_ = [("input_ids", vp), ("segment_ids", vp), ("word_emb", vp), ("pos_emb", vp), ("type_emb", vp),
                 ("vis_h", vp), ("vispe_h", vp), ("pre", vp),
-                ("B", i32), ("L", i32), ("Nv", i32), ("H", i32), ("vocab", i32), ("type_vocab", i32)]
+                ("B", i32), ("L", i32), ("Nv", i32), ("H", i32), ("vocab", i32), ("type_vocab", i32),
+                ("position_ids", vp), ("max_pos", i32)]
+
+
+class AttnDecodeArgs(C.Structure):
+    _fields_ = [("q", vp), ("ld_q", i64), ("q_rows_per_batch", i64), ("k", vp), ("v", vp), ("ld_kv", i64), ("kv_rows_per_batch", i64),
+                ("mask", vp), ("ctx", vp), ("ld_ctx", i64), ("B", i32), ("Lq", i32), ("Lk", i32), ("heads", i32), ("scale", f32)]
 
 
 class EmbedBwdArgs(C.Structure):
@@ -116,6 +122,10 @@ SYMBOLS = {
     "vlp_colsum": (C.c_int, [C.POINTER(ColsumArgs), vp]),
     "vlp_attn_fwd": (C.c_int, [C.POINTER(AttnFwdArgs), vp]),
     "vlp_attn_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), vp]),
+    "vlp_attn_decode": (C.c_int, [C.POINTER(AttnDecodeArgs), vp]),
+    "vlp_mask_pack_rect": (C.c_int, [vp, i64, i64, vp, i32, i32, i32, i32, vp]),
+    "vlp_kv_append": (C.c_int, [vp, i64, vp, i32, i32, i32, i32, i32, vp]),
+    "vlp_argmax_rows": (C.c_int, [vp, i64, i32, i32, vp, i64, vp, i64, vp]),
     "vlp_mask_pack": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
     "vlp_layernorm_fwd": (C.c_int, [C.POINTER(LayerNormFwdArgs), vp]),
     "vlp_layernorm_bwd_workspace_bytes": (i64, [i32]),
@@ -236,6 +246,30 @@ def attn_bwd(qkv, mask, mask_t, ctx, dctx, lse, dqkv, delta, B, L, heads, scale,
     _check(load().vlp_attn_bwd(C.byref(a), stream_ptr()))
 
 
+def attn_decode(q, ld_q, q_rows, k, v, ld_kv, kv_rows, mask, ctx, B, Lq, Lk, heads, scale):
+    _req_cuda(q, k, v, mask, ctx)
+    a = AttnDecodeArgs(ptr(q), ld_q, q_rows, ptr(k), ptr(v), ld_kv, kv_rows, ptr(mask), ptr(ctx), ctx.stride(0), B, Lq, Lk, heads, scale)
+    _check(load().vlp_attn_decode(C.byref(a), stream_ptr()))
+
+
+def mask_pack_rect(mask_view, out_u8, B, Lq, Lk, Lkp):
+    """mask_view: int64 tensor view [B, Lq, Lk] with unit column stride (any batch / row strides)."""
+    _req_cuda(mask_view, out_u8)
+    assert mask_view.stride(2) == 1 and mask_view.dtype == torch.int64
+    _check(load().vlp_mask_pack_rect(ptr(mask_view), mask_view.stride(0), mask_view.stride(1), ptr(out_u8), B, Lq, Lk, Lkp, stream_ptr()))
+
+
+def kv_append(qkv_new, ld, cache, Lcap, B, T, start, H):
+    _req_cuda(qkv_new, cache)
+    _check(load().vlp_kv_append(ptr(qkv_new), ld, ptr(cache), Lcap, B, T, start, H, stream_ptr()))
+
+
+def argmax_rows(logits, ld, rows, V, ids, vals):
+    """ids / vals: 1-D (possibly strided) views with `rows` elements."""
+    _req_cuda(logits, ids, vals)
+    _check(load().vlp_argmax_rows(ptr(logits), ld, rows, V, ptr(ids), ids.stride(0), ptr(vals), vals.stride(0), stream_ptr()))
+
+
 def mask_pack(mask_i64, out_u8, B, L, Lp, out_t=None):
     _req_cuda(mask_i64, out_u8, out_t)
     _check(load().vlp_mask_pack(ptr(mask_i64), ptr(out_u8), ptr(out_t), B, L, Lp, stream_ptr()))
@@ -262,10 +296,10 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M, H, workspace, 
     _check(load().vlp_layernorm_bwd(C.byref(a), stream_ptr()))
 
 
-def embed_fwd(input_ids, segment_ids, word_emb, pos_emb, type_emb, vis_h, vispe_h, pre, B, L, Nv, H):
-    _req_cuda(input_ids, segment_ids, word_emb, pos_emb, type_emb, pre)
+def embed_fwd(input_ids, segment_ids, word_emb, pos_emb, type_emb, vis_h, vispe_h, pre, B, L, Nv, H, position_ids=None):
+    _req_cuda(input_ids, segment_ids, word_emb, pos_emb, type_emb, pre, position_ids)
     a = EmbedFwdArgs(ptr(input_ids), ptr(segment_ids), ptr(word_emb), ptr(pos_emb), ptr(type_emb), ptr(vis_h), ptr(vispe_h),
-                     ptr(pre), B, L, Nv, H, word_emb.shape[0], type_emb.shape[0])
+                     ptr(pre), B, L, Nv, H, word_emb.shape[0], type_emb.shape[0], ptr(position_ids), pos_emb.shape[0])
     _check(load().vlp_embed_fwd(C.byref(a), stream_ptr()))
 
 

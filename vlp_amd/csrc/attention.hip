@@ -38,6 +38,11 @@ struct AttnParams {
     int B, L, Lp, heads, H;
     float scale;
     DropCtx drop;
+    // forward only: queries and keys/values may come from different buffers / lengths (incremental decoding).  Training is
+    // the special case Lq = Lk = L with q | k | v interleaved in one packed buffer.
+    const f16* q; int64_t ld_q; int64_t bs_q;      // row (b, i) at q + (b*bs_q + i)*ld_q   (+ h*64)
+    const f16* k; const f16* v; int64_t ld_kv; int64_t bs_kv;
+    int Lq, Lk;
 };
 
 // ---- LDS staging helpers ---------------------------------------------------------------------
@@ -90,22 +95,23 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(AttnParams p) 
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
     const int b = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
-    const int L = p.L;
-    const f16* qbase = p.qkv + (int64_t)b * L * p.ld_qkv + h * HD;
-    const f16* kbase = qbase + p.H;
-    const f16* vbase = qbase + 2 * p.H;
+    const int L = p.Lk;                        // keys (rows >= Lk of the LDS tiles are zero, mask bytes there are 2)
+    const int Lq = p.Lq;
+    const f16* qbase = p.q + (int64_t)b * p.bs_q * p.ld_q + h * HD;
+    const f16* kbase = p.k + (int64_t)b * p.bs_kv * p.ld_kv + h * HD;
+    const f16* vbase = p.v + (int64_t)b * p.bs_kv * p.ld_kv + h * HD;
 
-    stage_rowmajor(Ks, kbase, p.ld_qkv, L, LP, tid);
-    stage_rowmajor(Vs, vbase, p.ld_qkv, L, LP, tid);
+    stage_rowmajor(Ks, kbase, p.ld_kv, L, LP, tid);
+    stage_rowmajor(Vs, vbase, p.ld_kv, L, LP, tid);
     __syncthreads();
 
-    const int nqt = (L + 15) / 16;
+    const int nqt = (Lq + 15) / 16;
     for (int qt = wid; qt < nqt; qt += ATT_WAVES) {
         const int q = qt * 16 + li;             // this lane's query (column of every transposed tile)
-        const int qc = min(q, L - 1);
+        const int qc = min(q, Lq - 1);
         int gq = g;                             // opaque copy: keeps per-key index math inside the loop (no LICM + spills)
         asm volatile("" : "+v"(gq));
-        const f16* qrow = qbase + (int64_t)qc * p.ld_qkv;
+        const f16* qrow = qbase + (int64_t)qc * p.ld_q;
         f16x8 qf[2];
         qf[0] = ld8(qrow + g * 8);
         qf[1] = ld8(qrow + 32 + g * 8);
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(AttnParams p) 
                 s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], s[t], 0, 0, 0);
             }
         }
-        const uint8_t* mrow = p.mask + ((int64_t)b * L + qc) * p.Lp;
+        const uint8_t* mrow = p.mask + ((int64_t)b * Lq + qc) * p.Lp;
         float mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -147,12 +153,12 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(AttnParams p) 
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.f / sum;
-        if (g == 0 && q < L) p.lse[((int64_t)b * p.heads + h) * L + q] = mx + __logf(sum);
+        if (p.lse && g == 0 && q < Lq) p.lse[((int64_t)b * p.heads + h) * Lq + q] = mx + __logf(sum);
 
         // P^T (normalised, dropout applied) as fp16 B-operand fragments: pair u = tiles (2u, 2u+1)
         f16x8 pf[NT / 2];
         // dropout element = (row (b, h, q), col key)
-        const uint32_t rk = p.drop.thresh ? drop_rowkey(p.drop, ((uint64_t)b * p.heads + h) * (uint64_t)L + (uint64_t)qc) : 0u;
+        const uint32_t rk = p.drop.thresh ? drop_rowkey(p.drop, ((uint64_t)b * p.heads + h) * (uint64_t)Lq + (uint64_t)qc) : 0u;
 #pragma unroll
         for (int u = 0; u < NT / 2; ++u)
 #pragma unroll
@@ -170,9 +176,9 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(AttnParams p) 
 #pragma unroll
             for (int u = 0; u < NT / 2; ++u)
                 o = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(Vs, 32 * u, 32 * u + 16, 16 * n, g, li), pf[u], o, 0, 0, 0);
-            if (q < L) {
+            if (q < Lq) {
                 f16x4 ov = (f16x4){(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
-                st4(p.ctx + ((int64_t)b * L + q) * p.ld_ctx + h * HD + n * 16 + 4 * g, ov);
+                st4(p.ctx + ((int64_t)b * Lq + q) * p.ld_ctx + h * HD + n * 16 + 4 * g, ov);
             }
         }
     }
@@ -387,32 +393,57 @@ static int attn_common_check(const char* who, const void* qkv, int64_t ld_qkv, c
 
 static inline int lp_of(int L) { return L <= 64 ? 64 : (L <= 128 ? 128 : (L <= 192 ? 192 : 256)); }
 
-extern "C" int vlp_attn_fwd(const vlp_attn_fwd_args* a, void* stream) {
-    VLP_CHECK_ARG(a != nullptr, "vlp_attn_fwd: null args");
-    int rc = attn_common_check("vlp_attn_fwd", a->qkv, a->ld_qkv, a->mask, a->B, a->L, a->heads);
-    if (rc) return rc;
-    VLP_CHECK_ARG(a->ctx && a->lse && a->ld_ctx % 4 == 0 && (uintptr_t)a->ctx % 8 == 0, "vlp_attn_fwd: ctx/lse");
-    AttnParams p = {};
-    p.qkv = (const f16*)a->qkv; p.ld_qkv = a->ld_qkv; p.mask = a->mask;
-    p.ctx = (f16*)a->ctx; p.ld_ctx = a->ld_ctx; p.lse = a->lse;
-    p.B = a->B; p.L = a->L; p.heads = a->heads; p.H = a->heads * HD;
-    p.Lp = (a->L + 31) / 32 * 32;
-    p.scale = a->scale;
-    p.drop = make_drop(a->dropout_p, a->seed, a->rng_stream);
-    const int LP = lp_of(a->L);
+static int launch_attn_fwd(AttnParams& p, hipStream_t s) {
+    const int LP = lp_of(p.Lk);
     const size_t smem = (size_t)2 * LP * HD * 2;
-    dim3 grid(a->B * a->heads), block(ATT_THREADS);
-    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(p.B * p.heads), block(ATT_THREADS);
 #define LAUNCH_FWD(NT_)                                                                                              \
     do {                                                                                                             \
         static bool attr = false;                                                                                    \
-        if (!attr) { hipFuncSetAttribute((const void*)attn_fwd_kernel<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; } \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; } \
         hipLaunchKernelGGL(attn_fwd_kernel<NT_>, grid, block, smem, s, p);                                           \
     } while (0)
     if (LP == 64) LAUNCH_FWD(4); else if (LP == 128) LAUNCH_FWD(8); else if (LP == 192) LAUNCH_FWD(12); else LAUNCH_FWD(16);
 #undef LAUNCH_FWD
     VLP_CHECK_LAUNCH("vlp_attn_fwd");
     return VLP_OK;
+}
+
+extern "C" int vlp_attn_fwd(const vlp_attn_fwd_args* a, void* stream) {
+    VLP_CHECK_ARG(a != nullptr, "vlp_attn_fwd: null args");
+    int rc = attn_common_check("vlp_attn_fwd", a->qkv, a->ld_qkv, a->mask, a->B, a->L, a->heads);
+    if (rc) return rc;
+    VLP_CHECK_ARG(a->ctx && a->lse && a->ld_ctx % 4 == 0 && (uintptr_t)a->ctx % 8 == 0, "vlp_attn_fwd: ctx/lse");
+    AttnParams p = {};
+    p.mask = a->mask;
+    p.ctx = (f16*)a->ctx; p.ld_ctx = a->ld_ctx; p.lse = a->lse;
+    p.B = a->B; p.L = a->L; p.heads = a->heads; p.H = a->heads * HD;
+    p.Lp = (a->L + 31) / 32 * 32;
+    p.scale = a->scale;
+    p.drop = make_drop(a->dropout_p, a->seed, a->rng_stream);
+    p.q = (const f16*)a->qkv; p.k = p.q + p.H; p.v = p.q + 2 * p.H;
+    p.ld_q = p.ld_kv = a->ld_qkv; p.bs_q = p.bs_kv = a->L; p.Lq = p.Lk = a->L;
+    return launch_attn_fwd(p, (hipStream_t)stream);
+}
+
+extern "C" int vlp_attn_decode(const vlp_attn_decode_args* a, void* stream) {
+    VLP_CHECK_ARG(a != nullptr && a->q && a->k && a->v && a->mask && a->ctx, "vlp_attn_decode: null operand");
+    VLP_CHECK_ARG(a->B > 0 && a->heads > 0 && a->Lq > 0 && a->Lk > 0 && a->Lk <= 256, "vlp_attn_decode: bad shape (Lk <= 256)");
+    VLP_CHECK_ARG(a->ld_q % 8 == 0 && a->ld_kv % 8 == 0 && a->ld_ctx % 4 == 0, "vlp_attn_decode: leading dims");
+    VLP_CHECK_ARG(((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) % 16 == 0 && (uintptr_t)a->ctx % 8 == 0 && (uintptr_t)a->mask % 4 == 0,
+                  "vlp_attn_decode: alignment");
+    VLP_CHECK_ARG(a->kv_rows_per_batch >= a->Lk && a->q_rows_per_batch >= a->Lq, "vlp_attn_decode: batch strides");
+    AttnParams p = {};
+    p.mask = a->mask;
+    p.ctx = (f16*)a->ctx; p.ld_ctx = a->ld_ctx; p.lse = nullptr;
+    p.B = a->B; p.L = a->Lk; p.heads = a->heads; p.H = a->heads * HD;
+    p.Lp = (a->Lk + 31) / 32 * 32;
+    p.scale = a->scale;
+    p.drop = make_drop(0.f, 0, 0);
+    p.q = (const f16*)a->q; p.ld_q = a->ld_q; p.bs_q = a->q_rows_per_batch;
+    p.k = (const f16*)a->k; p.v = (const f16*)a->v; p.ld_kv = a->ld_kv; p.bs_kv = a->kv_rows_per_batch;
+    p.Lq = a->Lq; p.Lk = a->Lk;
+    return launch_attn_fwd(p, (hipStream_t)stream);
 }
 
 extern "C" int vlp_attn_bwd(const vlp_attn_bwd_args* a, void* stream) {
@@ -480,5 +511,27 @@ extern "C" int vlp_mask_pack(const int64_t* mask, uint8_t* out, uint8_t* out_t, 
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(mask_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mask, out, out_t, L, Lp, B);
     VLP_CHECK_LAUNCH("vlp_mask_pack");
+    return VLP_OK;
+}
+
+// rectangular slice [B, Lq, Lk] of an int64 mask given by strides (elements) -> uint8 [B, Lq, Lkp], columns >= Lk hold 2
+__global__ void mask_pack_rect_kernel(const int64_t* mask, int64_t bs, int64_t rs, uint8_t* out, int B, int Lq, int Lk, int Lkp) {
+    const int64_t total = (int64_t)B * Lq * Lkp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Lkp);
+        const int64_t r = i / Lkp;
+        const int q = (int)(r % Lq);
+        const int64_t b = r / Lq;
+        out[i] = c < Lk ? (mask[b * bs + q * rs + c] != 0 ? 1 : 0) : 2;
+    }
+}
+extern "C" int vlp_mask_pack_rect(const int64_t* mask, int64_t batch_stride, int64_t row_stride, uint8_t* out, int32_t B, int32_t Lq, int32_t Lk,
+                                  int32_t Lkp, void* stream) {
+    VLP_CHECK_ARG(mask && out && B > 0 && Lq > 0 && Lk > 0 && Lkp == (Lk + 31) / 32 * 32, "vlp_mask_pack_rect: bad args");
+    const int64_t total = (int64_t)B * Lq * Lkp;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(mask_pack_rect_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mask, batch_stride, row_stride, out, B, Lq, Lk, Lkp);
+    VLP_CHECK_LAUNCH("vlp_mask_pack_rect");
     return VLP_OK;
 }

@@ -28,7 +28,9 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(vlp_embed_fwd_args a) {
             int64_t id = a.input_ids[row];
             id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
             w = ld8(word + id * a.H + c * 8);
-            p = ld8(pos + (int64_t)l * a.H + c * 8);
+            int64_t pi = a.position_ids ? a.position_ids[row] : (int64_t)l;
+            pi = pi < 0 ? 0 : (pi >= a.max_pos ? a.max_pos - 1 : pi);
+            p = ld8(pos + pi * a.H + c * 8);
         }
         int64_t sg = a.segment_ids[row];
         sg = sg < 0 ? 0 : (sg >= a.type_vocab ? a.type_vocab - 1 : sg);
@@ -417,5 +419,63 @@ extern "C" int vlp_transpose_batched(const vlp_transpose_desc* descs_dev, const 
     VLP_CHECK_ARG(descs_dev && tile_start_dev && n > 0 && total_tiles > 0, "vlp_transpose_batched: bad args");
     hipLaunchKernelGGL(transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, descs_dev, tile_start_dev, n);
     VLP_CHECK_LAUNCH("vlp_transpose_batched");
+    return VLP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// incremental decoding helpers
+// ---------------------------------------------------------------------------------------------
+// cache[b, start + i, 0:2H] = qkv_new[b*T + i, H:3H]   (k | v of the new tokens go to their positions in the K/V cache)
+__global__ void kv_append_kernel(const f16* qkv, int64_t ld, f16* cache, int Lcap, int B, int T, int start, int H) {
+    const int nch = (2 * H) >> 3;
+    const int64_t total = (int64_t)B * T * nch;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nch);
+        const int64_t r = i / nch;
+        const int t = (int)(r % T);
+        const int64_t b = r / T;
+        st8(cache + ((b * Lcap + start + t) * 2 * (int64_t)H) + c * 8, ld8(qkv + r * ld + H + c * 8));
+    }
+}
+extern "C" int vlp_kv_append(const void* qkv_new, int64_t ld, void* cache, int32_t Lcap, int32_t B, int32_t T, int32_t start, int32_t H, void* stream) {
+    VLP_CHECK_ARG(qkv_new && cache && B > 0 && T > 0 && start >= 0 && start + T <= Lcap && H % 8 == 0 && ld % 8 == 0, "vlp_kv_append: bad args");
+    const int64_t total = (int64_t)B * T * (2 * H / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(kv_append_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)qkv_new, ld, (f16*)cache, Lcap, B, T, start, H);
+    VLP_CHECK_LAUNCH("vlp_kv_append");
+    return VLP_OK;
+}
+
+// ids[r] = argmax_v logits[r, v] (first maximum), vals[r] = that logit   (torch.max(prediction_scores, -1), modeling.py:1228)
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const f16* logits, int64_t ld, int V, int64_t* ids, int64_t ids_stride, float* vals,
+                                                          int64_t vals_stride) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const f16* x = logits + (int64_t)blockIdx.x * ld;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int v = threadIdx.x; v < V; v += 256) {
+        const float f = (float)x[v];
+        if (f > best) { best = f; bi = v; }
+    }
+    sv[threadIdx.x] = best;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const float f = sv[threadIdx.x + o];
+            const int j = si[threadIdx.x + o];
+            if (f > sv[threadIdx.x] || (f == sv[threadIdx.x] && j < si[threadIdx.x])) { sv[threadIdx.x] = f; si[threadIdx.x] = j; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { ids[blockIdx.x * ids_stride] = si[0]; vals[blockIdx.x * vals_stride] = sv[0]; }
+}
+extern "C" int vlp_argmax_rows(const void* logits, int64_t ld, int32_t rows, int32_t V, int64_t* ids, int64_t ids_stride, float* vals,
+                               int64_t vals_stride, void* stream) {
+    VLP_CHECK_ARG(logits && ids && vals && rows > 0 && V > 0 && ld >= V, "vlp_argmax_rows: bad args");
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const f16*)logits, ld, V, ids, ids_stride, vals, vals_stride);
+    VLP_CHECK_LAUNCH("vlp_argmax_rows");
     return VLP_OK;
 }

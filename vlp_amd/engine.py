@@ -450,6 +450,123 @@ class Engine(object):
         return st.ws["layers"][cfg.num_hidden_layers - 1]["x2"].view(st.B, st.L, cfg.hidden_size)
 
     # ------------------------------------------------------------------------------------------
+    # incremental greedy decoding with a K/V cache (modeling.py:1189-1253, :856-875, :386-394)
+    # ------------------------------------------------------------------------------------------
+    def _decode_workspace(self, B, T0, Lcap):
+        key = ("dec", B, T0, Lcap)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        model = self._model()
+        cfg = model.config
+        H, I, NL, Nv, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, model.len_vis_input, cfg.vocab_size
+        M, Mv, dev = B * T0, B * Nv, self.device
+
+        def h(*s):
+            return torch.empty(*s, device=dev, dtype=torch.float16)
+
+        Vp = _ru(V, 64)
+        ws = dict(Vp=Vp, maskb=torch.empty(B * T0 * _ru(Lcap, 32), device=dev, dtype=torch.uint8),
+                  img16=h(Mv, 2048), vpe_in=h(Mv, PE_PAD), wpe_pad=h(H, PE_PAD), h1=h(Mv, 2048), vis_h=h(Mv, H), vispe_h=h(Mv, H),
+                  emb_pre=h(M, H), xa=h(M, H), xb=h(M, H), qkv=h(M, 3 * H), ctx=h(M, H), pre=h(M, H), x1=h(M, H), g=h(M, I),
+                  kv=[h(B, Lcap, 2 * H) for _ in range(NL)],        # per layer: K | V of every position decoded so far
+                  sel=h(B, H), tg=h(B, H), tln=h(B, H), logits=h(B, Vp), last=torch.empty(B, 1, device=dev, dtype=torch.long),
+                  xids=torch.empty(B, 2, device=dev, dtype=torch.long))
+        self._ws[key] = ws
+        return ws
+
+    def decode_greedy(self, vis_feats, vis_pe, input_ids, token_type_ids, position_ids, attention_mask, mask_word_id):
+        """Greedy incremental decoding.  Step s feeds the tokens that are new since step s-1 plus one [MASK] slot, projects them
+        to Q/K/V, appends K|V to the per-layer cache at their absolute positions (the [MASK] slot's entry is overwritten by the
+        real token in the next step, which is exactly what the reference's hidden-state history achieves by dropping the last
+        row, :1236-1247) and attends over the cache.  Returns (ids [B, n] int64, max logits [B, n] f32)."""
+        self.pack()
+        model = self._model()
+        cfg = model.config
+        H, I, A, NL, Nv, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers, model.len_vis_input, cfg.vocab_size
+        B, in_len = input_ids.shape
+        out_len = token_type_ids.shape[1]
+        if H != A * 64:
+            raise RuntimeError("vlp_amd: attention kernels need head_dim == 64 (hidden %d, heads %d)" % (H, A))
+        if vis_feats.shape[1] != Nv or vis_feats.shape[2] != 2048 or vis_pe.shape[2] != PE_DIM:
+            raise RuntimeError("vlp_amd: expected vis_feats [B,%d,2048] and vis_pe [B,%d,%d]" % (Nv, Nv, PE_DIM))
+        if in_len < Nv + 2 or out_len <= in_len or out_len > 256:
+            raise RuntimeError("vlp_amd: decode needs %d <= input length < output length <= 256 (got %d, %d)" % (Nv + 2, in_len, out_len))
+        if attention_mask.dim() != 3 or attention_mask.shape[1] < out_len or attention_mask.shape[2] < out_len:
+            raise RuntimeError("vlp_amd: decode expects a [B, L, L] attention mask covering the output length")
+        n_steps, T0 = out_len - in_len, in_len + 1
+        ws = self._decode_workspace(B, T0, out_len)
+        dev = self.device
+        attention_mask = attention_mask.to(torch.long)
+        if attention_mask.stride(2) != 1:
+            attention_mask = attention_mask.contiguous()
+        token_type_ids, position_ids = token_type_ids.to(torch.long), position_ids.to(torch.long)
+        Mv = B * Nv
+        # ---- region projections, once (:1192-1193) -------------------------------------------------
+        vf = vis_feats.reshape(Mv, 2048)
+        if vf.dtype == torch.float32:
+            K.copy2d(vf.contiguous(), 2048, True, ws["img16"], 2048, Mv, 2048, 2048)
+            img = ws["img16"]
+        else:
+            img = vf.contiguous()
+        vp = vis_pe.reshape(Mv, PE_DIM).contiguous()
+        K.copy2d(vp, PE_DIM, vp.dtype == torch.float32, ws["vpe_in"], PE_PAD, Mv, PE_DIM, PE_PAD)
+        K.copy2d(self.P("vis_pe_embed.0.weight"), PE_DIM, False, ws["wpe_pad"], PE_PAD, H, PE_DIM, PE_PAD)
+        self._nt(img, self.P("vis_embed.0.weight"), ws["h1"], Mv, 2048, 2048, bias=self.P("vis_embed.0.bias"), act=K.ACT_RELU)
+        self._nt(ws["h1"], self.P("vis_embed.2.weight"), ws["vis_h"], Mv, H, 2048, bias=self.P("vis_embed.2.bias"), act=K.ACT_RELU)
+        self._nt(ws["vpe_in"], ws["wpe_pad"], ws["vispe_h"], Mv, H, PE_PAD, bias=self.P("vis_pe_embed.0.bias"), act=K.ACT_RELU)
+
+        out_ids = torch.empty(B, n_steps, device=dev, dtype=torch.long)
+        out_val = torch.empty(B, n_steps, device=dev, dtype=torch.float32)
+        E, C = "bert.embeddings.", "cls.predictions."
+        scale = 1.0 / math.sqrt(H // A)
+        x_first = torch.cat((input_ids.to(torch.long), torch.full((B, 1), int(mask_word_id), device=dev, dtype=torch.long)), dim=1).contiguous()
+        ws["xids"][:, 1] = int(mask_word_id)
+        next_pos = in_len
+        for s in range(n_steps):
+            first = s == 0
+            T = T0 if first else 2
+            st = next_pos + 1 - T
+            Lk = next_pos + 1
+            Lkp = _ru(Lk, 32)
+            M = B * T
+            xids = x_first if first else ws["xids"]
+            tt = token_type_ids[:, st:Lk].contiguous()
+            pid = position_ids[:, st:Lk].contiguous()
+            maskb = ws["maskb"][:B * T * Lkp]
+            K.mask_pack_rect(attention_mask[:, st:Lk, :Lk], maskb, B, T, Lk, Lkp)
+            K.embed_fwd(xids, tt, self.P(E + "word_embeddings.weight"), self.P(E + "position_embeddings.weight"),
+                        self.P(E + "token_type_embeddings.weight"), ws["vis_h"], ws["vispe_h"], ws["emb_pre"], B, T, Nv if first else 0, H,
+                        position_ids=pid)
+            x, alt = ws["xa"], ws["xb"]
+            K.layernorm_fwd(ws["emb_pre"], self.P(E + "LayerNorm.weight"), self.P(E + "LayerNorm.bias"), x, M, H)
+            for i in range(NL):
+                Ln = "bert.encoder.layer.%d." % i
+                kv = ws["kv"][i]
+                self._nt(x, self.P(Ln + "attention.self.query.weight"), ws["qkv"], M, 3 * H, H, bias=self.P(Ln + "attention.self.query.bias"))
+                K.kv_append(ws["qkv"], 3 * H, kv, out_len, B, T, st, H)
+                K.attn_decode(ws["qkv"], 3 * H, T, kv, kv[:, :, H:], 2 * H, out_len, maskb, ws["ctx"], B, T, Lk, A, scale)
+                self._nt(ws["ctx"], self.P(Ln + "attention.output.dense.weight"), ws["pre"], M, H, H, bias=self.P(Ln + "attention.output.dense.bias"),
+                         residual=x)
+                K.layernorm_fwd(ws["pre"], self.P(Ln + "attention.output.LayerNorm.weight"), self.P(Ln + "attention.output.LayerNorm.bias"),
+                                ws["x1"], M, H)
+                self._nt(ws["x1"], self.P(Ln + "intermediate.dense.weight"), ws["g"], M, I, H, bias=self.P(Ln + "intermediate.dense.bias"),
+                         act=K.ACT_GELU)
+                self._nt(ws["g"], self.P(Ln + "output.dense.weight"), ws["pre"], M, H, I, bias=self.P(Ln + "output.dense.bias"), residual=ws["x1"])
+                K.layernorm_fwd(ws["pre"], self.P(Ln + "output.LayerNorm.weight"), self.P(Ln + "output.LayerNorm.bias"), alt, M, H)
+                x, alt = alt, x
+            # ---- LM head on the [MASK] slot (:1226-1228) ------------------------------------------
+            ws["last"].fill_(T - 1)
+            K.gather_rows(x, H, ws["last"], ws["sel"], H, B, 1, T, H)
+            self._nt(ws["sel"], self.P(C + "transform.dense.weight"), ws["tg"], B, H, H, bias=self.P(C + "transform.dense.bias"), act=K.ACT_GELU)
+            K.layernorm_fwd(ws["tg"], self.P(C + "transform.LayerNorm.weight"), self.P(C + "transform.LayerNorm.bias"), ws["tln"], B, H)
+            self._nt(ws["tln"], self.P("bert.embeddings.word_embeddings.weight"), ws["logits"], B, V, H, bias=self.P(C + "bias"), ldy=ws["Vp"])
+            K.argmax_rows(ws["logits"], ws["Vp"], B, V, out_ids[:, s], out_val[:, s])
+            K.argmax_rows(ws["logits"], ws["Vp"], B, V, ws["xids"][:, 0], out_val[:, s])      # next step's first input token
+            next_pos += 1
+        return out_ids, out_val
+
+    # ------------------------------------------------------------------------------------------
     # backward
     # ------------------------------------------------------------------------------------------
     def _tn_splits(self, a, b, c, M, N, Kd, ws):

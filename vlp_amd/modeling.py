@@ -509,9 +509,10 @@ class BertForPreTrainingLossMask(PreTrainedBertModel):
 
 
 class BertForSeq2SeqDecoder(PreTrainedBertModel):
-    """Incremental caption decoder (:1147-1494).  The parameter tree (and therefore checkpoint
-    compatibility with BertForPreTrainingLossMask) is provided; the incremental HIP decode path is the
-    ranked-next row N1 of SURVEY.md section 8(f) and is not built yet."""
+    """Incremental caption decoder (:1147-1494): same parameter tree as BertForPreTrainingLossMask (checkpoint compatible);
+    greedy decoding (:1189-1253) runs on the HIP engine with a per-layer K/V cache (Engine.decode_greedy).  Beam search
+    (:1255-1494) and sample_mode='sample' are not built yet."""
+    tasks = "img2txt"
 
     def __init__(self, config, mask_word_id=0, num_labels=2, search_beam_size=1, length_penalty=1.0, eos_id=0,
                  forbid_duplicate_ngrams=False, forbid_ignore_set=None, ngram_size=3, min_len=0, enable_butd=False, len_vis_input=49,
@@ -524,6 +525,22 @@ class BertForSeq2SeqDecoder(PreTrainedBertModel):
         self.search_beam_size, self.length_penalty, self.eos_id = search_beam_size, length_penalty, eos_id
         self.forbid_duplicate_ngrams, self.forbid_ignore_set, self.ngram_size, self.min_len = forbid_duplicate_ngrams, forbid_ignore_set, ngram_size, min_len
         _region_embedders(self, config, enable_butd, allow_random_fc7)
+        self.__dict__["_engine"] = Engine(self)
+        for prm in self.parameters():
+            prm._vlp_owner = self.__dict__["_engine"]
+
+    @property
+    def engine(self):
+        return self.__dict__["_engine"]
 
     def forward(self, vis_feats, vis_pe, input_ids, token_type_ids, position_ids, attention_mask, task_idx=None, sample_mode="greedy"):
-        raise NotImplementedError("incremental decoding on the HIP path is SURVEY.md section 8(f) row N1 (next); not built in this round")
+        """Returns (output_ids [B, n], output_probs [B, n]) with n = token_type_ids.shape[1] - input_ids.shape[1], as :1253.
+        output_probs are the maximal prediction scores (logits), exactly what the reference returns in greedy mode (:1228)."""
+        if self.search_beam_size > 1:
+            raise NotImplementedError("vlp_amd: beam search (modeling.py:1255-1494) is not built yet; use search_beam_size=1")
+        if sample_mode != "greedy":
+            raise NotImplementedError("vlp_amd: sample_mode=%r is not built; only 'greedy'" % (sample_mode,))
+        if not input_ids.is_cuda:
+            raise RuntimeError("vlp_amd: the decoder runs on the HIP engine only (inputs must be on the GPU); there is no CPU path")
+        with torch.no_grad():
+            return self.engine.decode_greedy(vis_feats, vis_pe, input_ids, token_type_ids, position_ids, attention_mask, self.mask_word_id)
