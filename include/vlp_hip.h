@@ -68,7 +68,10 @@ typedef struct {
     int32_t variant;                     /* 0 = register-staged 128x128 tiles, 1 = LDS-DMA (global_load_lds) double-buffered,
                                             2 = LDS-DMA single buffer (4 workgroups/CU), 3 = LDS-DMA 256x128 tile, 8 waves,
                                             4 = 256x128 single buffer, 5 = 256x256 tile (16 waves, double-buffered);
-                                            +8 = XCD-aware tile order */
+                                            6 / 7 = phased 256x256 / 256x128 kernels (gemm_nt_ph.hip: half-tile LDS-DMA pipeline with
+                                            counted vmcnt, 128x64 / 64x64 wave tiles, two staggered wave groups; need K >= 128;
+                                            +16 = one barrier per phase, compiler-scheduled, +48 = no stagger);
+                                            +8 = XCD-aware tile order.  Every variant computes the same result. */
 } vlp_gemm_nt_args;
 int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream);
 

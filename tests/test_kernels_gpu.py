@@ -81,6 +81,30 @@ def test_gemm_nt_plain(variant, M, N, K, gen):
         assert float(y[:, N:].abs().max()) == 0.0        # padding columns are written as zero
 
 
+@pytest.mark.parametrize("variant", [6, 7, 14, 15, 22, 23, 54])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 768, 768), (77, 1000, 192), (256, 2304, 768), (515, 520, 1664),
+                                   (10688, 768, 3072), (10688, 2304, 768)])
+def test_gemm_nt_phased(variant, M, N, K, gen):
+    """Phased 256-row kernels (gemm_nt_ph.hip): counted-vmcnt LDS-DMA pipeline with two staggered wave groups.  Repeated launches
+    on the same inputs must be bit-identical (a race between DMA and fragment reads would show up as run-to-run differences)."""
+    Kd = K
+    from vlp_amd import _lib as K
+    x, w = h16(M, Kd, gen=gen), h16(N, Kd, scale=0.05, gen=gen)
+    ldy = (N + 7) // 8 * 8
+    ref = x.float() @ w.float().t()
+    first = None
+    for it in range(4):
+        y = torch.full((M, ldy), 7.0, device=DEV, dtype=torch.half)
+        K.gemm_nt(x, w, y, M, N, Kd, variant=variant)
+        assert rel(y[:, :N].float(), ref) < 1.5e-3, "variant %d run %d" % (variant, it)
+        if first is None:
+            first = y.clone()
+        else:
+            assert torch.equal(first, y), "variant %d: run %d differs from run 0" % (variant, it)
+    with pytest.raises(RuntimeError):
+        K.gemm_nt(x[:, :64], w[:, :64], y, M, N, 64, ldx=Kd, ldw=Kd, variant=variant)       # K < 128 is refused, not mis-computed
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_gemm_nt_asymmetric_identity(variant):
     """A = I against an asymmetric B catches swapped row/col in the MFMA C-layout handling."""
@@ -92,7 +116,7 @@ def test_gemm_nt_asymmetric_identity(variant):
     assert torch.equal(y, w.t().contiguous())
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, 6, 7])
 def test_gemm_nt_epilogues(variant, gen):
     M, N, Kd = 200, 384, 256
     x, w = h16(M, Kd, gen=gen), h16(N, Kd, scale=0.06, gen=gen)

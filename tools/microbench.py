@@ -38,13 +38,13 @@ def main():
         return (torch.randn(*s, device=DEV, generator=g) * 0.5).half()
 
     # ---- NT GEMMs
-    for name, (m, n, k) in {"qkv": (M, 3 * H, H), "attn_out": (M, H, H), "ffn1": (M, I, H), "ffn2": (M, H, I),
+    for name, (m, n, k) in {} if '--tn-sweep' in sys.argv else {"qkv": (M, 3 * H, H), "attn_out": (M, H, H), "ffn1": (M, I, H), "ffn2": (M, H, I),
                             "fc7": (B * 100, 2048, 2048), "lm_decoder": (192, 28996, H)}.items():
         x, w = r(m, k), r(n, k)
         ldy = (n + 63) // 64 * 64
         y = torch.empty(m, ldy, device=DEV, dtype=torch.half)
         bias = r(ldy)
-        for var in (1, 2, 4, 5, 9, 11, 12, 13):
+        for var in ((6, 22, 7, 23, 31, 13, 11) if '--ph' in sys.argv else (1, 2, 4, 5, 6, 7, 9, 11, 12, 13, 14, 15)):
             us = timeit(lambda: K.gemm_nt(x, w, y, m, n, k, bias=bias, variant=var))
             res["gemm_nt/%s/v%d" % (name, var)] = {"us": us, "tflops": 2.0 * m * n * k / us / 1e6}
         if name == "ffn1":
@@ -58,13 +58,18 @@ def main():
         a = torch.randn(m, k, device=DEV, dtype=torch.half)
         us = timeit(lambda: torch.matmul(a, w.t()))
         res["torch_matmul/%s" % name] = {"us": us, "tflops": 2.0 * m * n * k / us / 1e6}
+    if '--nt-only' in sys.argv:
+        json.dump(res, open('gpurun_out/microbench_nt.json', 'w'), indent=1)
+        for k, v in res.items():
+            print('%-40s %8.1f us  tflops=%.1f' % (k, v['us'], v['tflops']))
+        return
     # ---- TN GEMMs (wgrad)
     for name, (m, n, k) in {"w_qkv": (M, 3 * H, H), "w_out": (M, H, H), "w_ffn1": (M, I, H), "w_ffn2": (M, H, I)}.items():
         a, b = r(m, n), r(m, k)
         c = torch.empty(n, k, device=DEV, dtype=torch.half)
         ws = torch.empty(K.gemm_tn_workspace_bytes(m, n, k), device=DEV, dtype=torch.uint8)
-        for var in (2, 3, 4, 5):
-            for sp in ((0, 2, 4, 8) if quick else (0, 1, 2, 4, 8)):
+        for var in ((2, 10, 26) if '--tn-sweep' in sys.argv else (2, 3, 4, 5)):
+            for sp in (range(1, 17) if '--tn-sweep' in sys.argv else ((0, 2, 4, 8) if quick else (0, 1, 2, 4, 8))):
                 us = timeit(lambda: K.gemm_tn(a, b, c, m, n, k, workspace=ws, variant=var, splits=sp), iters=10)
                 res["gemm_tn/%s/v%d/s%d" % (name, var, sp)] = {"us": us, "tflops": 2.0 * m * n * k / us / 1e6}
         us = timeit(lambda: torch.matmul(a.t(), b))

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 BUILD = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libvlp_hip.so")
-SOURCES = ["api.cpp", "gemm_nt.hip", "gemm_tn.hip", "attention.hip", "layernorm.hip", "elementwise.hip", "loss.hip", "adam.hip"]
+SOURCES = ["api.cpp", "gemm_nt.hip", "gemm_nt_ph.hip", "gemm_tn.hip", "attention.hip", "layernorm.hip", "elementwise.hip", "loss.hip", "adam.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-Wno-unused-result", "-ffp-contract=fast"]
 
@@ -30,7 +30,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(BUILD, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "vlp_hip.h")]
+    headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + [os.path.join(INCLUDE, "vlp_hip.h")]
     jobs = []
     objs = []
     for src in SOURCES:

@@ -1,0 +1,23 @@
+// Parameter block shared by the NT GEMM kernels (gemm_nt.hip: 2-barrier kernels; gemm_nt_ph.hip: phased 256-row kernels).
+#pragma once
+#include "common.h"
+
+struct GemmNtParams {
+    const f16* X; int64_t ldx;
+    const f16* W; int64_t ldw;
+    f16* Y; int64_t ldy;
+    const f16* bias;
+    const f16* residual; int64_t ldr;
+    f16* preact; int64_t ldp;
+    const f16* mulsrc; int64_t ldm;
+    int M, N, K;
+    int act;       // VLP_ACT_*
+    int mulmode;   // VLP_MUL_*
+    float alpha;
+    DropCtx drop;
+    int tiles_n;
+    int xcd_remap;   // 1: workgroups of one XCD (blockIdx % 8) take a contiguous range of tiles (X-panel reuse in that XCD's L2)
+};
+
+// phased kernels (gemm_nt_ph.hip): bn = 256 or 128 columns per workgroup tile (256 rows); p.xcd_remap honoured
+int vlp_gemm_nt_ph_launch(GemmNtParams& p, int bn, int mode, hipStream_t s);

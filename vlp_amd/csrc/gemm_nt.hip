@@ -18,26 +18,11 @@
 // MFMA block of the current tile), VARIANT 1 = global_load_lds_dwordx4 (LDS-DMA; the swizzle is applied
 // to the per-lane SOURCE address because the LDS destination is lane-linear).
 #include "common.h"
+#include "gemm_nt.h"
 
 #define BM 128
 #define BK 64
 
-struct GemmNtParams {
-    const f16* X; int64_t ldx;
-    const f16* W; int64_t ldw;
-    f16* Y; int64_t ldy;
-    const f16* bias;
-    const f16* residual; int64_t ldr;
-    f16* preact; int64_t ldp;
-    const f16* mulsrc; int64_t ldm;
-    int M, N, K;
-    int act;       // VLP_ACT_*
-    int mulmode;   // VLP_MUL_*
-    float alpha;
-    DropCtx drop;
-    int tiles_n;
-    int xcd_remap;   // 1: workgroups of one XCD (blockIdx % 8) take a contiguous range of tiles (X-panel reuse in that XCD's L2)
-};
 
 DEVFN int swz_x(int r) { return r & 7; }
 DEVFN int swz_w(int r) { return (((r >> 4) & 3) << 1) | ((r >> 1) & 1); }
@@ -308,6 +293,11 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
     } while (0)
     p.xcd_remap = (a->variant & 8) ? 1 : 0;
     switch (a->variant & 7) {
+        case 6: case 7: {
+            const int rc = vlp_gemm_nt_ph_launch(p, (a->variant & 7) == 6 ? 256 : 128, (a->variant >> 4) & 3, s);
+            if (rc != VLP_OK) return rc;
+            break;
+        }
         case 0: LAUNCH_NT(0, 128, 128, 2); break;
         case 2: LAUNCH_NT(2, 128, 128, 1); break;
         case 3: LAUNCH_NT(1, 256, 128, 2); break;

@@ -51,8 +51,12 @@ class Engine(object):
     # throughput on one MI355X (4706 vs 4637 samples/s); off by default so that per-kernel timings (bench.py roofline,
     # rocprofv3) are single-kernel measurements.  VLP_WGRAD_SIDE_STREAM=1 turns it on.
     WGRAD_SIDE_STREAM = os.environ.get("VLP_WGRAD_SIDE_STREAM", "0") == "1"
-    TN_SPLITS = None         # None -> autotune the split-M factor per (M, N, K) among TN_SPLIT_CANDIDATES
-    TN_SPLIT_CANDIDATES = (0, 2, 4, 8, 16)
+    TN_SPLITS = None         # None -> autotune (variant flags, split-M factor) per (M, N, K)
+    # split-M factor: the wgrad outputs are small (36..144 tiles of 128x128) and the contraction long (M = 10 688), so the
+    # workgroup count tiles*splits has to land just under a multiple of the 256 CUs x 2 resident workgroups: 3 (432 workgroups)
+    # beats 4 (576) by 25 % on the FFN wgrads, 14 beats 8 on the 768x768 ones (microbench, profiles/r01_tn_split_sweep.json)
+    TN_SPLIT_CANDIDATES = (0, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16)
+    TN_VARIANT_CANDIDATES = (2, 26)     # 26 = LDS-DMA kernel + XCD-aware tile order + split-major block order
     _nt_choice = {}          # shared across engines of one process: (M, N, K) -> variant
     _tn_choice = {}          # (M, N, K) -> splits
 
@@ -571,36 +575,37 @@ class Engine(object):
     # ------------------------------------------------------------------------------------------
     def _tn_splits(self, a, b, c, M, N, Kd, ws):
         if self.TN_SPLITS is not None:
-            return self.TN_SPLITS
+            return (self.GEMM_TN_VARIANT, self.TN_SPLITS)
         key = (M, N, Kd)
         sp = Engine._tn_choice.get(key)
         if sp is not None:
             return sp
-        best, best_t = 0, float("inf")
+        best, best_t = (self.GEMM_TN_VARIANT, 0), float("inf")
         if M >= 1024:
             torch.cuda.synchronize()
             scratch = torch.empty(N, Kd, device=c.device, dtype=torch.float16)   # never time into the live gradient buffer
-            if True:
-                for cand in self.TN_SPLIT_CANDIDATES:
-                    if cand > 1 and M // cand < 128:
-                        continue
-                    K.gemm_tn(a, b, scratch, M, N, Kd, beta=0, workspace=ws["tn_ws"], variant=self.GEMM_TN_VARIANT, splits=cand)
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(3):
-                        K.gemm_tn(a, b, scratch, M, N, Kd, beta=0, workspace=ws["tn_ws"], variant=self.GEMM_TN_VARIANT, splits=cand)
-                    e1.record()
-                    e1.synchronize()
-                    t = e0.elapsed_time(e1)
-                    if t < best_t:
-                        best, best_t = cand, t
+            for rnd in range(2):
+                for var in self.TN_VARIANT_CANDIDATES:
+                    for cand in self.TN_SPLIT_CANDIDATES:
+                        if cand > 1 and M // cand < 128:
+                            continue
+                        K.gemm_tn(a, b, scratch, M, N, Kd, beta=0, workspace=ws["tn_ws"], variant=var, splits=cand)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(3):
+                            K.gemm_tn(a, b, scratch, M, N, Kd, beta=0, workspace=ws["tn_ws"], variant=var, splits=cand)
+                        e1.record()
+                        e1.synchronize()
+                        t = e0.elapsed_time(e1)
+                        if t < best_t:
+                            best, best_t = (var, cand), t
         Engine._tn_choice[key] = best
         return best
 
     def _tn(self, a, b, c, M, N, Kd, ws, beta, bias=None, **kw):
         """wgrad GEMM; `bias` (the Linear's bias gradient = column sums of dY) is fused into the same launch."""
-        sp = self._tn_splits(a, b, c, M, N, Kd, ws)
-        K.gemm_tn(a, b, c, M, N, Kd, beta=beta, workspace=ws["tn_ws"], variant=self.GEMM_TN_VARIANT, bias_out=bias, splits=sp, **kw)
+        var, sp = self._tn_splits(a, b, c, M, N, Kd, ws)
+        K.gemm_tn(a, b, c, M, N, Kd, beta=beta, workspace=ws["tn_ws"], variant=var, bias_out=bias, splits=sp, **kw)
 
     def _bucket_done(self, idx):
         if self.grad_ready_hook is not None:
