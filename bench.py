@@ -178,9 +178,10 @@ def main():
                     traffic = json.load(open(tf)).get("gemm_nt_bytes_per_launch")
                 except Exception:
                     traffic = None
-            roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<1> (all forward + dgrad GEMMs)", "achieved": round(achieved, 1),
+            roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (all forward + dgrad GEMMs; every %dth launch bracketed by HIP events)" % eng.PROF_EVERY, "achieved": round(achieved, 1),
                     "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "launches_per_step": len(prof) // max(args.steps, 1), "avg_launch_us": round(sum(ms) / len(ms) * 1e3, 2),
+                    "launches_per_step": len(prof) * eng.PROF_EVERY // max(args.steps, 1), "sampled_launches": len(prof),
+                    "avg_launch_us": round(sum(ms) / len(ms) * 1e3, 2),
                     "avg_gflop_per_launch": round(sum(flops) / len(flops) / 1e9, 3),
                     "step_mfma_frac": round((world * args.batch * args.steps / dt) / world * FLOP_PER_SAMPLE / (MFMA_PEAK_TFLOPS * 1e12), 4)}
         out = {"metric": METRIC, "value": round(world * args.batch * args.steps / dt, 2), "unit": "samples/s", "n_gpus": world,

@@ -8,5 +8,6 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o
 echo "prof exit $?"
 cp /tmp/prof/bench_kernel_stats.csv gpurun_out/prof_kernel_stats.csv
 python tools/prof_summary.py /tmp/prof/bench_kernel_trace.csv 0.4 > gpurun_out/prof_steady.txt
+python tools/prof_timeline.py /tmp/prof/bench_kernel_trace.csv > gpurun_out/prof_timeline.txt
 cat gpurun_out/prof_steady.txt
 tail -n 1 gpurun_out/prof_bench.log | cut -c1-400

@@ -57,6 +57,10 @@ class Engine(object):
     # beats 4 (576) by 25 % on the FFN wgrads, 14 beats 8 on the 768x768 ones (microbench, profiles/r01_tn_split_sweep.json)
     TN_SPLIT_CANDIDATES = (0, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16)
     TN_VARIANT_CANDIDATES = (2, 26)     # 26 = LDS-DMA kernel + XCD-aware tile order + split-major block order
+    # bench.py's live roofline: an event pair around a launch costs ~2 x 2.5 us of serialisation (5-6 % of the step when all 103
+    # NT launches of a step are bracketed), so every 8th launch is sampled; 103 is coprime to 8, so successive steps sample
+    # different launch positions and K >= 8 steps cover every launch of the step.
+    PROF_EVERY = 8
     _nt_choice = {}          # shared across engines of one process: (M, N, K) -> variant
     _tn_choice = {}          # (M, N, K) -> splits
 
@@ -71,7 +75,8 @@ class Engine(object):
         self.post_backward_hook = None    # callable() set by the DDP wrapper
         self._ws = {}
         self._shadow = None
-        self.prof = None                  # list -> every NT-GEMM launch is bracketed by HIP events (bench.py roofline)
+        self.prof = None                  # list -> every PROF_EVERY-th NT-GEMM launch is bracketed by HIP events (bench.py roofline)
+        self._prof_ctr = 0
 
     # ------------------------------------------------------------------------------------------
     # parameter packing
@@ -322,7 +327,9 @@ class Engine(object):
 
     def _nt(self, x, w, y, M, N, Kd, **kw):
         v = self._nt_variant(x, w, y, M, N, Kd, kw)
-        if self.prof is None:
+        if self.prof is not None:
+            self._prof_ctr += 1
+        if self.prof is None or self._prof_ctr % self.PROF_EVERY:
             K.gemm_nt(x, w, y, M, N, Kd, variant=v, **kw)
             return
         # events are recorded on torch's current stream == the stream handed to the C ABI
