@@ -270,6 +270,40 @@ int vlp_mask_pack_rect(const int64_t* mask, int64_t batch_stride, int64_t row_st
 int vlp_kv_append(const void* qkv_new, int64_t ld, void* cache, int32_t Lcap, int32_t B, int32_t T, int32_t start, int32_t H, void* stream);
 int vlp_argmax_rows(const void* logits, int64_t ld, int32_t rows, int32_t V, int64_t* ids, int64_t ids_stride, float* vals, int64_t vals_stride,
                     void* stream);
+/* sample_mode == 'sample' (modeling.py:1229-1235): ids[r*ids_stride] ~ Categorical(softmax(logits[r, :V])) drawn by the Gumbel-max trick
+ * on the library's counter-based hash (seed, rng_stream, row, column) -- torch.multinomial's stream cannot be reproduced, the
+ * distribution is the same; logp[r*logp_stride] = log_softmax(logits[r])[ids[r]]. */
+int vlp_sample_rows(const void* logits, int64_t ld, int32_t rows, int32_t V, uint64_t seed, uint32_t rng_stream, int64_t* ids,
+                    int64_t ids_stride, float* logp, int64_t logp_stride, void* stream);
+/* Beam search (modeling.py:1255-1494):
+ *   vlp_logsoftmax_topk: per row log_softmax over V (fp32 from fp16 logits), -10000 added on forbidden words (uint8 [rows, V], may be
+ *       NULL; :1298-1299), the eos column forced to -10000 while the minimum length is not reached (:1300-1301), then the K best
+ *       (value descending, index ascending on ties; :1302) -> out_scores / out_ids [rows, K];
+ *   vlp_beam_select: per sample the K best of the K*K continuations  kk + last_eos * -10000 + last_total  (:1308-1316), their back
+ *       pointers, ids and eos flags; src_rows[b*K+k] = the cache row the beam continues (b in the first step, b*K+ptr later);
+ *       next_ids receives the chosen ids with the given element stride (the decoder's next input column);
+ *   vlp_kv_gather: dst[r, pos, :] = src[idx[r], pos, :] for pos in [lo, hi) -- first_expand / select_beam_items (:1325-1349) applied
+ *       to the K/V caches instead of the reference's hidden-state history. */
+int vlp_logsoftmax_topk(const void* logits, int64_t ld, int32_t rows, int32_t V, int32_t K, const uint8_t* forbid, int32_t eos_id,
+                        int32_t block_eos, float* out_scores, int64_t* out_ids, void* stream);
+typedef struct {
+    const float* kk_scores;   /* [rows, K]  rows = B (first) or B*K */
+    const int64_t* kk_ids;    /* [rows, K] */
+    const float* last_total;  /* [B, K] cumulative scores of the previous frame (NULL when first) */
+    const float* last_eos;    /* [B, K] 1.0 where the previous frame's word was eos (NULL when first) */
+    float* out_scores;        /* [B, K] */
+    int64_t* out_ids;         /* [B, K] */
+    int64_t* out_ptrs;        /* [B, K] */
+    float* out_eos;           /* [B, K] */
+    int64_t* src_rows;        /* [B*K] */
+    int64_t* next_ids;        /* B*K elements, stride next_ids_stride */
+    int64_t next_ids_stride;
+    int32_t B, K, first;
+    int64_t eos_id;
+} vlp_beam_select_args;
+int vlp_beam_select(const vlp_beam_select_args* a, void* stream);
+int vlp_kv_gather(const void* src, int64_t src_rows_per_batch, void* dst, int64_t dst_rows_per_batch, const int64_t* idx, int32_t R, int32_t lo,
+                  int32_t hi, int32_t row_elems, void* stream);
 /* VQA fusion (modeling.py:1044,1138): out[b,:] = h[b,0,:] * h[b,Nv+1,:]; backward adds into dh rows. */
 int vlp_vqa_mul_fwd(const void* h, void* out, int32_t B, int32_t L, int32_t Nv, int32_t H, void* stream);
 int vlp_vqa_mul_bwd(const void* h, const void* dout, void* dh, int32_t B, int32_t L, int32_t Nv, int32_t H, void* stream);

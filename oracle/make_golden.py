@@ -43,6 +43,14 @@ DECODE_CASES = {
     "decode_12l_T20": (dict(vocab_size=2048, layers=12, tasks="img2txt", seed=22, std=0.04), 2, 20, 202),
 }
 
+# beam search cases (BertForSeq2SeqDecoder.beam_search, modeling.py:1255-1494): (model kwargs, B, T, input seed, decoder kwargs)
+BEAM_CASES = {
+    "beam_2l_K3": (dict(vocab_size=1024, layers=2, tasks="img2txt", seed=27, std=0.1), 3, 10, 213,
+                   dict(search_beam_size=3, length_penalty=0.4, min_len=2, forbid_duplicate_ngrams=True, ngram_size=2)),
+    "beam_12l_K5": (dict(vocab_size=2048, layers=12, tasks="img2txt", seed=24, std=0.04), 2, 12, 212,
+                    dict(search_beam_size=5, length_penalty=1.0, min_len=0, forbid_duplicate_ngrams=False, ngram_size=3)),
+}
+
 GRAD_SAMPLES = [
     "bert.embeddings.word_embeddings.weight", "bert.embeddings.position_embeddings.weight",
     "bert.embeddings.token_type_embeddings.weight", "bert.embeddings.LayerNorm.weight",
@@ -169,9 +177,48 @@ def run_reference_decode_case(mk, B, T, seed):
             "margin": (t2[..., 0] - t2[..., 1]).float().numpy()}
 
 
+def run_reference_beam_case(mk, B, T, seed, dk):
+    """The reference is pinned to torch 1.1 (Dockerfile:1): integer torch.div floors there (modeling.py:1314 needs that for the
+    back pointers) and the forbid mask is moved with .cuda() (:1427) -- both are emulated around the unmodified reference call."""
+    p = O.init_params(vocab_size=mk["vocab_size"], layers=mk["layers"], tasks=mk["tasks"], seed=mk["seed"], std=mk["std"])
+    dec = ref_loader.build_reference_model(dict(vocab_size=mk["vocab_size"], num_hidden_layers=mk["layers"]), seed=0, decoder=True,
+                                           mask_word_id=S.MASK_ID, eos_id=S.SEP_ID, **dk)
+    sd = dict(p)
+    sd["cls.predictions.decoder.weight"] = p["bert.embeddings.word_embeddings.weight"]
+    missing, unexpected = dec.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    dec.eval()
+    inp = decode_inputs(B, T, seed)
+    true_div, true_cuda = torch.div, torch.Tensor.cuda
+    torch.div = lambda a, b, **kw: true_div(a, b, **kw) if (torch.is_tensor(a) and a.is_floating_point()) else true_div(a, b, rounding_mode="floor")
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        with torch.no_grad():
+            tr = dec(*inp, task_idx=None)
+    finally:
+        torch.div, torch.Tensor.cuda = true_div, true_cuda
+    with torch.no_grad():
+        mine = O.beam_search(p, *inp, S.MASK_ID, dk["search_beam_size"], S.SEP_ID, length_penalty=dk["length_penalty"], min_len=dk["min_len"],
+                             forbid_duplicate_ngrams=dk["forbid_duplicate_ngrams"], ngram_size=dk["ngram_size"], want_margins=True)
+    out = {"fingerprint": decode_fingerprint(p, inp), "margins": np.asarray(mine["margins"], dtype=np.float64),
+           "logit_scale": np.asarray(mine["logit_scale"], dtype=np.float64)}
+    for k in ("pred_seq", "scores", "wids", "ptrs"):
+        out[k] = tr[k].numpy()
+    pad = O.pad_traces(mine, inp[3].shape[1])
+    assert all(torch.equal(pad[k], tr[k]) for k in ("pred_seq", "wids", "ptrs")), "oracle restatement disagrees with the reference"
+    return out
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(GOLDEN_DIR, exist_ok=True)
+    for name, (mk, B, T, seed, dk) in BEAM_CASES.items():
+        out = run_reference_beam_case(mk, B, T, seed, dk)
+        path = os.path.join(GOLDEN_DIR, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("%s: pred_seq[0]=%s min margin=%.4f -> %s" % (name, out["pred_seq"][0][:12], out["margins"].min(), path))
+    if "--beam-only" in sys.argv:
+        return
     for name, (mk, B, T, seed) in DECODE_CASES.items():
         out = run_reference_decode_case(mk, B, T, seed)
         path = os.path.join(GOLDEN_DIR, name + ".npz")

@@ -271,6 +271,178 @@ def greedy_decode(p, batch_img, batch_vis_pe, input_ids, token_type_ids, positio
     return torch.cat(out_ids, dim=1), torch.cat(out_probs, dim=1)
 
 
+def _incr_step(p, vf, vp, x_ids, tt, pid, am, prev_emb, prev_layers, num_heads, len_vis_input):
+    """One incremental forward (BertModelIncr.forward :856-875 + BertEncoder history path :386-394): returns the new
+    embedding rows, the new hidden rows of every layer and the LM logits of the last ([MASK]) position."""
+    dt = p["bert.embeddings.word_embeddings.weight"].dtype
+    ext = extended_attention_mask(am, dt)
+    emb, _ = embeddings(p, vf, vp, x_ids, tt, len_vis_input, position_ids=pid, vis_input=(prev_layers is None))
+    x, hist, new_layers = emb, prev_emb, []
+    for i in range(num_layers_of(p)):
+        x = bert_layer(p, i, x, ext, num_heads, history=hist)
+        new_layers.append(x)
+        if prev_layers is not None:
+            hist = prev_layers[i]
+    return emb, new_layers, lm_head(p, new_layers[-1][:, -1:, :])
+
+
+def dup_ngram_candidates(seq, n, ignore=None):
+    """modeling.py:1388-1406: words that would complete an n-gram already present in `seq` (sorted)."""
+    if len(seq) < n:
+        return []
+    tail = seq[len(seq) - (n - 1):]
+    if ignore and any(t in ignore for t in tail):
+        return []
+    out = set()
+    for i in range(len(seq) - (n - 1)):
+        if seq[i:i + n - 1] == tail and not (ignore and seq[i + n - 1] in ignore):
+            out.add(seq[i + n - 1])
+    return sorted(out)
+
+
+def beam_backtrack(total_scores, step_ids, step_ptrs, eos_id, length_penalty):
+    """modeling.py:1437-1474 for ONE sample: lists over frames of K-lists.  Picks the best finished hypothesis
+    (ended by eos, or alive in the last valid frame) by score + length_penalty * length and follows the back pointers."""
+    last = len(total_scores) - 1
+    for i, w in enumerate(step_ids):
+        if all(x == eos_id for x in w):
+            last = i
+            break
+    best, fid_b, pos_b = -math.inf, -1, -1
+    for fid in range(last + 1):
+        for i, w in enumerate(step_ids[fid]):
+            if w == eos_id or fid == last:
+                sc = total_scores[fid][i] + length_penalty * (fid + 1)
+                if sc > best:
+                    best, fid_b, pos_b = sc, fid, i
+    if fid_b < 0:
+        return [0]
+    seq = [step_ids[fid_b][pos_b]]
+    for fid in range(fid_b, 0, -1):
+        pos_b = step_ptrs[fid][pos_b]
+        seq.append(step_ids[fid - 1][pos_b])
+    return seq[::-1]
+
+
+def beam_search(p, batch_img, batch_vis_pe, input_ids, token_type_ids, position_ids, attention_mask, mask_word_id,
+                beam_size, eos_id, length_penalty=1.0, min_len=0, forbid_duplicate_ngrams=False, forbid_ignore_set=None,
+                ngram_size=3, num_heads=12, len_vis_input=100, want_margins=False):
+    """modeling.py:1255-1494 (BertForSeq2SeqDecoder.beam_search).  Returns the traces dict with python lists
+    (pred_seq [B][*], scores / wids / ptrs [B][frames][K]); `margins` (optional) holds, per frame and sample, the gap
+    between the K-th kept and the best rejected candidate score -- the test uses it to tell a numerical tie from an error."""
+    dt = p["bert.embeddings.word_embeddings.weight"].dtype
+    vf, vp = vis_embed(p, batch_img.to(dt)), vis_pe_embed(p, batch_vis_pe.to(dt))
+    B, in_len = input_ids.shape
+    out_len = token_type_ids.shape[1]
+    K = beam_size
+    V = p["bert.embeddings.word_embeddings.weight"].shape[0]
+    curr_ids = input_ids
+    mask_ids = torch.full_like(input_ids[:, :1], mask_word_id)
+    prev_emb, prev_layers = None, None
+    tot, wids, ptrs, eos_flags, margins = [], [], [], [], []
+    partial = None
+    forbid = None
+    logit_scale = 0.0
+    next_pos = in_len
+    while next_pos < out_len:
+        st = next_pos - curr_ids.shape[1]
+        x_ids = torch.cat((curr_ids, mask_ids), dim=1)
+        emb, new_layers, logits = _incr_step(p, vf, vp, x_ids, token_type_ids[:, st:next_pos + 1], position_ids[:, st:next_pos + 1],
+                                             attention_mask[:, st:next_pos + 1, :next_pos + 1], prev_emb, prev_layers, num_heads,
+                                             len_vis_input)
+        logp = F.log_softmax(logits, dim=-1)                       # [rows, 1, V]
+        logit_scale = max(logit_scale, float(logits.abs().max()))
+        if forbid is not None:
+            logp = logp + forbid * -10000.0
+        if min_len and (next_pos - in_len + 1 <= min_len):
+            logp[:, :, eos_id] = -10000.0
+        kk_s, kk_i = torch.topk(logp, k=K)                         # [rows, 1, K]
+        first = not tot
+        if first:
+            k_s, k_i = kk_s.reshape(B, K), kk_i.reshape(B, K)
+            bp = torch.zeros(B, K, dtype=torch.long, device=k_i.device)
+            if want_margins:
+                kk1 = torch.topk(logp, k=K + 1)[0].reshape(B, K + 1)
+                margins.append((kk1[:, K - 1] - kk1[:, K]).tolist())
+        else:
+            cand = kk_s + eos_flags[-1].reshape(B * K, 1, 1) * -10000.0 + tot[-1].reshape(B * K, 1, 1)
+            cand = cand.reshape(B, K * K)
+            k_s, sel = torch.topk(cand, k=K)
+            bp = sel // K
+            k_i = torch.gather(kk_i.reshape(B, K * K), 1, sel)
+            if want_margins:
+                # candidates beyond each beam's own top-K can never outrank that beam's K-th, so K*K (+1 per beam) suffices
+                kk1_s = torch.topk(logp, k=K + 1)[0] + eos_flags[-1].reshape(B * K, 1, 1) * -10000.0 + tot[-1].reshape(B * K, 1, 1)
+                allc = torch.sort(kk1_s.reshape(B, K * (K + 1)), dim=1, descending=True)[0]
+                margins.append((allc[:, K - 1] - allc[:, K]).tolist())
+        tot.append(k_s)
+        wids.append(k_i)
+        ptrs.append(bp)
+        eos_flags.append((k_i == eos_id).to(k_s.dtype))
+
+        def expand(x):                                             # first_expand :1325-1332
+            return x.unsqueeze(1).expand(x.shape[0], K, *x.shape[1:]).reshape(x.shape[0] * K, *x.shape[1:])
+
+        def pick(x):                                               # select_beam_items :1334-1349
+            xs = x.reshape(B, K, *x.shape[1:])
+            idx = bp.reshape(B, K, *([1] * (x.dim() - 1))).expand(B, K, *x.shape[1:])
+            return torch.gather(xs, 1, idx).reshape(x.shape)
+
+        if first:
+            prev_emb = expand(emb[:, :-1])
+            prev_layers = [expand(t[:, :-1]) for t in new_layers]
+            token_type_ids, position_ids, attention_mask, mask_ids = (expand(t) for t in (token_type_ids, position_ids, attention_mask,
+                                                                                          mask_ids))
+        else:
+            prev_emb = pick(torch.cat((prev_emb, emb[:, :-1]), dim=1))
+            prev_layers = [pick(torch.cat((a, b[:, :-1]), dim=1)) for a, b in zip(prev_layers, new_layers)]
+        curr_ids = k_i.reshape(B * K, 1)
+
+        if forbid_duplicate_ngrams:                                # :1367-1430
+            w, q = k_i.tolist(), bp.tolist()
+            if first:
+                partial = [[w[b][k]] for b in range(B) for k in range(K)]
+            else:
+                partial = [partial[q[b][k] + b * K] + [w[b][k]] for b in range(B) for k in range(K)]
+            forbid = None
+            if len(partial[0]) >= ngram_size:
+                cands = [dup_ngram_candidates(sq, ngram_size, forbid_ignore_set) for sq in partial]
+                if max(len(c) for c in cands) > 0:
+                    fm = torch.zeros(B * K, 1, V, dtype=logp.dtype, device=logp.device)
+                    for r, c in enumerate(cands):
+                        for wid in c:
+                            fm[r, 0, wid] = 1.0
+                    forbid = fm
+        next_pos += 1
+
+    tot_l = [t.tolist() for t in tot]
+    wid_l = [t.tolist() for t in wids]
+    ptr_l = [t.tolist() for t in ptrs]
+    traces = {"pred_seq": [], "scores": [], "wids": [], "ptrs": []}
+    for b in range(B):
+        sc, ww, pp = [x[b] for x in tot_l], [x[b] for x in wid_l], [x[b] for x in ptr_l]
+        traces["scores"].append(sc)
+        traces["wids"].append(ww)
+        traces["ptrs"].append(pp)
+        traces["pred_seq"].append(beam_backtrack(sc, ww, pp, eos_id, length_penalty))
+    if want_margins:
+        traces["margins"] = [[m[b] for m in margins] for b in range(B)]
+        traces["logit_scale"] = logit_scale
+    return traces
+
+
+def pad_traces(traces, out_len, device=None):
+    """modeling.py:1476-1494: lists -> zero-padded tensors [B, out_len, ...] (what the reference's forward returns)."""
+    out = {}
+    for k in ("pred_seq", "scores", "wids", "ptrs"):
+        ts = [torch.tensor(t, dtype=torch.float if k == "scores" else torch.long) for t in traces[k]]
+        buf = ts[0].new_zeros((len(ts), out_len) + tuple(ts[0].shape[1:]))
+        for i, t in enumerate(ts):
+            buf[i, :t.shape[0]] = t
+        out[k] = buf if device is None else buf.to(device)
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # optimizers
 # ----------------------------------------------------------------------------------------------

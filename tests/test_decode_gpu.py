@@ -198,12 +198,182 @@ def test_greedy_decode_vs_oracle_ragged_mask():
     assert compared >= 0.8 * B * T, (compared, flips)
 
 
-def test_decoder_rejects_unbuilt_modes():
+def test_decoder_rejects_unknown_mode_and_cpu_inputs():
     cfg = BertConfig(512, num_hidden_layers=1, type_vocab_size=6)
-    m = BertForSeq2SeqDecoder(cfg, mask_word_id=S.MASK_ID, enable_butd=True, len_vis_input=100, search_beam_size=2).half().to(DEV)
-    inp = [t.to(DEV) for t in decode_inputs(1, 2, 1)]
+    m = BertForSeq2SeqDecoder(cfg, mask_word_id=S.MASK_ID, enable_butd=True, len_vis_input=100).half().to(DEV)
+    inp = decode_inputs(1, 2, 1)
     with pytest.raises(NotImplementedError):
-        m(*inp)
-    m.search_beam_size = 1
-    with pytest.raises(NotImplementedError):
-        m(*inp, sample_mode="sample")
+        m(*[t.to(DEV) for t in inp], sample_mode="nucleus")
+    with pytest.raises(RuntimeError):
+        m(*inp)                                              # CPU tensors: there is no CPU path
+
+
+def test_sample_rows_distribution_and_logprob():
+    rows, V = 4096, 11
+    Vp = 64
+    base = torch.tensor([2.0, 1.0, 0.0, -1.0, 0.5, 3.0, -2.0, 0.0, 1.5, -0.5, 2.5])
+    logits = torch.zeros(rows, Vp).half()
+    logits[:, :V] = base.half()
+    logits[:, V:] = 50.0
+    logits = logits.to(DEV)
+    ids = torch.zeros(rows, dtype=torch.long, device=DEV)
+    lp = torch.zeros(rows, dtype=torch.float32, device=DEV)
+    K.sample_rows(logits, Vp, rows, V, 1234, 7001, ids, lp)
+    ref_lp = torch.log_softmax(base.half().float(), dim=-1).to(DEV)
+    assert int(ids.max()) < V
+    assert float((lp - ref_lp[ids]).abs().max()) < 1e-5
+    freq = torch.bincount(ids, minlength=V).float() / rows
+    prob = ref_lp.exp()
+    sigma = torch.sqrt(prob * (1 - prob) / rows)
+    assert float(((freq - prob).abs() / sigma).max()) < 5.0, (freq, prob)          # every bin within 5 sigma
+    ids2 = torch.zeros_like(ids)
+    K.sample_rows(logits, Vp, rows, V, 1234, 7001, ids2, lp)
+    assert torch.equal(ids, ids2)                                                  # pure function of (seed, stream, row, column)
+    K.sample_rows(logits, Vp, rows, V, 1235, 7001, ids2, lp)
+    assert not torch.equal(ids, ids2)
+
+
+def test_sample_mode_end_to_end():
+    """sample_mode='sample' (:1229-1235): ids are draws (not comparable to torch.multinomial's stream); the returned values must be
+    the log-probabilities of the drawn ids under the model, checked by teacher-forcing the drawn sequence through the oracle."""
+    mk = dict(vocab_size=1024, layers=2, tasks="img2txt", seed=41, std=0.05)
+    p = O.init_params(vocab_size=mk["vocab_size"], layers=mk["layers"], tasks=mk["tasks"], seed=mk["seed"], std=mk["std"])
+    B, T = 3, 6
+    inp = decode_inputs(B, T, 99)
+    m = build_decoder(p, mk)
+    dv = [t.to(DEV) for t in inp]
+    ids, lps = m(dv[0].half(), dv[1].half(), *dv[2:], sample_mode="sample")
+    assert ids.shape == (B, T) and lps.shape == (B, T) and float(lps.max()) <= 0.0
+    ids_b, _ = m(dv[0].half(), dv[1].half(), *dv[2:], sample_mode="sample")
+    assert not torch.equal(ids, ids_b)                      # a new draw every call
+    # teacher-forced check: full (non-incremental) oracle forward over [prefix, drawn tokens with a [MASK] at the position to predict]
+    pd = {k: v.to(DEV).half().float() for k, v in p.items()}
+    in_len = dv[2].shape[1]
+    vf, vp = O.vis_embed(pd, dv[0].half().float()), O.vis_pe_embed(pd, dv[1].half().float())
+    for s in range(T):
+        x = torch.cat((dv[2], ids[:, :s], torch.full((B, 1), S.MASK_ID, device=DEV, dtype=torch.long)), dim=1)
+        Lk = in_len + s + 1
+        emb, _ = O.embeddings(pd, vf, vp, x, dv[3][:, :Lk], 100, position_ids=dv[4][:, :Lk])
+        hs = O.encoder(pd, emb, O.extended_attention_mask(dv[5][:, :Lk, :Lk], torch.float32), 12)
+        logp = torch.log_softmax(O.lm_head(pd, hs[-1][:, -1:, :])[:, 0], dim=-1)
+        ref = torch.gather(logp, 1, ids[:, s:s + 1])[:, 0]
+        assert float((ref - lps[:, s]).abs().max()) < 3e-2, (s, ref, lps[:, s])
+
+
+# ------------------------------------------------------------------------------------------------
+# beam search (modeling.py:1255-1494)
+# ------------------------------------------------------------------------------------------------
+from oracle.make_golden import BEAM_CASES                  # noqa: E402  (pure data)
+
+
+@pytest.mark.parametrize("rows,V,Kb", [(5, 1000, 3), (64, 28996, 5), (2, 50, 50)])
+def test_logsoftmax_topk(rows, V, Kb):
+    Vp = (V + 63) // 64 * 64
+    g = torch.Generator().manual_seed(V + Kb)
+    logits = (torch.randn(rows, Vp, generator=g) * 3).half().to(DEV)
+    logits[:, V:] = 100.0
+    forbid = (torch.rand(rows, V, generator=g) < 0.02).to(torch.uint8).to(DEV)
+    eos = 7
+    for fb, block in ((None, False), (forbid, True)):
+        sc = torch.zeros(rows, Kb, dtype=torch.float32, device=DEV)
+        ids = torch.zeros(rows, Kb, dtype=torch.long, device=DEV)
+        K.logsoftmax_topk(logits, Vp, rows, V, Kb, sc, ids, forbid=fb, eos_id=eos, block_eos=block)
+        ref = torch.log_softmax(logits[:, :V].float(), dim=-1)
+        if fb is not None:
+            ref = ref + fb.float() * -10000.0
+        if block:
+            ref[:, eos] = -10000.0
+        es, ei = torch.topk(ref, Kb, dim=-1)
+        assert float((sc - es).abs().max()) < 2e-4
+        # ids may differ from torch.topk only inside exact ties: compare through the values they select
+        assert float((torch.gather(ref, 1, ids) - es).abs().max()) < 2e-4
+        assert all(len(set(r)) == Kb for r in ids.tolist())
+
+
+def test_beam_select_and_kv_gather():
+    B, Kb, eos = 3, 4, 9
+    g = torch.Generator().manual_seed(5)
+    kk_s = torch.randn(B * Kb, Kb, generator=g).to(DEV)
+    kk_i = torch.randint(0, 30, (B * Kb, Kb), generator=g).to(DEV)
+    last_tot = torch.randn(B, Kb, generator=g).to(DEV)
+    last_eos = (torch.rand(B, Kb, generator=g) < 0.3).float().to(DEV)
+    outs = [torch.zeros(B, Kb, device=DEV, dtype=dt) for dt in (torch.float32, torch.long, torch.long, torch.float32)]
+    src = torch.zeros(B * Kb, dtype=torch.long, device=DEV)
+    nxt = torch.zeros(B * Kb, 2, dtype=torch.long, device=DEV)
+    K.beam_select(kk_s, kk_i, last_tot, last_eos, *outs, src, nxt[:, 0], B, Kb, False, eos)
+    cand = (kk_s.view(B, Kb, Kb) + (last_eos * -10000.0 + last_tot).unsqueeze(-1)).reshape(B, Kb * Kb)
+    es, sel = torch.topk(cand, Kb)
+    assert torch.allclose(outs[0], es) and torch.equal(outs[2], sel // Kb)
+    assert torch.equal(outs[1], torch.gather(kk_i.view(B, Kb * Kb), 1, sel))
+    assert torch.equal(outs[3], (outs[1] == eos).float())
+    assert torch.equal(src, (torch.arange(B, device=DEV).unsqueeze(1) * Kb + outs[2]).reshape(-1))
+    assert torch.equal(nxt[:, 0], outs[1].reshape(-1)) and int(nxt[:, 1].abs().sum()) == 0
+    # first frame: the K candidates of the single row, pointers 0, cache rows = sample index
+    kk_s = torch.sort(kk_s, dim=1, descending=True)[0]          # what vlp_logsoftmax_topk hands over: best first
+    K.beam_select(kk_s, kk_i, None, None, *outs, src, nxt[:, 0], B, Kb, True, eos)
+    assert torch.equal(outs[0], kk_s[:B]) and torch.equal(outs[1], kk_i[:B]) and int(outs[2].abs().sum()) == 0
+    assert torch.equal(src, torch.arange(B, device=DEV).repeat_interleave(Kb))
+    # cache rows follow src
+    R, Lcap, E = B * Kb, 12, 64
+    a = torch.randn(R, Lcap, E, generator=g).half().to(DEV)
+    b = torch.zeros_like(a)
+    idx = torch.randint(0, R, (R,), generator=g).to(DEV)
+    K.kv_gather(a, Lcap, b, Lcap, idx, R, 3, 9, E)
+    exp = torch.zeros_like(a)
+    exp[:, 3:9] = a[idx][:, 3:9]
+    assert torch.equal(b, exp)
+
+
+def compare_beams(tr, g, Kb, n_frames):
+    """Frame by frame per sample: words / back pointers must equal the reference's as long as the reference's own margin between
+    the K-th kept and the best rejected continuation exceeds the fp16 noise; scores within tolerance up to there."""
+    full = 0
+    B = g["wids"].shape[0]
+    for b in range(B):
+        ok_frames = 0
+        for f in range(n_frames):
+            rs, ms = g["scores"][b, f], tr["scores"][b, f].cpu().numpy()
+            same = np.array_equal(g["wids"][b, f], tr["wids"][b, f].cpu().numpy()) and np.array_equal(g["ptrs"][b, f], tr["ptrs"][b, f].cpu().numpy())
+            if not same:
+                # a different ORDER or membership is only acceptable next to a near-tie: either the K-th/K+1-th margin, or two kept
+                # hypotheses closer than the noise
+                kept_gap = np.min(np.abs(np.diff(np.sort(rs)))) if Kb > 1 else np.inf
+                assert min(g["margins"][b, f], kept_gap) < MARGIN_TOL, "sample %d frame %d: beams differ although margins are %g / %g" % (
+                    b, f, g["margins"][b, f], kept_gap)
+                break
+            # cumulative log-probabilities of fp16 logits: every frame may add 2e-3 of the logit magnitude (north-star 1e-3 relative
+            # per evaluation, two evaluations compared; one fp16 ulp of a logit near 16 is already 1.6e-2)
+            tol = 2e-3 * float(g["logit_scale"]) * (f + 1) + 1e-3
+            assert np.max(np.abs(rs - ms)) < tol, "sample %d frame %d scores %s vs %s (tol %g)" % (b, f, ms, rs, tol)
+            ok_frames += 1
+        if ok_frames == n_frames:
+            full += 1
+            L = g["pred_seq"].shape[1]
+            assert np.array_equal(g["pred_seq"][b], tr["pred_seq"][b].cpu().numpy()[:L]), "sample %d: back-tracked sequence differs" % b
+    return full
+
+
+@pytest.mark.parametrize("name", list(BEAM_CASES.keys()))
+def test_beam_search_vs_reference_fixture(name):
+    mk, B, T, seed, dk = BEAM_CASES[name]
+    g = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    p = O.init_params(vocab_size=mk["vocab_size"], layers=mk["layers"], tasks=mk["tasks"], seed=mk["seed"], std=mk["std"])
+    inp = decode_inputs(B, T, seed)
+    if not np.allclose(decode_fingerprint(p, inp), g["fingerprint"], rtol=1e-9, atol=0):
+        pytest.skip("RNG stream differs from the one that generated the fixture")
+    cfg = BertConfig(mk["vocab_size"], num_hidden_layers=mk["layers"], type_vocab_size=6)
+    m = BertForSeq2SeqDecoder(cfg, mask_word_id=S.MASK_ID, eos_id=S.SEP_ID, enable_butd=True, len_vis_input=100, **dk)
+    sd = dict(p)
+    sd["cls.predictions.decoder.weight"] = p["bert.embeddings.word_embeddings.weight"]
+    m.load_state_dict(sd, strict=True)
+    m = m.half().to(DEV).eval()
+    img, vis_pe, input_ids, token_type, pos, am = [t.to(DEV) for t in inp]
+    tr = m(img.half(), vis_pe.half(), input_ids, token_type, pos, am, task_idx=None)
+    Kb, out_len = dk["search_beam_size"], token_type.shape[1]
+    assert tr["pred_seq"].shape == (B, out_len) and tr["scores"].shape == (B, out_len, Kb) and tr["wids"].dtype == torch.long
+    assert tr["scores"].is_cuda
+    full = compare_beams(tr, g, Kb, T)
+    if name == "beam_2l_K3":          # fixture chosen with every margin > 0.03: the whole search must be identical
+        assert full == B
+    tr2 = m(img.half(), vis_pe.half(), input_ids, token_type, pos, am)
+    assert all(torch.equal(tr[k], tr2[k]) for k in tr)

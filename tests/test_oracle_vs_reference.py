@@ -78,6 +78,44 @@ def test_greedy_decode_vs_reference():
     assert float((probs - oprobs).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("forbid,min_len", [(False, 0), (True, 3)])
+def test_beam_search_vs_reference(forbid, min_len, monkeypatch):
+    """BertForSeq2SeqDecoder.beam_search (modeling.py:1255-1494): scores / wids / ptrs of every frame and the back-tracked
+    sequences; with n-gram blocking and a minimum length too (the reference moves its forbid mask with .cuda(): patched to a
+    no-op here, CPU run)."""
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    # the reference is pinned to torch 1.1 (Dockerfile:1), where torch.div on integer tensors is an integer division
+    # (modeling.py:1314 relies on it for the back pointers); torch >= 1.6 returns floats there
+    true_div = torch.div
+    monkeypatch.setattr(torch, "div", lambda a, b, **kw: true_div(a, b, **kw) if (torch.is_tensor(a) and a.is_floating_point())
+                        else true_div(a, b, rounding_mode="floor"))
+    Kb = 3
+    dec = ref_loader.build_reference_model(dict(vocab_size=1024, num_hidden_layers=2), seed=9, decoder=True,
+                                           mask_word_id=S.MASK_ID, eos_id=S.SEP_ID, search_beam_size=Kb, length_penalty=0.3,
+                                           forbid_duplicate_ngrams=forbid, ngram_size=2, min_len=min_len).eval()
+    B, Nv, T = 2, 100, 7
+    g = torch.Generator().manual_seed(1)
+    img = torch.randn(B, Nv, 2048, generator=g).abs()
+    vis_pe = torch.randn(B, Nv, 1607, generator=g)
+    in_len, out_len = Nv + 2, Nv + 2 + T
+    input_ids = torch.tensor([[S.CLS_ID] + [S.UNK_ID] * Nv + [S.SEP_ID]] * B)
+    token_type = torch.tensor([[4] * in_len + [5] * T] * B)
+    pos = torch.arange(out_len).unsqueeze(0).expand(B, -1)
+    am = torch.zeros(B, out_len, out_len, dtype=torch.long)
+    am[:, :, :in_len] = 1
+    am[:, in_len:, in_len:] = torch.tril(torch.ones(T, T, dtype=torch.long))
+    with torch.no_grad():
+        ref_tr = dec(img, vis_pe, input_ids, token_type, pos, am, task_idx=None)
+    p = O.params_from_state_dict(dec.state_dict())
+    with torch.no_grad():
+        tr = O.beam_search(p, img, vis_pe, input_ids, token_type, pos, am, S.MASK_ID, Kb, S.SEP_ID, length_penalty=0.3, min_len=min_len,
+                           forbid_duplicate_ngrams=forbid, ngram_size=2)
+    mine = O.pad_traces(tr, out_len)
+    for k in ("pred_seq", "wids", "ptrs"):
+        assert torch.equal(ref_tr[k], mine[k]), k
+    assert float((ref_tr["scores"] - mine["scores"]).abs().max()) < 1e-3
+
+
 def test_bert_adam_vs_reference():
     ref = ref_loader.load_reference()
     torch.manual_seed(0)

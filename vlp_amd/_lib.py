@@ -78,6 +78,12 @@ class AttnDecodeArgs(C.Structure):
                 ("mask", vp), ("ctx", vp), ("ld_ctx", i64), ("B", i32), ("Lq", i32), ("Lk", i32), ("heads", i32), ("scale", f32)]
 
 
+class BeamSelectArgs(C.Structure):
+    _fields_ = [("kk_scores", vp), ("kk_ids", vp), ("last_total", vp), ("last_eos", vp), ("out_scores", vp), ("out_ids", vp),
+                ("out_ptrs", vp), ("out_eos", vp), ("src_rows", vp), ("next_ids", vp), ("next_ids_stride", i64),
+                ("B", i32), ("K", i32), ("first", i32), ("eos_id", i64)]
+
+
 class EmbedBwdArgs(C.Structure):
     _fields_ = [("dpre", vp), ("input_ids", vp), ("segment_ids", vp), ("vis_h", vp), ("vispe_h", vp),
                 ("d_word_emb", vp), ("d_pos_emb", vp), ("d_type_emb", vp), ("d_vis_h", vp), ("d_vispe_h", vp), ("acc32", vp),
@@ -125,6 +131,10 @@ SYMBOLS = {
     "vlp_attn_decode": (C.c_int, [C.POINTER(AttnDecodeArgs), vp]),
     "vlp_mask_pack_rect": (C.c_int, [vp, i64, i64, vp, i32, i32, i32, i32, vp]),
     "vlp_kv_append": (C.c_int, [vp, i64, vp, i32, i32, i32, i32, i32, vp]),
+    "vlp_logsoftmax_topk": (C.c_int, [vp, i64, i32, i32, i32, vp, i32, i32, vp, vp, vp]),
+    "vlp_beam_select": (C.c_int, [C.POINTER(BeamSelectArgs), vp]),
+    "vlp_kv_gather": (C.c_int, [vp, i64, vp, i64, vp, i32, i32, i32, i32, vp]),
+    "vlp_sample_rows": (C.c_int, [vp, i64, i32, i32, C.c_uint64, C.c_uint32, vp, i64, vp, i64, vp]),
     "vlp_argmax_rows": (C.c_int, [vp, i64, i32, i32, vp, i64, vp, i64, vp]),
     "vlp_mask_pack": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
     "vlp_layernorm_fwd": (C.c_int, [C.POINTER(LayerNormFwdArgs), vp]),
@@ -268,6 +278,31 @@ def argmax_rows(logits, ld, rows, V, ids, vals):
     """ids / vals: 1-D (possibly strided) views with `rows` elements."""
     _req_cuda(logits, ids, vals)
     _check(load().vlp_argmax_rows(ptr(logits), ld, rows, V, ptr(ids), ids.stride(0), ptr(vals), vals.stride(0), stream_ptr()))
+
+
+def logsoftmax_topk(logits, ld, rows, V, K, out_scores, out_ids, forbid=None, eos_id=0, block_eos=False):
+    _req_cuda(logits, out_scores, out_ids, forbid)
+    _check(load().vlp_logsoftmax_topk(ptr(logits), ld, rows, V, K, ptr(forbid), eos_id, 1 if block_eos else 0, ptr(out_scores), ptr(out_ids),
+                                      stream_ptr()))
+
+
+def beam_select(kk_scores, kk_ids, last_total, last_eos, out_scores, out_ids, out_ptrs, out_eos, src_rows, next_ids, B, K, first, eos_id):
+    """next_ids: 1-D (possibly strided) int64 view with B*K elements."""
+    _req_cuda(kk_scores, kk_ids, last_total, last_eos, out_scores, out_ids, out_ptrs, out_eos, src_rows, next_ids)
+    a = BeamSelectArgs(ptr(kk_scores), ptr(kk_ids), ptr(last_total), ptr(last_eos), ptr(out_scores), ptr(out_ids), ptr(out_ptrs), ptr(out_eos),
+                       ptr(src_rows), ptr(next_ids), next_ids.stride(0), B, K, 1 if first else 0, eos_id)
+    _check(load().vlp_beam_select(C.byref(a), stream_ptr()))
+
+
+def kv_gather(src, src_rows, dst, dst_rows, idx, R, lo, hi, row_elems):
+    _req_cuda(src, dst, idx)
+    _check(load().vlp_kv_gather(ptr(src), src_rows, ptr(dst), dst_rows, ptr(idx), R, lo, hi, row_elems, stream_ptr()))
+
+
+def sample_rows(logits, ld, rows, V, seed, rng_stream, ids, logp):
+    """ids / logp: 1-D (possibly strided) views with `rows` elements."""
+    _req_cuda(logits, ids, logp)
+    _check(load().vlp_sample_rows(ptr(logits), ld, rows, V, seed, rng_stream, ptr(ids), ids.stride(0), ptr(logp), logp.stride(0), stream_ptr()))
 
 
 def mask_pack(mask_i64, out_u8, B, L, Lp, out_t=None):

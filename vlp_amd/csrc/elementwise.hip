@@ -479,3 +479,205 @@ extern "C" int vlp_argmax_rows(const void* logits, int64_t ld, int32_t rows, int
     VLP_CHECK_LAUNCH("vlp_argmax_rows");
     return VLP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// beam search helpers (modeling.py:1255-1494)
+// ---------------------------------------------------------------------------------------------
+// per row: log_softmax over V, + (-10000) on forbidden words, eos column forced to -10000 when blocked, then the K best
+// (value descending, index ascending on ties)  -- :1297-1303
+__global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const f16* logits, int64_t ld, int V, int K, const uint8_t* forbid, int eos_id,
+                                                              int block_eos, float* out_scores, int64_t* out_ids) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const f16* x = logits + (int64_t)row * ld;
+    const uint8_t* fb = forbid ? forbid + (int64_t)row * V : nullptr;
+    float mx = -INFINITY;
+    for (int v = tid; v < V; v += 256) mx = fmaxf(mx, (float)x[v]);
+    sv[tid] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) sv[tid] = fmaxf(sv[tid], sv[tid + o]);
+        __syncthreads();
+    }
+    mx = sv[0];
+    __syncthreads();
+    float sum = 0.f;
+    for (int v = tid; v < V; v += 256) sum += __expf((float)x[v] - mx);
+    sv[tid] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) sv[tid] += sv[tid + o];
+        __syncthreads();
+    }
+    const float lse = mx + __logf(sv[0]);
+    __syncthreads();
+    float pv = INFINITY;
+    int pi = -1;
+    for (int k = 0; k < K; ++k) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int v = tid; v < V; v += 256) {
+            float val = (float)x[v] - lse;
+            if (fb && fb[v]) val += -10000.0f;
+            if (block_eos && v == eos_id) val = -10000.0f;
+            const bool after = (val < pv) || (val == pv && v > pi);          // not yet taken
+            if (after && (val > best || (val == best && v < bi))) { best = val; bi = v; }
+        }
+        sv[tid] = best;
+        si[tid] = bi;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) {
+                const float f = sv[tid + o];
+                const int j = si[tid + o];
+                if (f > sv[tid] || (f == sv[tid] && j < si[tid])) { sv[tid] = f; si[tid] = j; }
+            }
+            __syncthreads();
+        }
+        pv = sv[0];
+        pi = si[0];
+        if (tid == 0) { out_scores[(int64_t)row * K + k] = pv; out_ids[(int64_t)row * K + k] = pi; }
+        __syncthreads();
+    }
+}
+extern "C" int vlp_logsoftmax_topk(const void* logits, int64_t ld, int32_t rows, int32_t V, int32_t K, const uint8_t* forbid, int32_t eos_id,
+                                   int32_t block_eos, float* out_scores, int64_t* out_ids, void* stream) {
+    VLP_CHECK_ARG(logits && out_scores && out_ids && rows > 0 && V > 0 && K > 0 && K <= V && ld >= V, "vlp_logsoftmax_topk: bad args");
+    hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const f16*)logits, ld, V, K, forbid, eos_id, block_eos,
+                       out_scores, out_ids);
+    VLP_CHECK_LAUNCH("vlp_logsoftmax_topk");
+    return VLP_OK;
+}
+
+// one workgroup per sample: the K best of the K*K continuations (:1304-1320); first step: the K candidates of the single row
+__global__ void beam_select_kernel(vlp_beam_select_args a) {
+    const int b = blockIdx.x, K = a.K;
+    if (threadIdx.x != 0) return;
+    float pv = INFINITY;
+    int pi = -1;
+    for (int k = 0; k < K; ++k) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        const int ncand = a.first ? K : K * K;
+        for (int i = 0; i < ncand; ++i) {
+            float val;
+            if (a.first) {
+                val = a.kk_scores[(int64_t)b * K + i];
+            } else {
+                const int src = i / K;
+                val = a.kk_scores[((int64_t)b * K + src) * K + (i % K)] + a.last_eos[(int64_t)b * K + src] * -10000.0f + a.last_total[(int64_t)b * K + src];
+            }
+            const bool after = (val < pv) || (val == pv && i > pi);
+            if (after && (val > best || (val == best && i < bi))) { best = val; bi = i; }
+        }
+        pv = best;
+        pi = bi;
+        const int ptr = a.first ? 0 : bi / K;
+        const int64_t id = a.first ? a.kk_ids[(int64_t)b * K + bi] : a.kk_ids[((int64_t)b * K + ptr) * K + (bi % K)];
+        const int64_t o = (int64_t)b * K + k;
+        a.out_scores[o] = best;
+        a.out_ids[o] = id;
+        a.out_ptrs[o] = ptr;
+        a.out_eos[o] = id == a.eos_id ? 1.0f : 0.0f;
+        a.src_rows[o] = a.first ? (int64_t)b : (int64_t)b * K + ptr;
+        a.next_ids[o * a.next_ids_stride] = id;
+    }
+}
+extern "C" int vlp_beam_select(const vlp_beam_select_args* a, void* stream) {
+    VLP_CHECK_ARG(a && a->kk_scores && a->kk_ids && a->out_scores && a->out_ids && a->out_ptrs && a->out_eos && a->src_rows && a->next_ids,
+                  "vlp_beam_select: null operand");
+    VLP_CHECK_ARG(a->B > 0 && a->K > 0 && a->K <= 64 && (a->first || (a->last_total && a->last_eos)), "vlp_beam_select: bad args");
+    hipLaunchKernelGGL(beam_select_kernel, dim3(a->B), dim3(64), 0, (hipStream_t)stream, *a);
+    VLP_CHECK_LAUNCH("vlp_beam_select");
+    return VLP_OK;
+}
+
+// dst[r, pos, :] = src[idx[r], pos, :] for pos in [lo, hi): first_expand / select_beam_items (:1325-1349) on the K/V caches
+__global__ void kv_gather_kernel(const f16* src, int64_t src_rows, f16* dst, int64_t dst_rows, const int64_t* idx, int R, int lo, int hi, int E) {
+    const int nch = E >> 3;
+    const int64_t total = (int64_t)R * (hi - lo) * nch;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nch);
+        const int64_t t = i / nch;
+        const int pos = lo + (int)(t % (hi - lo));
+        const int64_t r = t / (hi - lo);
+        st8(dst + ((r * dst_rows + pos) * E) + c * 8, ld8(src + ((idx[r] * src_rows + pos) * E) + c * 8));
+    }
+}
+extern "C" int vlp_kv_gather(const void* src, int64_t src_rows_per_batch, void* dst, int64_t dst_rows_per_batch, const int64_t* idx, int32_t R,
+                             int32_t lo, int32_t hi, int32_t row_elems, void* stream) {
+    VLP_CHECK_ARG(src && dst && idx && R > 0 && lo >= 0 && hi >= lo && hi <= src_rows_per_batch && hi <= dst_rows_per_batch && row_elems % 8 == 0,
+                  "vlp_kv_gather: bad args");
+    if (hi == lo) return VLP_OK;
+    const int64_t total = (int64_t)R * (hi - lo) * (row_elems / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(kv_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)src, src_rows_per_batch, (f16*)dst,
+                       dst_rows_per_batch, idx, R, lo, hi, row_elems);
+    VLP_CHECK_LAUNCH("vlp_kv_gather");
+    return VLP_OK;
+}
+
+// ids[r] ~ Categorical(softmax(logits[r, :V])) by the Gumbel-max trick on the counter hash (element = (row, v) of stream `stream`), and
+// logp[r] = log_softmax(logits[r])[ids[r]]   (sample_mode == 'sample', modeling.py:1229-1235)
+__global__ __launch_bounds__(256) void sample_rows_kernel(const f16* logits, int64_t ld, int V, DropCtx rng, int64_t* ids, int64_t ids_stride, float* logp,
+                                                          int64_t logp_stride) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const f16* x = logits + (int64_t)row * ld;
+    float mx = -INFINITY;
+    for (int v = tid; v < V; v += 256) mx = fmaxf(mx, (float)x[v]);
+    sv[tid] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) sv[tid] = fmaxf(sv[tid], sv[tid + o]);
+        __syncthreads();
+    }
+    mx = sv[0];
+    __syncthreads();
+    const uint32_t rkey = drop_rowkey(rng, (uint64_t)row);
+    float sum = 0.f, best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int v = tid; v < V; v += 256) {
+        const float l = (float)x[v];
+        sum += __expf(l - mx);
+        const uint32_t h = mix32(rkey + (uint32_t)v * 0x9E3779B9u);
+        const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1)
+        const float gum = -__logf(-__logf(u));
+        const float val = l + gum;
+        if (val > best) { best = val; bi = v; }
+    }
+    sv[tid] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) sv[tid] += sv[tid + o];
+        __syncthreads();
+    }
+    const float lse = mx + __logf(sv[0]);
+    __syncthreads();
+    sv[tid] = best;
+    si[tid] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            const float f = sv[tid + o];
+            const int j = si[tid + o];
+            if (f > sv[tid] || (f == sv[tid] && j < si[tid])) { sv[tid] = f; si[tid] = j; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        ids[row * ids_stride] = si[0];
+        logp[row * logp_stride] = (float)x[si[0]] - lse;
+    }
+}
+extern "C" int vlp_sample_rows(const void* logits, int64_t ld, int32_t rows, int32_t V, uint64_t seed, uint32_t rng_stream, int64_t* ids,
+                               int64_t ids_stride, float* logp, int64_t logp_stride, void* stream) {
+    VLP_CHECK_ARG(logits && ids && logp && rows > 0 && V > 0 && ld >= V, "vlp_sample_rows: bad args");
+    DropCtx rng = make_drop(0.5f, seed, rng_stream);
+    hipLaunchKernelGGL(sample_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const f16*)logits, ld, V, rng, ids, ids_stride, logp, logp_stride);
+    VLP_CHECK_LAUNCH("vlp_sample_rows");
+    return VLP_OK;
+}

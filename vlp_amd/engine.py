@@ -463,38 +463,43 @@ class Engine(object):
     # ------------------------------------------------------------------------------------------
     # incremental greedy decoding with a K/V cache (modeling.py:1189-1253, :856-875, :386-394)
     # ------------------------------------------------------------------------------------------
-    def _decode_workspace(self, B, T0, Lcap):
-        key = ("dec", B, T0, Lcap)
+    def _decode_workspace(self, B, T0, Lcap, K=1):
+        key = ("dec", B, T0, Lcap, K)
         ws = self._ws.get(key)
         if ws is not None:
             return ws
         model = self._model()
         cfg = model.config
         H, I, NL, Nv, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, model.len_vis_input, cfg.vocab_size
-        M, Mv, dev = B * T0, B * Nv, self.device
+        R = B * K                                     # sequences decoded in parallel after the first step
+        M, Mv, dev = max(B * T0, R * 2), B * Nv, self.device
 
         def h(*s):
             return torch.empty(*s, device=dev, dtype=torch.float16)
 
+        def f(*s):
+            return torch.empty(*s, device=dev, dtype=torch.float32)
+
+        def i64(*s):
+            return torch.empty(*s, device=dev, dtype=torch.long)
+
         Vp = _ru(V, 64)
-        ws = dict(Vp=Vp, maskb=torch.empty(B * T0 * _ru(Lcap, 32), device=dev, dtype=torch.uint8),
+        ws = dict(Vp=Vp, maskb=torch.empty(max(B * T0, R * 2) * _ru(Lcap, 32), device=dev, dtype=torch.uint8),
                   img16=h(Mv, 2048), vpe_in=h(Mv, PE_PAD), wpe_pad=h(H, PE_PAD), h1=h(Mv, 2048), vis_h=h(Mv, H), vispe_h=h(Mv, H),
                   emb_pre=h(M, H), xa=h(M, H), xb=h(M, H), qkv=h(M, 3 * H), ctx=h(M, H), pre=h(M, H), x1=h(M, H), g=h(M, I),
                   kv=[h(B, Lcap, 2 * H) for _ in range(NL)],        # per layer: K | V of every position decoded so far
-                  sel=h(B, H), tg=h(B, H), tln=h(B, H), logits=h(B, Vp), last=torch.empty(B, 1, device=dev, dtype=torch.long),
-                  xids=torch.empty(B, 2, device=dev, dtype=torch.long))
+                  sel=h(R, H), tg=h(R, H), tln=h(R, H), logits=h(R, Vp), last=i64(R, 1), xids=i64(R, 2))
+        if K > 1:
+            # beams: two caches per layer (select_beam_items permutes rows: gather from one into the other, then swap)
+            ws.update(kvA=[h(R, Lcap, 2 * H) for _ in range(NL)], kvB=[h(R, Lcap, 2 * H) for _ in range(NL)],
+                      kk_s=f(R, K), kk_i=i64(R, K), src_rows=i64(R))
         self._ws[key] = ws
         return ws
 
-    def decode_greedy(self, vis_feats, vis_pe, input_ids, token_type_ids, position_ids, attention_mask, mask_word_id):
-        """Greedy incremental decoding.  Step s feeds the tokens that are new since step s-1 plus one [MASK] slot, projects them
-        to Q/K/V, appends K|V to the per-layer cache at their absolute positions (the [MASK] slot's entry is overwritten by the
-        real token in the next step, which is exactly what the reference's hidden-state history achieves by dropping the last
-        row, :1236-1247) and attends over the cache.  Returns (ids [B, n] int64, max logits [B, n] f32)."""
-        self.pack()
+    def _decode_check(self, vis_feats, vis_pe, input_ids, token_type_ids, attention_mask):
         model = self._model()
         cfg = model.config
-        H, I, A, NL, Nv, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers, model.len_vis_input, cfg.vocab_size
+        H, A, Nv = cfg.hidden_size, cfg.num_attention_heads, model.len_vis_input
         B, in_len = input_ids.shape
         out_len = token_type_ids.shape[1]
         if H != A * 64:
@@ -505,15 +510,13 @@ class Engine(object):
             raise RuntimeError("vlp_amd: decode needs %d <= input length < output length <= 256 (got %d, %d)" % (Nv + 2, in_len, out_len))
         if attention_mask.dim() != 3 or attention_mask.shape[1] < out_len or attention_mask.shape[2] < out_len:
             raise RuntimeError("vlp_amd: decode expects a [B, L, L] attention mask covering the output length")
-        n_steps, T0 = out_len - in_len, in_len + 1
-        ws = self._decode_workspace(B, T0, out_len)
-        dev = self.device
-        attention_mask = attention_mask.to(torch.long)
-        if attention_mask.stride(2) != 1:
-            attention_mask = attention_mask.contiguous()
-        token_type_ids, position_ids = token_type_ids.to(torch.long), position_ids.to(torch.long)
-        Mv = B * Nv
-        # ---- region projections, once (:1192-1193) -------------------------------------------------
+        return B, in_len, out_len
+
+    def _decode_regions(self, ws, vis_feats, vis_pe):
+        """Region projections, once per decode call (:1192-1193)."""
+        model = self._model()
+        H, Nv = model.config.hidden_size, model.len_vis_input
+        Mv = vis_feats.shape[0] * Nv
         vf = vis_feats.reshape(Mv, 2048)
         if vf.dtype == torch.float32:
             K.copy2d(vf.contiguous(), 2048, True, ws["img16"], 2048, Mv, 2048, 2048)
@@ -527,10 +530,66 @@ class Engine(object):
         self._nt(ws["h1"], self.P("vis_embed.2.weight"), ws["vis_h"], Mv, H, 2048, bias=self.P("vis_embed.2.bias"), act=K.ACT_RELU)
         self._nt(ws["vpe_in"], ws["wpe_pad"], ws["vispe_h"], Mv, H, PE_PAD, bias=self.P("vis_pe_embed.0.bias"), act=K.ACT_RELU)
 
-        out_ids = torch.empty(B, n_steps, device=dev, dtype=torch.long)
-        out_val = torch.empty(B, n_steps, device=dev, dtype=torch.float32)
+    def _decode_model_step(self, ws, caches, Lcap, xids, tt, pid, mask_view, R, T, st, first):
+        """One incremental forward of R sequences x T new tokens at absolute positions st..st+T-1: Q/K/V projection of the new
+        tokens, K|V appended to the per-layer caches, attention over positions 0..st+T-1, LM head on the last ([MASK]) slot.
+        Leaves the logits [R, V] in ws['logits'] (pitch ws['Vp'])."""
+        model = self._model()
+        cfg = model.config
+        H, I, A, NL, Nv, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers, model.len_vis_input, cfg.vocab_size
         E, C = "bert.embeddings.", "cls.predictions."
         scale = 1.0 / math.sqrt(H // A)
+        Lk = st + T
+        Lkp = _ru(Lk, 32)
+        M = R * T
+        maskb = ws["maskb"][:R * T * Lkp]
+        K.mask_pack_rect(mask_view, maskb, R, T, Lk, Lkp)
+        K.embed_fwd(xids, tt, self.P(E + "word_embeddings.weight"), self.P(E + "position_embeddings.weight"),
+                    self.P(E + "token_type_embeddings.weight"), ws["vis_h"], ws["vispe_h"], ws["emb_pre"], R, T, Nv if first else 0, H,
+                    position_ids=pid)
+        x, alt = ws["xa"], ws["xb"]
+        K.layernorm_fwd(ws["emb_pre"], self.P(E + "LayerNorm.weight"), self.P(E + "LayerNorm.bias"), x, M, H)
+        for i in range(NL):
+            Ln = "bert.encoder.layer.%d." % i
+            kv = caches[i]
+            self._nt(x, self.P(Ln + "attention.self.query.weight"), ws["qkv"], M, 3 * H, H, bias=self.P(Ln + "attention.self.query.bias"))
+            K.kv_append(ws["qkv"], 3 * H, kv, Lcap, R, T, st, H)
+            K.attn_decode(ws["qkv"], 3 * H, T, kv, kv[:, :, H:], 2 * H, Lcap, maskb, ws["ctx"], R, T, Lk, A, scale)
+            self._nt(ws["ctx"], self.P(Ln + "attention.output.dense.weight"), ws["pre"], M, H, H, bias=self.P(Ln + "attention.output.dense.bias"),
+                     residual=x)
+            K.layernorm_fwd(ws["pre"], self.P(Ln + "attention.output.LayerNorm.weight"), self.P(Ln + "attention.output.LayerNorm.bias"),
+                            ws["x1"], M, H)
+            self._nt(ws["x1"], self.P(Ln + "intermediate.dense.weight"), ws["g"], M, I, H, bias=self.P(Ln + "intermediate.dense.bias"),
+                     act=K.ACT_GELU)
+            self._nt(ws["g"], self.P(Ln + "output.dense.weight"), ws["pre"], M, H, I, bias=self.P(Ln + "output.dense.bias"), residual=ws["x1"])
+            K.layernorm_fwd(ws["pre"], self.P(Ln + "output.LayerNorm.weight"), self.P(Ln + "output.LayerNorm.bias"), alt, M, H)
+            x, alt = alt, x
+        # ---- LM head on the [MASK] slot (:1226-1228 / :1293-1296) ----------------------------------
+        ws["last"][:R].fill_(T - 1)
+        K.gather_rows(x, H, ws["last"], ws["sel"], H, R, 1, T, H)
+        self._nt(ws["sel"], self.P(C + "transform.dense.weight"), ws["tg"], R, H, H, bias=self.P(C + "transform.dense.bias"), act=K.ACT_GELU)
+        K.layernorm_fwd(ws["tg"], self.P(C + "transform.LayerNorm.weight"), self.P(C + "transform.LayerNorm.bias"), ws["tln"], R, H)
+        self._nt(ws["tln"], self.P("bert.embeddings.word_embeddings.weight"), ws["logits"], R, V, H, bias=self.P(C + "bias"), ldy=ws["Vp"])
+
+    def decode_greedy(self, vis_feats, vis_pe, input_ids, token_type_ids, position_ids, attention_mask, mask_word_id, sample=False):
+        """Greedy incremental decoding.  Step s feeds the tokens that are new since step s-1 plus one [MASK] slot, projects them
+        to Q/K/V, appends K|V to the per-layer cache at their absolute positions (the [MASK] slot's entry is overwritten by the
+        real token in the next step, which is exactly what the reference's hidden-state history achieves by dropping the last
+        row, :1236-1247) and attends over the cache.  Returns (ids [B, n] int64, max logits [B, n] f32); with sample=True the
+        ids are drawn from softmax(logits) (:1229-1235) and the second output holds their log-probabilities."""
+        self.pack()
+        V = self._model().config.vocab_size
+        B, in_len, out_len = self._decode_check(vis_feats, vis_pe, input_ids, token_type_ids, attention_mask)
+        n_steps, T0 = out_len - in_len, in_len + 1
+        ws = self._decode_workspace(B, T0, out_len)
+        dev = self.device
+        attention_mask = attention_mask.to(torch.long)
+        if attention_mask.stride(2) != 1:
+            attention_mask = attention_mask.contiguous()
+        token_type_ids, position_ids = token_type_ids.to(torch.long), position_ids.to(torch.long)
+        self._decode_regions(ws, vis_feats, vis_pe)
+        out_ids = torch.empty(B, n_steps, device=dev, dtype=torch.long)
+        out_val = torch.empty(B, n_steps, device=dev, dtype=torch.float32)
         x_first = torch.cat((input_ids.to(torch.long), torch.full((B, 1), int(mask_word_id), device=dev, dtype=torch.long)), dim=1).contiguous()
         ws["xids"][:, 1] = int(mask_word_id)
         next_pos = in_len
@@ -539,43 +598,83 @@ class Engine(object):
             T = T0 if first else 2
             st = next_pos + 1 - T
             Lk = next_pos + 1
-            Lkp = _ru(Lk, 32)
-            M = B * T
-            xids = x_first if first else ws["xids"]
-            tt = token_type_ids[:, st:Lk].contiguous()
-            pid = position_ids[:, st:Lk].contiguous()
-            maskb = ws["maskb"][:B * T * Lkp]
-            K.mask_pack_rect(attention_mask[:, st:Lk, :Lk], maskb, B, T, Lk, Lkp)
-            K.embed_fwd(xids, tt, self.P(E + "word_embeddings.weight"), self.P(E + "position_embeddings.weight"),
-                        self.P(E + "token_type_embeddings.weight"), ws["vis_h"], ws["vispe_h"], ws["emb_pre"], B, T, Nv if first else 0, H,
-                        position_ids=pid)
-            x, alt = ws["xa"], ws["xb"]
-            K.layernorm_fwd(ws["emb_pre"], self.P(E + "LayerNorm.weight"), self.P(E + "LayerNorm.bias"), x, M, H)
-            for i in range(NL):
-                Ln = "bert.encoder.layer.%d." % i
-                kv = ws["kv"][i]
-                self._nt(x, self.P(Ln + "attention.self.query.weight"), ws["qkv"], M, 3 * H, H, bias=self.P(Ln + "attention.self.query.bias"))
-                K.kv_append(ws["qkv"], 3 * H, kv, out_len, B, T, st, H)
-                K.attn_decode(ws["qkv"], 3 * H, T, kv, kv[:, :, H:], 2 * H, out_len, maskb, ws["ctx"], B, T, Lk, A, scale)
-                self._nt(ws["ctx"], self.P(Ln + "attention.output.dense.weight"), ws["pre"], M, H, H, bias=self.P(Ln + "attention.output.dense.bias"),
-                         residual=x)
-                K.layernorm_fwd(ws["pre"], self.P(Ln + "attention.output.LayerNorm.weight"), self.P(Ln + "attention.output.LayerNorm.bias"),
-                                ws["x1"], M, H)
-                self._nt(ws["x1"], self.P(Ln + "intermediate.dense.weight"), ws["g"], M, I, H, bias=self.P(Ln + "intermediate.dense.bias"),
-                         act=K.ACT_GELU)
-                self._nt(ws["g"], self.P(Ln + "output.dense.weight"), ws["pre"], M, H, I, bias=self.P(Ln + "output.dense.bias"), residual=ws["x1"])
-                K.layernorm_fwd(ws["pre"], self.P(Ln + "output.LayerNorm.weight"), self.P(Ln + "output.LayerNorm.bias"), alt, M, H)
-                x, alt = alt, x
-            # ---- LM head on the [MASK] slot (:1226-1228) ------------------------------------------
-            ws["last"].fill_(T - 1)
-            K.gather_rows(x, H, ws["last"], ws["sel"], H, B, 1, T, H)
-            self._nt(ws["sel"], self.P(C + "transform.dense.weight"), ws["tg"], B, H, H, bias=self.P(C + "transform.dense.bias"), act=K.ACT_GELU)
-            K.layernorm_fwd(ws["tg"], self.P(C + "transform.LayerNorm.weight"), self.P(C + "transform.LayerNorm.bias"), ws["tln"], B, H)
-            self._nt(ws["tln"], self.P("bert.embeddings.word_embeddings.weight"), ws["logits"], B, V, H, bias=self.P(C + "bias"), ldy=ws["Vp"])
-            K.argmax_rows(ws["logits"], ws["Vp"], B, V, out_ids[:, s], out_val[:, s])
-            K.argmax_rows(ws["logits"], ws["Vp"], B, V, ws["xids"][:, 0], out_val[:, s])      # next step's first input token
+            self._decode_model_step(ws, ws["kv"], out_len, x_first if first else ws["xids"], token_type_ids[:, st:Lk].contiguous(),
+                                    position_ids[:, st:Lk].contiguous(), attention_mask[:, st:Lk, :Lk], B, T, st, first)
+            if sample:
+                self.step_seed += 1
+                for dst in (out_ids[:, s], ws["xids"][:, 0]):                   # same (seed, stream) -> same draw; 2nd = next input token
+                    K.sample_rows(ws["logits"], ws["Vp"], B, V, self.base_seed + self.step_seed, 7001, dst, out_val[:, s])
+            else:
+                K.argmax_rows(ws["logits"], ws["Vp"], B, V, out_ids[:, s], out_val[:, s])
+                K.argmax_rows(ws["logits"], ws["Vp"], B, V, ws["xids"][:, 0], out_val[:, s])      # next step's first input token
             next_pos += 1
         return out_ids, out_val
+
+    def decode_beam(self, vis_feats, vis_pe, input_ids, token_type_ids, position_ids, attention_mask, mask_word_id, beam_size, eos_id,
+                    min_len=0, forbid_fn=None):
+        """Beam search frames (modeling.py:1255-1430) on the K/V-cache decoder.  The first step runs B sequences; its cache rows are
+        replicated to the B*K beams (first_expand), afterwards every step decodes B*K sequences and the caches follow the back
+        pointers (select_beam_items) -- only the generated positions, the prefix is identical for all beams of a sample.
+        `forbid_fn(step_ids [B,K] list, back_ptrs [B,K] list, first)` -> uint8 [B*K, V] numpy mask or None implements the host-side
+        n-gram blocking (:1367-1430); when given, ids / pointers are copied to the host every step exactly as the reference does.
+        Returns (total_scores, step_ids, back_ptrs) as [frames, B, K] tensors on the device."""
+        self.pack()
+        model = self._model()
+        cfg = model.config
+        H, NL, V = cfg.hidden_size, cfg.num_hidden_layers, cfg.vocab_size
+        Kb = int(beam_size)
+        B, in_len, out_len = self._decode_check(vis_feats, vis_pe, input_ids, token_type_ids, attention_mask)
+        if Kb < 2 or Kb > 64:
+            raise RuntimeError("vlp_amd: beam size must be in [2, 64]")
+        n_steps, T0 = out_len - in_len, in_len + 1
+        R = B * Kb
+        ws = self._decode_workspace(B, T0, out_len, Kb)
+        dev = self.device
+        attention_mask = attention_mask.to(torch.long)
+        if attention_mask.stride(2) != 1:
+            attention_mask = attention_mask.contiguous()
+        token_type_ids, position_ids = token_type_ids.to(torch.long), position_ids.to(torch.long)
+        self._decode_regions(ws, vis_feats, vis_pe)
+        tot = torch.empty(n_steps, B, Kb, device=dev, dtype=torch.float32)
+        wids = torch.empty(n_steps, B, Kb, device=dev, dtype=torch.long)
+        ptrs = torch.empty(n_steps, B, Kb, device=dev, dtype=torch.long)
+        eos = torch.empty(n_steps, B, Kb, device=dev, dtype=torch.float32)
+        x_first = torch.cat((input_ids.to(torch.long), torch.full((B, 1), int(mask_word_id), device=dev, dtype=torch.long)), dim=1).contiguous()
+        ws["xids"][:, 1] = int(mask_word_id)
+        cur, other = ws["kvA"], ws["kvB"]
+        forbid = None
+        next_pos = in_len
+        for s in range(n_steps):
+            first = s == 0
+            T = T0 if first else 2
+            st = next_pos + 1 - T
+            Lk = next_pos + 1
+            rows = B if first else R
+            self._decode_model_step(ws, ws["kv"] if first else cur, out_len, x_first if first else ws["xids"],
+                                    token_type_ids[:, st:Lk].contiguous(), position_ids[:, st:Lk].contiguous(), attention_mask[:, st:Lk, :Lk],
+                                    rows, T, st, first)
+            block_eos = bool(min_len) and (next_pos - in_len + 1 <= min_len)
+            K.logsoftmax_topk(ws["logits"], ws["Vp"], rows, V, Kb, ws["kk_s"], ws["kk_i"], forbid=forbid, eos_id=int(eos_id), block_eos=block_eos)
+            K.beam_select(ws["kk_s"], ws["kk_i"], None if first else tot[s - 1], None if first else eos[s - 1], tot[s], wids[s], ptrs[s], eos[s],
+                          ws["src_rows"], ws["xids"][:, 0], B, Kb, first, int(eos_id))
+            if first:
+                # first_expand (:1325-1332, 1361-1365): caches, and the per-sample inputs of all later steps
+                for i in range(NL):
+                    K.kv_gather(ws["kv"][i], out_len, cur[i], out_len, ws["src_rows"], R, 0, in_len, 2 * H)
+                    K.kv_gather(ws["kv"][i], out_len, other[i], out_len, ws["src_rows"], R, 0, in_len, 2 * H)
+                token_type_ids = token_type_ids.repeat_interleave(Kb, dim=0)
+                position_ids = position_ids.repeat_interleave(Kb, dim=0)
+                attention_mask = attention_mask.repeat_interleave(Kb, dim=0)
+            elif s + 1 < n_steps:
+                # select_beam_items (:1334-1359): generated positions in_len .. next_pos-1 follow their beam
+                for i in range(NL):
+                    K.kv_gather(cur[i], out_len, other[i], out_len, ws["src_rows"], R, in_len, next_pos, 2 * H)
+                cur, other = other, cur
+            if forbid_fn is not None:
+                fm = forbid_fn(wids[s].tolist(), ptrs[s].tolist(), first)
+                forbid = None if fm is None else torch.from_numpy(fm).to(dev)
+            next_pos += 1
+        return tot, wids, ptrs
 
     # ------------------------------------------------------------------------------------------
     # backward

@@ -510,8 +510,9 @@ class BertForPreTrainingLossMask(PreTrainedBertModel):
 
 class BertForSeq2SeqDecoder(PreTrainedBertModel):
     """Incremental caption decoder (:1147-1494): same parameter tree as BertForPreTrainingLossMask (checkpoint compatible);
-    greedy decoding (:1189-1253) runs on the HIP engine with a per-layer K/V cache (Engine.decode_greedy).  Beam search
-    (:1255-1494) and sample_mode='sample' are not built yet."""
+    greedy decoding (:1189-1253) and beam search (:1255-1494) run on the HIP engine with per-layer K/V caches
+    (Engine.decode_greedy / Engine.decode_beam); the host keeps only what the reference keeps on the host (n-gram blocking
+    over python lists, back-tracking of the frames).  sample_mode='sample' draws with the library's counter-based RNG."""
     tasks = "img2txt"
 
     def __init__(self, config, mask_word_id=0, num_labels=2, search_beam_size=1, length_penalty=1.0, eos_id=0,
@@ -536,11 +537,100 @@ class BertForSeq2SeqDecoder(PreTrainedBertModel):
     def forward(self, vis_feats, vis_pe, input_ids, token_type_ids, position_ids, attention_mask, task_idx=None, sample_mode="greedy"):
         """Returns (output_ids [B, n], output_probs [B, n]) with n = token_type_ids.shape[1] - input_ids.shape[1], as :1253.
         output_probs are the maximal prediction scores (logits), exactly what the reference returns in greedy mode (:1228)."""
-        if self.search_beam_size > 1:
-            raise NotImplementedError("vlp_amd: beam search (modeling.py:1255-1494) is not built yet; use search_beam_size=1")
-        if sample_mode != "greedy":
-            raise NotImplementedError("vlp_amd: sample_mode=%r is not built; only 'greedy'" % (sample_mode,))
         if not input_ids.is_cuda:
             raise RuntimeError("vlp_amd: the decoder runs on the HIP engine only (inputs must be on the GPU); there is no CPU path")
+        if self.search_beam_size > 1:
+            with torch.no_grad():
+                return self.beam_search(vis_feats, vis_pe, input_ids, token_type_ids, position_ids, attention_mask, task_idx=task_idx)
+        if sample_mode not in ("greedy", "sample"):
+            raise NotImplementedError("sample_mode=%r (the reference knows 'greedy' and 'sample', modeling.py:1227-1237)" % (sample_mode,))
         with torch.no_grad():
-            return self.engine.decode_greedy(vis_feats, vis_pe, input_ids, token_type_ids, position_ids, attention_mask, self.mask_word_id)
+            return self.engine.decode_greedy(vis_feats, vis_pe, input_ids, token_type_ids, position_ids, attention_mask, self.mask_word_id,
+                                             sample=(sample_mode == "sample"))
+
+    # ---- beam search: host side (what the reference also does on the host) -------------------------------
+    def _ngram_blocker(self, batch_size, vocab_size):
+        """Stateful callback for Engine.decode_beam: tracks the partial hypotheses (:1367-1384) and returns the uint8 [B*K, V] mask
+        of words that would repeat an n-gram (:1386-1430), or None."""
+        import numpy as np
+        K, n, ignore = self.search_beam_size, self.ngram_size, self.forbid_ignore_set
+        state = {"seqs": None}
+
+        def repeats(seq):
+            if len(seq) < n:
+                return ()
+            tail = seq[len(seq) - (n - 1):]
+            if ignore and any(t in ignore for t in tail):
+                return ()
+            hits = set()
+            for i in range(len(seq) - (n - 1)):
+                if seq[i:i + n - 1] == tail:
+                    nxt = seq[i + n - 1]
+                    if not (ignore and nxt in ignore):
+                        hits.add(nxt)
+            return hits
+
+        def step(ids, back, first):
+            if first:
+                state["seqs"] = [[ids[b][k]] for b in range(batch_size) for k in range(K)]
+            else:
+                old = state["seqs"]
+                state["seqs"] = [old[b * K + back[b][k]] + [ids[b][k]] for b in range(batch_size) for k in range(K)]
+            seqs = state["seqs"]
+            if len(seqs[0]) < n:
+                return None
+            hits = [repeats(sq) for sq in seqs]
+            if not any(hits):
+                return None
+            mask = np.zeros((batch_size * K, vocab_size), dtype=np.uint8)
+            for r, hs in enumerate(hits):
+                for w in hs:
+                    mask[r, w] = 1
+            return mask
+        return step
+
+    def _backtrack(self, scores, words, back):
+        """One sample's frames (lists [frames][K]) -> best hypothesis (:1446-1474): candidates are the hypotheses that emitted eos, or
+        any hypothesis of the last valid frame (the first frame whose words are all eos, else the final one); rank by cumulative
+        log-probability + length_penalty * length; follow the back pointers."""
+        eos, lp = self.eos_id, self.length_penalty
+        last = next((i for i, w in enumerate(words) if all(x == eos for x in w)), len(scores) - 1)
+        best = None
+        for f in range(last + 1):
+            for k, w in enumerate(words[f]):
+                if w == eos or f == last:
+                    val = scores[f][k] + lp * (f + 1)
+                    if best is None or val > best[0]:
+                        best = (val, f, k)
+        if best is None or best[0] == -math.inf:
+            return [0]
+        _, f, k = best
+        out = [words[f][k]]
+        while f > 0:
+            k = back[f][k]
+            f -= 1
+            out.append(words[f][k])
+        out.reverse()
+        return out
+
+    def beam_search(self, vis_feats, vis_pe, input_ids, token_type_ids, position_ids, attention_mask, task_idx=None):
+        """Returns the reference's traces dict (:1436-1494): 'pred_seq' [B, L] (0 padded), 'scores' f32 / 'wids' / 'ptrs' [B, L, K]
+        (frames padded with zeros to the output length L), on the input device."""
+        B, out_len = input_ids.shape[0], token_type_ids.shape[1]
+        K = self.search_beam_size
+        forbid_fn = self._ngram_blocker(B, self.config.vocab_size) if self.forbid_duplicate_ngrams else None
+        tot, wids, ptrs = self.engine.decode_beam(vis_feats, vis_pe, input_ids, token_type_ids, position_ids, attention_mask, self.mask_word_id,
+                                                  K, self.eos_id, min_len=self.min_len, forbid_fn=forbid_fn)
+        frames = tot.shape[0]
+        tot_l, wid_l, ptr_l = tot.tolist(), wids.tolist(), ptrs.tolist()           # one device -> host copy each
+        dev = input_ids.device
+        traces = {"pred_seq": torch.zeros(B, out_len, dtype=torch.long), "scores": torch.zeros(B, out_len, K, dtype=torch.float32),
+                  "wids": torch.zeros(B, out_len, K, dtype=torch.long), "ptrs": torch.zeros(B, out_len, K, dtype=torch.long)}
+        for b in range(B):
+            sc, ww, pp = [tot_l[f][b] for f in range(frames)], [wid_l[f][b] for f in range(frames)], [ptr_l[f][b] for f in range(frames)]
+            seq = self._backtrack(sc, ww, pp)
+            traces["pred_seq"][b, :len(seq)] = torch.tensor(seq, dtype=torch.long)
+            traces["scores"][b, :frames] = torch.tensor(sc, dtype=torch.float32)
+            traces["wids"][b, :frames] = torch.tensor(ww, dtype=torch.long)
+            traces["ptrs"][b, :frames] = torch.tensor(pp, dtype=torch.long)
+        return {k: v.to(dev) for k, v in traces.items()}
