@@ -270,6 +270,26 @@ int vlp_mask_pack_rect(const int64_t* mask, int64_t batch_stride, int64_t row_st
 int vlp_kv_append(const void* qkv_new, int64_t ld, void* cache, int32_t Lcap, int32_t B, int32_t T, int32_t start, int32_t H, void* stream);
 int vlp_argmax_rows(const void* logits, int64_t ld, int32_t rows, int32_t V, int64_t* ids, int64_t ids_stride, float* vals, int64_t vals_stride,
                     void* stream);
+/* On-device input preparation (replaces per-sample CPU work of vlp/seq2seq_loader.py):
+ *   vlp_mask_build: the packed attention masks (format of vlp_mask_pack, incl. the optional key-major copy) straight from the per-sample
+ *       lengths, seq2seq_loader.py:292-301:  second_st = len(tokens_a)+2, second_end = len(tokens_a)+len(tokens_b)+3;
+ *       s2s: attend(q,k) = k < st || (st <= q < en && st <= k <= q);  bi: attend(q,k) = k < en.  No int64 [B,L,L] tensor is shipped or read.
+ *   vlp_vis_pe_prep: raw boxes [B,Nv,6] (x1,y1,x2,y2,-,confidence) + class probabilities [B*Nv, ld_cls] (f16 as stored on disk, or f32)
+ *       -> the 6+n_cls encoding of seq2seq_loader.py:338-351 (corners / largest corner of the image, clamped relative area, layer norm of the 6
+ *       box numbers and of the class probabilities, eps inside the sqrt) in f16, zero padded to pad_to columns = the K-padded operand of the
+ *       vis_pe_embed GEMM (modeling.py:1016). */
+int vlp_mask_build(const int32_t* second_st, const int32_t* second_end, const int32_t* is_s2s, uint8_t* out, uint8_t* out_t, int32_t B, int32_t L,
+                   int32_t Lp, void* stream);
+typedef struct {
+    const float* bbox;       /* [B, Nv, 6] f32 */
+    const void* cls;         /* [B*Nv, ld_cls] f16 or f32 */
+    int64_t ld_cls;
+    void* out;               /* [B*Nv, ld_out] f16 */
+    int64_t ld_out;
+    int32_t B, Nv, n_cls, pad_to, cls_is_f32;
+    float eps;               /* 1e-5 (F.layer_norm default) */
+} vlp_vis_pe_prep_args;
+int vlp_vis_pe_prep(const vlp_vis_pe_prep_args* a, void* stream);
 /* sample_mode == 'sample' (modeling.py:1229-1235): ids[r*ids_stride] ~ Categorical(softmax(logits[r, :V])) drawn by the Gumbel-max trick
  * on the library's counter-based hash (seed, rng_stream, row, column) -- torch.multinomial's stream cannot be reproduced, the
  * distribution is the same; logp[r*logp_stride] = log_softmax(logits[r])[ids[r]]. */

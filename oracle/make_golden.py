@@ -51,6 +51,9 @@ BEAM_CASES = {
                     dict(search_beam_size=5, length_penalty=1.0, min_len=0, forbid_duplicate_ngrams=False, ngram_size=3)),
 }
 
+# input-preparation cases (Preprocess4Seq2seq.__call__, vlp/seq2seq_loader.py:229-359): (mode, caption tokens, seed)
+LOADER_CASES = {"loader_s2s_n9": ("s2s", 9, 1), "loader_bi_n14": ("bi", 14, 2)}
+
 GRAD_SAMPLES = [
     "bert.embeddings.word_embeddings.weight", "bert.embeddings.position_embeddings.weight",
     "bert.embeddings.token_type_embeddings.weight", "bert.embeddings.LayerNorm.weight",
@@ -209,9 +212,51 @@ def run_reference_beam_case(mk, B, T, seed, dk):
     return out
 
 
+def loader_raw_inputs(seed, Nv=100):
+    """Synthetic raw arrays shaped like the dataset's h5 contents: Detectron boxes in pixels (+ a dummy column and a confidence),
+    fp16 class probabilities, fp16 fc6 features (README.md:64,118; seq2seq_loader.py:325-330)."""
+    rng = np.random.RandomState(seed)
+    wh = np.asarray([640.0, 480.0])
+    xy1 = rng.uniform(0, 0.7, size=(Nv, 2)) * wh
+    xy2 = np.minimum(xy1 + rng.uniform(0.05, 0.3, size=(Nv, 2)) * wh, wh - 1)
+    bbox = np.concatenate((xy1, xy2, rng.uniform(0, 1, size=(Nv, 1)), rng.uniform(0.2, 1, size=(Nv, 1))), axis=1).astype(np.float32)
+    logits = rng.standard_normal((Nv, 1601)) * 3
+    cls = (np.exp(logits) / np.exp(logits).sum(-1, keepdims=True)).astype(np.float16)
+    feat = np.abs(rng.standard_normal((Nv, 2048))).astype(np.float16)
+    tokens = rng.randint(0, 200, size=64)
+    return bbox, cls, feat, tokens
+
+
+def run_reference_loader_case(mode, n_tokens, seed, max_len_b=20, Nv=100):
+    """Runs the UNMODIFIED Preprocess4Seq2seq.__call__ on the synthetic raw arrays, served by the in-memory h5py of ref_loader."""
+    import random
+    L = ref_loader.load_reference_loader()
+    bbox, cls, feat, tokens = loader_raw_inputs(seed, Nv)
+    img_id = "COCO_%06d" % seed
+    ref_loader.H5_REGISTRY["det_feat" + img_id[-3:] + ".h5"] = {img_id: feat}
+    ref_loader.H5_REGISTRY["det_cls" + img_id[-3:] + ".h5"] = {img_id: cls}
+    ref_loader.H5_REGISTRY["bbox.h5"] = {img_id: bbox.copy()}
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + ["w%d" % i for i in range(200)]
+    idx = {w: i for i, w in enumerate(vocab)}
+    proc = L.Preprocess4Seq2seq(3, 0.15, vocab, lambda toks: [idx[t] for t in toks], max_len=Nv + max_len_b + 3, new_segment_ids=True,
+                                truncate_config={"max_len_b": max_len_b, "trunc_seg": "b", "always_truncate_tail": True}, mode=mode,
+                                len_vis_input=Nv, enable_butd=True, region_bbox_file="bbox.h5", region_det_file_prefix="det")
+    random.seed(seed)
+    out = proc(("/data/" + img_id + ".jpg", ["w%d" % int(t) for t in tokens[:n_tokens]]))
+    return out, bbox, cls, feat, min(n_tokens, max_len_b)
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(GOLDEN_DIR, exist_ok=True)
+    for name, (mode, n_tokens, seed) in LOADER_CASES.items():
+        out, bbox, cls, feat, nb = run_reference_loader_case(mode, n_tokens, seed)
+        path = os.path.join(GOLDEN_DIR, name + ".npz")
+        np.savez_compressed(path, bbox=bbox, cls=cls, vis_pe=out[10].numpy().astype(np.float32), input_mask=out[2].numpy().astype(np.uint8),
+                            segment_ids=np.asarray(out[1]), len_b=np.asarray(nb), img_sum=np.asarray(float(out[8].double().sum())))
+        print("%s: vis_pe %s mask rows %d -> %s (%.0f KB)" % (name, tuple(out[10].shape), out[2].shape[0], path, os.path.getsize(path) / 1024))
+    if "--loader-only" in sys.argv:
+        return
     for name, (mk, B, T, seed, dk) in BEAM_CASES.items():
         out = run_reference_beam_case(mk, B, T, seed, dk)
         path = os.path.join(GOLDEN_DIR, name + ".npz")

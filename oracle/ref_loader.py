@@ -124,3 +124,63 @@ def build_reference_model(cfg_kwargs, tasks="img2txt", seed=0, drop_prob=0.0, de
             model = ref.modeling.BertForPreTrainingLossMask(config, num_labels=2, enable_butd=True,
                                                             len_vis_input=100, tasks=tasks)
     return model
+
+
+# ----------------------------------------------------------------------------------------------
+# the reference's data pipeline (vlp/seq2seq_loader.py), for the N2 row: on-device input preparation
+# ----------------------------------------------------------------------------------------------
+H5_REGISTRY = {}          # fake file name -> {dataset key: numpy array}; served by the stub h5py below
+
+
+class _FakeH5File(object):
+    def __init__(self, name, mode="r"):
+        if name not in H5_REGISTRY:
+            raise IOError("fake h5py: no such file %r" % name)
+        self._d = H5_REGISTRY[name]
+
+    def __enter__(self):
+        return self._d
+
+    def __exit__(self, *a):
+        return False
+
+
+def load_reference_loader():
+    """Returns the reference's own vlp.seq2seq_loader module (unmodified).  torchvision (image transforms, unused with region
+    features) is stubbed; h5py is replaced by an in-memory fake so that Preprocess4Seq2seq.__call__ (seq2seq_loader.py:229-359)
+    reads arrays registered in H5_REGISTRY instead of the dataset's .h5 files."""
+    if "loader" in _cache:
+        return _cache["loader"]
+    if not reference_available():
+        raise RuntimeError("reference tree not found at %s" % REFERENCE_ROOT)
+    tv = _stub("torchvision")
+    tr = _stub("torchvision.transforms", Resize=lambda *a, **k: None, RandomCrop=lambda *a, **k: None, ToTensor=lambda *a, **k: None,
+               Normalize=lambda *a, **k: None)
+    tv.transforms = tr
+    real_h5 = sys.modules.get("h5py")
+    sys.modules["h5py"] = types.SimpleNamespace(File=_FakeH5File)
+    saved = {k: v for k, v in sys.modules.items() if k == "vlp" or k.startswith("vlp.")}
+    for k in saved:
+        del sys.modules[k]
+    pkg = types.ModuleType("vlp")
+    pkg.__path__ = [os.path.join(REFERENCE_ROOT, "vlp")]
+    sys.modules["vlp"] = pkg
+    try:
+        mods = {}
+        for name in ("loader_utils", "seq2seq_loader"):
+            spec = importlib.util.spec_from_file_location("vlp." + name, os.path.join(REFERENCE_ROOT, "vlp", name + ".py"))
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules["vlp." + name] = mod
+            spec.loader.exec_module(mod)
+            mods[name] = mod
+    finally:
+        for k in list(sys.modules):
+            if k == "vlp" or k.startswith("vlp."):
+                del sys.modules[k]
+        sys.modules.update(saved)
+        if real_h5 is not None:
+            sys.modules["h5py"] = real_h5
+        else:
+            del sys.modules["h5py"]
+    _cache["loader"] = mods["seq2seq_loader"]
+    return _cache["loader"]

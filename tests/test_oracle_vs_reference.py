@@ -144,3 +144,21 @@ def test_state_dict_keys_match_reference():
         ref_keys = set(model.state_dict().keys())
         ours = set(O.init_params(vocab_size=512, layers=1, tasks=tasks).keys()) | {"cls.predictions.decoder.weight"}
         assert ref_keys == ours
+
+
+from oracle.make_golden import run_reference_loader_case as _loader_case      # noqa: E402
+
+
+@pytest.mark.parametrize("mode,n_tokens,seed", [("s2s", 9, 1), ("bi", 14, 2), ("s2s", 31, 3)])
+def test_loader_oracle_vs_reference(mode, n_tokens, seed):
+    """Input preparation (seq2seq_loader.py:229-359): attention mask, segment ids and the normalised box / class encoding."""
+    from oracle import loader_oracle as LO
+    out, bbox, cls, feat, nb = _loader_case(mode, n_tokens, seed)
+    input_ids, segment_ids, input_mask, _, masked_pos, _, is_next, task_idx, img, vis_masked_pos, vis_pe, _ = out
+    max_len = len(input_ids)
+    assert np.array_equal(input_mask.numpy(), LO.attention_mask(100, nb, max_len, mode))
+    assert np.array_equal(np.asarray(segment_ids), LO.segment_ids(100, nb, max_len, mode))
+    mine = LO.vis_pe_prepare(bbox, cls.astype(np.float32))
+    assert vis_pe.shape == (100, 1607) and np.abs(vis_pe.numpy() - mine).max() < 2e-4
+    assert np.array_equal(img.numpy(), feat.astype(np.float32)) and task_idx == (3 if mode == "s2s" else 0) and is_next == -1
+    assert all(100 + 2 <= p < 100 + 2 + nb + 1 for p in masked_pos if p)

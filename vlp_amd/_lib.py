@@ -78,6 +78,11 @@ class AttnDecodeArgs(C.Structure):
                 ("mask", vp), ("ctx", vp), ("ld_ctx", i64), ("B", i32), ("Lq", i32), ("Lk", i32), ("heads", i32), ("scale", f32)]
 
 
+class VisPePrepArgs(C.Structure):
+    _fields_ = [("bbox", vp), ("cls", vp), ("ld_cls", i64), ("out", vp), ("ld_out", i64), ("B", i32), ("Nv", i32), ("n_cls", i32),
+                ("pad_to", i32), ("cls_is_f32", i32), ("eps", f32)]
+
+
 class BeamSelectArgs(C.Structure):
     _fields_ = [("kk_scores", vp), ("kk_ids", vp), ("last_total", vp), ("last_eos", vp), ("out_scores", vp), ("out_ids", vp),
                 ("out_ptrs", vp), ("out_eos", vp), ("src_rows", vp), ("next_ids", vp), ("next_ids_stride", i64),
@@ -134,6 +139,8 @@ SYMBOLS = {
     "vlp_logsoftmax_topk": (C.c_int, [vp, i64, i32, i32, i32, vp, i32, i32, vp, vp, vp]),
     "vlp_beam_select": (C.c_int, [C.POINTER(BeamSelectArgs), vp]),
     "vlp_kv_gather": (C.c_int, [vp, i64, vp, i64, vp, i32, i32, i32, i32, vp]),
+    "vlp_mask_build": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "vlp_vis_pe_prep": (C.c_int, [C.POINTER(VisPePrepArgs), vp]),
     "vlp_sample_rows": (C.c_int, [vp, i64, i32, i32, C.c_uint64, C.c_uint32, vp, i64, vp, i64, vp]),
     "vlp_argmax_rows": (C.c_int, [vp, i64, i32, i32, vp, i64, vp, i64, vp]),
     "vlp_mask_pack": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
@@ -297,6 +304,22 @@ def beam_select(kk_scores, kk_ids, last_total, last_eos, out_scores, out_ids, ou
 def kv_gather(src, src_rows, dst, dst_rows, idx, R, lo, hi, row_elems):
     _req_cuda(src, dst, idx)
     _check(load().vlp_kv_gather(ptr(src), src_rows, ptr(dst), dst_rows, ptr(idx), R, lo, hi, row_elems, stream_ptr()))
+
+
+def mask_build(second_st, second_end, is_s2s, out_u8, B, L, Lp, out_t=None):
+    """second_st / second_end / is_s2s: int32 [B] device tensors."""
+    _req_cuda(second_st, second_end, is_s2s, out_u8, out_t)
+    for t in (second_st, second_end, is_s2s):
+        assert t.dtype == torch.int32 and t.is_contiguous() and t.numel() == B
+    _check(load().vlp_mask_build(ptr(second_st), ptr(second_end), ptr(is_s2s), ptr(out_u8), ptr(out_t), B, L, Lp, stream_ptr()))
+
+
+def vis_pe_prep(bbox, cls, out, B, Nv, n_cls, pad_to, eps=1e-5):
+    """bbox f32 [B,Nv,6]; cls f16/f32 [B*Nv, >=n_cls] (row stride = stride(0)); out f16 [B*Nv, >=pad_to]."""
+    _req_cuda(bbox, cls, out)
+    assert bbox.dtype == torch.float32 and bbox.is_contiguous() and cls.dtype in (torch.float16, torch.float32) and cls.stride(-1) == 1
+    a = VisPePrepArgs(ptr(bbox), ptr(cls), cls.stride(0), ptr(out), out.stride(0), B, Nv, n_cls, pad_to, 1 if cls.dtype == torch.float32 else 0, eps)
+    _check(load().vlp_vis_pe_prep(C.byref(a), stream_ptr()))
 
 
 def sample_rows(logits, ld, rows, V, seed, rng_stream, ids, logp):

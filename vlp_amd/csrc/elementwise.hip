@@ -681,3 +681,76 @@ extern "C" int vlp_sample_rows(const void* logits, int64_t ld, int32_t rows, int
     VLP_CHECK_LAUNCH("vlp_sample_rows");
     return VLP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// box / class encoding of the regions (seq2seq_loader.py:338-351), one wave per region row
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vis_pe_prep_kernel(vlp_vis_pe_prep_args a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (int64_t)a.B * a.Nv) return;
+    const int64_t b = row / a.Nv;
+    // "lazy normalisation": largest x / y corner of the image (:339-340)
+    const float* bb = a.bbox + b * a.Nv * 6;
+    float wmax = -INFINITY, hmax = -INFINITY;
+    for (int j = lane; j < a.Nv; j += 64) {
+        wmax = fmaxf(wmax, fmaxf(bb[j * 6 + 0], bb[j * 6 + 2]));
+        hmax = fmaxf(hmax, fmaxf(bb[j * 6 + 1], bb[j * 6 + 3]));
+    }
+    const float w_est = wave_max(wmax) + 1e-5f, h_est = wave_max(hmax) + 1e-5f;
+    const float* r = a.bbox + row * 6;
+    float six[6];
+    six[0] = r[0] / w_est; six[1] = r[1] / h_est; six[2] = r[2] / w_est; six[3] = r[3] / h_est;
+    six[4] = fmaxf((six[3] - six[1]) * (six[2] - six[0]), 0.f);          // relative area, clamped (:345-346)
+    six[5] = r[5];                                                        // confidence (:348)
+    float mu = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) mu += six[i];
+    mu *= (1.f / 6.f);
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) var += (six[i] - mu) * (six[i] - mu);
+    const float rs6 = rsqrtf(var * (1.f / 6.f) + a.eps);
+    f16* o = (f16*)a.out + row * a.ld_out;
+    if (lane < 6) {
+        float v = six[0];
+#pragma unroll
+        for (int i = 1; i < 6; ++i) v = lane == i ? six[i] : v;
+        o[lane] = (f16)((v - mu) * rs6);
+    }
+    // class probabilities: layer norm over n_cls (:350-351)
+    constexpr int MAXE = 32;                                              // up to 2048 classes per row
+    float x[MAXE];
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        const int c = lane + 64 * e;
+        float v = 0.f;
+        if (c < a.n_cls) v = a.cls_is_f32 ? ((const float*)a.cls)[row * a.ld_cls + c] : (float)((const f16*)a.cls)[row * a.ld_cls + c];
+        x[e] = v;
+        s += v;
+    }
+    const float cm = wave_sum(s) / (float)a.n_cls;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        const int c = lane + 64 * e;
+        if (c < a.n_cls) q += (x[e] - cm) * (x[e] - cm);
+    }
+    const float crs = rsqrtf(wave_sum(q) / (float)a.n_cls + a.eps);
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        const int c = lane + 64 * e;
+        if (c < a.n_cls) o[6 + c] = (f16)((x[e] - cm) * crs);
+    }
+    for (int c = 6 + a.n_cls + lane; c < a.pad_to; c += 64) o[c] = (f16)0.f;
+}
+extern "C" int vlp_vis_pe_prep(const vlp_vis_pe_prep_args* a, void* stream) {
+    VLP_CHECK_ARG(a && a->bbox && a->cls && a->out && a->B > 0 && a->Nv > 0, "vlp_vis_pe_prep: null operand / bad shape");
+    VLP_CHECK_ARG(a->n_cls > 0 && a->n_cls <= 2048 && a->ld_cls >= a->n_cls && a->pad_to >= 6 + a->n_cls && a->ld_out >= a->pad_to,
+                  "vlp_vis_pe_prep: n_cls <= 2048, ld_cls >= n_cls, ld_out >= pad_to >= 6 + n_cls");
+    const int64_t rows = (int64_t)a->B * a->Nv;
+    hipLaunchKernelGGL(vis_pe_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
+    VLP_CHECK_LAUNCH("vlp_vis_pe_prep");
+    return VLP_OK;
+}

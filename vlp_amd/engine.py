@@ -23,6 +23,7 @@ import weakref
 import torch
 
 from . import _lib as K
+from .input_prep import MaskSpec, RawRegions
 
 ALIGN = 64            # elements; every parameter starts on a 128-byte boundary inside its flat buffer
 NO_DECAY = ("bias", "LayerNorm.bias", "LayerNorm.weight")    # run_img2txt_dist.py:395
@@ -350,6 +351,8 @@ class Engine(object):
             raise RuntimeError("vlp_amd: attention kernels need head_dim == 64 (hidden %d, heads %d)" % (H, A))
         if vis_feats.shape[1] != Nv or vis_feats.shape[2] != 2048 or vis_pe.shape[2] != PE_DIM:
             raise RuntimeError("vlp_amd: expected vis_feats [B,%d,2048] and vis_pe [B,%d,%d]" % (Nv, Nv, PE_DIM))
+        raw_regions = isinstance(vis_pe, RawRegions)
+        mask_spec = isinstance(attention_mask, MaskSpec)
         if L < Nv + 2:
             raise RuntimeError("vlp_amd: sequence length %d too short for %d regions" % (L, Nv))
         P = masked_pos.shape[1] if (want_mlm and masked_pos is not None and masked_pos.numel() > 0) else 0
@@ -366,20 +369,29 @@ class Engine(object):
         M, Mv = B * L, B * Nv
 
         # ---- inputs -----------------------------------------------------------------------------
-        if attention_mask is None:
-            attention_mask = torch.ones(B, L, dtype=torch.long, device=input_ids.device)
-        if attention_mask.dim() == 2:       # modeling.py:818-819
-            attention_mask = attention_mask[:, None, :].expand(B, L, L)
-        attention_mask = attention_mask.to(torch.long).contiguous()
-        K.mask_pack(attention_mask, ws["maskb"], B, L, ws["Lp"], out_t=ws["maskt"] if train or torch.is_grad_enabled() else None)
+        want_t = ws["maskt"] if train or torch.is_grad_enabled() else None
+        if mask_spec:                       # per-sample lengths -> packed masks on the device (seq2seq_loader.py:292-301)
+            attention_mask.check(B, L)
+            K.mask_build(attention_mask.second_st, attention_mask.second_end, attention_mask.is_s2s, ws["maskb"], B, L, ws["Lp"], out_t=want_t)
+        else:
+            if attention_mask is None:
+                attention_mask = torch.ones(B, L, dtype=torch.long, device=input_ids.device)
+            if attention_mask.dim() == 2:       # modeling.py:818-819
+                attention_mask = attention_mask[:, None, :].expand(B, L, L)
+            attention_mask = attention_mask.to(torch.long).contiguous()
+            K.mask_pack(attention_mask, ws["maskb"], B, L, ws["Lp"], out_t=want_t)
         vf = vis_feats.reshape(Mv, 2048)
         if vf.dtype == torch.float32:
             K.copy2d(vf.contiguous(), 2048, True, ws["img16"], 2048, Mv, 2048, 2048)
             img = ws["img16"]
         else:
             img = vf.contiguous()
-        vp = vis_pe.reshape(Mv, PE_DIM).contiguous()
-        K.copy2d(vp, PE_DIM, vp.dtype == torch.float32, ws["vpe_in"], PE_PAD, Mv, PE_DIM, PE_PAD)
+        if raw_regions:                     # raw boxes + class probabilities -> K-padded encoding (seq2seq_loader.py:338-351)
+            vis_pe.check(B, Nv)
+            K.vis_pe_prep(vis_pe.bbox, vis_pe.cls_prob.reshape(Mv, PE_DIM - 6), ws["vpe_in"], B, Nv, PE_DIM - 6, PE_PAD)
+        else:
+            vp = vis_pe.reshape(Mv, PE_DIM).contiguous()
+            K.copy2d(vp, PE_DIM, vp.dtype == torch.float32, ws["vpe_in"], PE_PAD, Mv, PE_DIM, PE_PAD)
         K.copy2d(self.P("vis_pe_embed.0.weight"), PE_DIM, False, ws["wpe_pad"], PE_PAD, H, PE_DIM, PE_PAD)
         st.batch = (img, input_ids.contiguous(), token_type_ids.contiguous(), masked_pos)
 
