@@ -218,11 +218,12 @@ typedef struct {
 } vlp_embed_fwd_args;
 int vlp_embed_fwd(const vlp_embed_fwd_args* a, void* stream);
 
-/* Backward of the splice: scatter-adds dpre into d_word_emb rows (fp16 packed atomics), d_pos_emb,
- * d_type_emb, and writes the region-row gradients.  d_vis_h = dpre * relu'(vis_h) * dropmask(vis),
- * d_vispe_h = dpre * relu'(vispe_h) * dropmask(vispe) (backward of ReLU+Dropout, modeling.py:1006-1007,
- * 1017-1018).  acc32 is f32 scratch of 64 * 8 * H floats (type-table partial sums); type_vocab <= 8.
+/* Backward of the splice: adds dpre into d_word_emb rows (no atomics: one owner per token id sums its rows in a fixed order in fp32, so
+ * the result is bitwise reproducible), d_pos_emb, d_type_emb, and writes the region-row gradients.
+ * d_vis_h = dpre * relu'(vis_h) * dropmask(vis), d_vispe_h = dpre * relu'(vispe_h) * dropmask(vispe) (backward of ReLU+Dropout,
+ * modeling.py:1006-1007, 1017-1018).  acc32 is f32 scratch of vlp_embed_bwd_workspace_floats(B, L, Nv, H) floats; type_vocab <= 8; H <= 2048.
  */
+int64_t vlp_embed_bwd_workspace_floats(int32_t B, int32_t L, int32_t Nv, int32_t H);
 typedef struct {
     const void* dpre;                                       /* [B*L, H] */
     const int64_t* input_ids; const int64_t* segment_ids;

@@ -120,6 +120,33 @@ def test_training_reduces_loss_and_checkpoint_round_trip(tmp_path):
     opt.load_state_dict(osd)
 
 
+def test_exact_resume_from_model_and_optimizer_checkpoint(tmp_path):
+    """N4: the optimizer checkpoint the reference left disabled (run_img2txt_dist.py:599) and the resume path (:310,:428-437):
+    2 epochs in one go == 1 epoch, process "restart", resume for epoch 2 -- bit for bit, with dropout on (the engine's mask-stream
+    position travels with the optimizer state) and the dynamic loss scaler's state."""
+    from vlp_amd import run_img2txt_dist as R
+    common = ["--bert_model", "bert-base-cased", "--from_scratch", "--fp16", "--enable_butd", "--len_vis_input", "100", "--new_segment_ids",
+              "--synthetic", "3", "--num_train_epochs", "2", "--train_batch_size", "4", "--max_len_b", "20", "--num_hidden_layers", "2",
+              "--learning_rate", "3e-4", "--warmup_proportion", "0.3", "--loss_scale", "0", "--seed", "7"]
+    a, b = os.path.join(tmp_path, "a"), os.path.join(tmp_path, "b")
+    R.main(common + ["--output_dir", a])
+    R.main(common + ["--output_dir", b, "--stop_after_epoch", "1"])
+    assert os.path.exists(os.path.join(b, "optim.1.bin")) and not os.path.exists(os.path.join(b, "model.2.bin"))
+    R.main(common + ["--output_dir", b])                   # finds model.1.bin + optim.1.bin and continues with epoch 2
+    sa, sb = torch.load(os.path.join(a, "model.2.bin")), torch.load(os.path.join(b, "model.2.bin"))
+    assert sa.keys() == sb.keys()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    oa, ob = torch.load(os.path.join(a, "optim.2.bin")), torch.load(os.path.join(b, "optim.2.bin"))
+    assert oa["cur_iter"] == ob["cur_iter"] == 6 and oa["cur_scale"] == ob["cur_scale"]
+    for x, y in zip(oa["fp32_groups_flat"] + oa["optimizer_state_dict"]["exp_avg"] + oa["optimizer_state_dict"]["exp_avg_sq"],
+                    ob["fp32_groups_flat"] + ob["optimizer_state_dict"]["exp_avg"] + ob["optimizer_state_dict"]["exp_avg_sq"]):
+        assert torch.equal(x, y) and not x.is_cuda
+    # and the one-epoch model differs from the two-epoch one (the second epoch really ran)
+    assert not torch.equal(torch.load(os.path.join(b, "model.1.bin"))["bert.encoder.layer.0.output.dense.weight"],
+                           sb["bert.encoder.layer.0.output.dense.weight"])
+
+
 def test_bert_adam_on_model_matches_reference_restatement():
     model, p0 = small_model()
     model.train()

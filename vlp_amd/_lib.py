@@ -139,6 +139,7 @@ SYMBOLS = {
     "vlp_logsoftmax_topk": (C.c_int, [vp, i64, i32, i32, i32, vp, i32, i32, vp, vp, vp]),
     "vlp_beam_select": (C.c_int, [C.POINTER(BeamSelectArgs), vp]),
     "vlp_kv_gather": (C.c_int, [vp, i64, vp, i64, vp, i32, i32, i32, i32, vp]),
+    "vlp_embed_bwd_workspace_floats": (C.c_int64, [i32, i32, i32, i32]),
     "vlp_mask_build": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "vlp_vis_pe_prep": (C.c_int, [C.POINTER(VisPePrepArgs), vp]),
     "vlp_sample_rows": (C.c_int, [vp, i64, i32, i32, C.c_uint64, C.c_uint32, vp, i64, vp, i64, vp]),
@@ -359,6 +360,10 @@ def embed_fwd(input_ids, segment_ids, word_emb, pos_emb, type_emb, vis_h, vispe_
     a = EmbedFwdArgs(ptr(input_ids), ptr(segment_ids), ptr(word_emb), ptr(pos_emb), ptr(type_emb), ptr(vis_h), ptr(vispe_h),
                      ptr(pre), B, L, Nv, H, word_emb.shape[0], type_emb.shape[0], ptr(position_ids), pos_emb.shape[0])
     _check(load().vlp_embed_fwd(C.byref(a), stream_ptr()))
+
+
+def embed_bwd_workspace_floats(B, L, Nv, H):
+    return int(load().vlp_embed_bwd_workspace_floats(B, L, Nv, H))
 
 
 def embed_bwd(dpre, input_ids, segment_ids, vis_h, vispe_h, d_word, d_pos, d_type, d_vis_h, d_vispe_h, acc32,

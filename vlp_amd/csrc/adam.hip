@@ -142,6 +142,10 @@ __global__ __launch_bounds__(256) void fused_adam_kernel(vlp_fused_adam_args a) 
             vv[e] = a.b2 * vv[e] + (1.f - a.b2) * sg * sg;
             const float denom = a.eps_inside_sqrt ? sqrtf(vv[e] + a.eps) : sqrtf(vv[e]) + a.eps;
             pp[e] = pp[e] - step_size * (mm[e] / denom + a.decay * pp[e]);
+            // the fp16 model copy is the rounding of the STORED fp32 master (apex: p_copy = (half) p).  Without the opaque copy the
+            // compiler folds the last fma and the conversion into v_fma_mixlo_f16 (one rounding of the exact fma), which differs from
+            // half(master) in double-rounding cases -- a resumed run, which can only rebuild the copy from the master, would diverge.
+            asm volatile("" : "+v"(pp[e]));
             o[e] = (f16)pp[e];
         }
         *reinterpret_cast<f32x4*>(a.p32 + i * 8) = (f32x4){pp[0], pp[1], pp[2], pp[3]};

@@ -52,10 +52,10 @@ extern "C" int vlp_embed_fwd(const vlp_embed_fwd_args* a, void* stream) {
     return VLP_OK;
 }
 
-// backward.  (1) one pass over dpre: region rows -> d_vis_h / d_vispe_h (through ReLU + dropout), token rows
-// -> packed fp16 atomics into d_word_emb (all-zero rows, i.e. padding, are skipped); (2) position table:
-// deterministic sum over the batch per token position; (3) type table: masked column sums (one register
-// accumulator per type) over row splits + a small reduce.  No float atomics.
+// backward.  (1) one pass over dpre: region rows -> d_vis_h / d_vispe_h (through ReLU + dropout); (1b) token rows -> d_word_emb by
+// embed_word_bwd_kernel (one owner per distinct id, row-ordered fp32 sums); (2) position table: deterministic sum over the batch per
+// token position; (3) type table: masked column sums (one register accumulator per type) over row splits + a small reduce.
+// No atomics anywhere: the whole backward is bitwise reproducible.
 #define EMB_TSPLITS 64
 #define EMB_MAXT 8
 __global__ __launch_bounds__(256) void embed_bwd_kernel(vlp_embed_bwd_args a, DropCtx dvis, DropCtx dvpe) {
@@ -88,15 +88,116 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(vlp_embed_bwd_args a, Dr
             }
             st8((f16*)a.d_vis_h + vr * a.H + c * 8, ov);
             st8((f16*)a.d_vispe_h + vr * a.H + c * 8, op);
-        } else {
-            const u32x4 bits = __builtin_bit_cast(u32x4, d);
-            if (((bits[0] | bits[1] | bits[2] | bits[3]) & 0x7fff7fffu) == 0u) continue;   // +-0 everywhere: nothing to add
-            int64_t id = a.input_ids[row];
-            id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
-            __half2* wdst = reinterpret_cast<__half2*>((f16*)a.d_word_emb + id * a.H + c * 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) unsafeAtomicAdd(wdst + e, __floats2half2_rn((float)d[2 * e], (float)d[2 * e + 1]));
         }
+        // token rows: see embed_word_bwd_kernel (deterministic, no atomics)
+    }
+}
+// d_word_emb[id] += sum of dpre over the token rows (l == 0 or l > Nv) whose input id is `id` -- without atomics, in a fixed order, so the
+// result is bitwise reproducible (the reference's nn.Embedding backward on the GPU is not).  Token rows are enumerated as
+// t = b*(L-Nv) + j (j = 0 -> l = 0, j >= 1 -> l = Nv + j); rows sharing an id form a chain ordered by t.
+//   pass 1 (one workgroup per token row): rank = number of earlier rows with the same id; every EWB_G-th row of a chain is a group
+//           leader and writes the fp32 sum of its group (itself + the next EWB_G-1 chain members, in order) to partial[t];
+//   pass 2 (one workgroup per token row, only chain heads act): sums the leaders' partials of its chain in order and adds them to
+//           d_word_emb[id] (single writer per id).
+// Long chains ([PAD] rows: ~2000 at B = 64) are thereby summed by ~60 workgroups in parallel instead of one.
+#define EWB_G 32
+#define EWB_LIST 1024
+struct EwbGeom {
+    const int64_t* ids;
+    int L, Nv, T, NT, vocab;
+    DEVFN int64_t row_of(int u) const { const int b = u / T, j = u - b * T; return (int64_t)b * L + (j == 0 ? 0 : Nv + j); }
+    DEVFN int id_of(int u) const { const int64_t id = ids[row_of(u)]; return (int)(id < 0 ? 0 : (id >= vocab ? vocab - 1 : id)); }
+};
+// ordered compaction of { u in [u0, min(u0+256, NT)) : pred(u) } behind list[n..]; returns the new n (uniform).  256 threads.
+template <typename Pred>
+DEVFN int ewb_compact(int* list, int* wcnt, int n, int u0, int NT, Pred pred) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int u = u0 + tid;
+    const bool m = u < NT && pred(u);
+    const uint64_t bal = __ballot(m);
+    if (lane == 0) wcnt[wv] = __popcll(bal);
+    __syncthreads();
+    int off = n;
+    for (int w = 0; w < wv; ++w) off += wcnt[w];
+    if (m) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = u;
+    n += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
+    return n;
+}
+__global__ __launch_bounds__(256) void embed_word_partial_kernel(EwbGeom g, const f16* dpre, int H, int* rank, float* partial) {
+    __shared__ int list[256 + EWB_G];
+    __shared__ int wcnt[4];
+    __shared__ float wsum[4];
+    const int tid = threadIdx.x, t = blockIdx.x;
+    const int id = g.id_of(t);
+    float c = 0.f;
+    for (int u = tid; u < t; u += 256) c += (g.id_of(u) == id) ? 1.f : 0.f;
+    c = wave_sum(c);
+    if ((tid & 63) == 0) wsum[tid >> 6] = c;
+    __syncthreads();
+    const int r = (int)(wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+    if (tid == 0) rank[t] = r;
+    if (r % EWB_G) return;
+    int n = 0;
+    for (int u0 = t; u0 < g.NT && n < EWB_G; u0 += 256) n = ewb_compact(list, wcnt, n, u0, g.NT, [&](int u) { return g.id_of(u) == id; });
+    n = min(n, EWB_G);
+    const int nch = H >> 3;
+    if (tid < nch) {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        int i = 0;
+        for (; i + 4 <= n; i += 4) {
+            f16x8 d[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] = ld8(dpre + g.row_of(list[i + k]) * H + tid * 8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)d[k][e];
+        }
+        for (; i < n; ++i) {
+            const f16x8 d = ld8(dpre + g.row_of(list[i]) * H + tid * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)d[e];
+        }
+        float* dst = partial + (int64_t)t * H + tid * 8;
+        *reinterpret_cast<f32x4*>(dst) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+        *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){acc[4], acc[5], acc[6], acc[7]};
+    }
+}
+__global__ __launch_bounds__(256) void embed_word_reduce_kernel(EwbGeom g, int H, const int* rank, const float* partial, f16* dword) {
+    __shared__ int list[EWB_LIST + 256];
+    __shared__ int wcnt[4];
+    const int tid = threadIdx.x, t = blockIdx.x;
+    if (rank[t] != 0) return;                            // only the first row of a chain owns the id
+    const int id = g.id_of(t);
+    const int nch = H >> 3;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    int start = t;
+    while (start < g.NT) {
+        int n = 0, u0 = start;
+        for (; u0 < g.NT && n < EWB_LIST; u0 += 256)
+            n = ewb_compact(list, wcnt, n, u0, g.NT, [&](int u) { return (rank[u] % EWB_G) == 0 && g.id_of(u) == id; });
+        start = u0;
+        if (tid < nch) {
+            for (int i = 0; i < n; ++i) {
+                const float* src = partial + (int64_t)list[i] * H + tid * 8;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc[e] += a0[e]; acc[4 + e] += a1[e]; }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < nch) {
+        f16* dst = dword + (int64_t)id * H + tid * 8;
+        f16x8 o = ld8(dst);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)((float)o[e] + acc[e]);
+        st8(dst, o);
     }
 }
 // d_pos_emb[l] += sum_b dpre[b,l]  for token positions (l == 0 or l > Nv)
@@ -168,9 +269,14 @@ __global__ void embed_bwd_type_reduce_kernel(const float* part, int nsplits, f16
     for (int p = 0; p < nsplits; ++p) s += part[((int64_t)p * EMB_MAXT + t) * H + c];
     dtyp[i] = (f16)((float)dtyp[i] + s);
 }
+extern "C" int64_t vlp_embed_bwd_workspace_floats(int32_t B, int32_t L, int32_t Nv, int32_t H) {
+    const int64_t nt = (int64_t)B * (L - Nv);
+    return (int64_t)EMB_TSPLITS * EMB_MAXT * H + nt * H + nt;
+}
 extern "C" int vlp_embed_bwd(const vlp_embed_bwd_args* a, void* stream) {
     VLP_CHECK_ARG(a && a->dpre && a->input_ids && a->segment_ids && a->d_word_emb && a->d_pos_emb && a->d_type_emb && a->acc32, "vlp_embed_bwd: null operand");
-    VLP_CHECK_ARG(a->H % 8 == 0 && a->B > 0 && a->L > 0 && a->type_vocab >= 1 && a->type_vocab <= EMB_MAXT, "vlp_embed_bwd: bad shape (type_vocab <= 8)");
+    VLP_CHECK_ARG(a->H % 8 == 0 && a->H <= 2048 && a->B > 0 && a->L > a->Nv && a->type_vocab >= 1 && a->type_vocab <= EMB_MAXT,
+                  "vlp_embed_bwd: bad shape (H % 8 == 0, H <= 2048, L > Nv, type_vocab <= 8)");
     VLP_CHECK_ARG(a->Nv == 0 || (a->vis_h && a->vispe_h && a->d_vis_h && a->d_vispe_h), "vlp_embed_bwd: region buffers");
     hipStream_t s = (hipStream_t)stream;
     const int64_t total = (int64_t)a->B * a->L * (a->H / 8);
@@ -179,6 +285,16 @@ extern "C" int vlp_embed_bwd(const vlp_embed_bwd_args* a, void* stream) {
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(256), 0, s, *a, make_drop(a->drop_p, a->seed, a->vis_stream),
                        make_drop(a->drop_p, a->seed, a->vispe_stream));
     VLP_CHECK_LAUNCH("vlp_embed_bwd");
+    {
+        EwbGeom g;
+        g.ids = a->input_ids; g.L = a->L; g.Nv = a->Nv; g.T = a->L - a->Nv; g.NT = a->B * g.T; g.vocab = a->vocab;
+        float* partial = a->acc32 + (int64_t)EMB_TSPLITS * EMB_MAXT * a->H;                 // behind the type-table partials
+        int* rank = reinterpret_cast<int*>(partial + (int64_t)g.NT * a->H);
+        hipLaunchKernelGGL(embed_word_partial_kernel, dim3(g.NT), dim3(256), 0, s, g, (const f16*)a->dpre, a->H, rank, partial);
+        VLP_CHECK_LAUNCH("vlp_embed_word_partial");
+        hipLaunchKernelGGL(embed_word_reduce_kernel, dim3(g.NT), dim3(256), 0, s, g, a->H, (const int*)rank, (const float*)partial, (f16*)a->d_word_emb);
+        VLP_CHECK_LAUNCH("vlp_embed_word_reduce");
+    }
     hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3(cdiv((int64_t)a->L * (a->H / 8), 256)), dim3(256), 0, s, (const f16*)a->dpre,
                        (f16*)a->d_pos_emb, a->B, a->L, a->Nv, a->H);
     VLP_CHECK_LAUNCH("vlp_embed_bwd_pos");

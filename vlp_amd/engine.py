@@ -236,7 +236,7 @@ class Engine(object):
             ws.update(NAp=NAp, vq_e=h(B, H), vq_a1=h(B, 2 * H), vq_logits=h(B, NAp), vq_dlogits=h(B, NAp), vq_dz1=h(B, 2 * H), vq_de=h(B, H))
         # backward scratch (shared by all layers)
         ws.update(dx=h(M, H), dx_alt=h(M, H), dpre=h(M, H), dpre_d=h(M, H), dz=h(M, I), dctx=h(M, H), dqkv=h(M, 3 * H),
-                  delta=f(B, A, L), d_vis_h=h(Mv, H), d_vispe_h=h(Mv, H), dz1v=h(Mv, 2048), dwpe_pad=h(H, PE_PAD), acc32=f(64 * 8 * H))
+                  delta=f(B, A, L), d_vis_h=h(Mv, H), d_vispe_h=h(Mv, H), dz1v=h(Mv, 2048), dwpe_pad=h(H, PE_PAD), acc32=f(K.embed_bwd_workspace_floats(B, L, Nv, H)))
         # dY operands of the weight-gradient GEMMs, double-buffered by layer parity: the wgrads of layer i run on a side stream
         # while the main stream already works on layer i-1
         ws["dyset"] = [{"dpre2": h(M, H), "dpre2_d": h(M, H), "dpre1": h(M, H), "dpre1_d": h(M, H), "dz": h(M, I), "dqkv": h(M, 3 * H)}

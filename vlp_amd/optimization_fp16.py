@@ -179,6 +179,8 @@ class FP16_Optimizer_State(object):
         inner["group_keys"] = list(self._group_key)
         sd["optimizer_state_dict"] = inner
         sd["fp32_groups_flat"] = [t.clone() for t in self.fp32_groups_flat]
+        # not in the reference's format: the engine's dropout stream position, so that a resumed run continues the SAME mask sequence
+        sd["vlp_rng"] = {"base_seed": self.engine.base_seed, "step_seed": self.engine.step_seed}
         return sd
 
     def load_state_dict(self, sd):
@@ -199,3 +201,5 @@ class FP16_Optimizer_State(object):
             cur.data.copy_(saved.data)
         for i, key in enumerate(self._group_key):       # refresh the fp16 model copy from the restored masters
             self.engine.flat[key].copy_(self.fp32_groups_flat[i])
+        if "vlp_rng" in sd:
+            self.engine.base_seed, self.engine.step_seed = int(sd["vlp_rng"]["base_seed"]), int(sd["vlp_rng"]["step_seed"])

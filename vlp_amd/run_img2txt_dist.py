@@ -46,6 +46,16 @@ def _get_max_epoch_model(output_dir):   # reference :33-43
     return max(both) if both else None
 
 
+def _to_cpu(x):
+    if torch.is_tensor(x):
+        return x.detach().cpu()
+    if isinstance(x, dict):
+        return {k: _to_cpu(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_to_cpu(v) for v in x)
+    return x
+
+
 def build_parser():
     p = argparse.ArgumentParser()
     # General (same names / defaults as the reference)
@@ -111,6 +121,7 @@ def build_parser():
     p.add_argument("--synthetic", type=int, default=0, metavar="STEPS_PER_EPOCH",
                    help="train on seeded synthetic batches (vlp_amd/synthetic.py) for this many steps per epoch")
     p.add_argument("--num_hidden_layers", type=int, default=None, help="override the config's depth (plumbing tests)")
+    p.add_argument("--stop_after_epoch", type=int, default=0, help="stop after this epoch (schedule still spans --num_train_epochs); 0 = off")
     p.add_argument("--log_every", type=int, default=100, help="steps between loss read-backs (each read-back is a host sync)")
     return p
 
@@ -254,14 +265,25 @@ def main(argv=None):
     steps_per_epoch = args.synthetic
     t_total = int(steps_per_epoch * args.num_train_epochs * 1. / args.gradient_accumulation_steps)
 
+    recover_step = _get_max_epoch_model(args.output_dir)     # :310: resume from the newest epoch that has model AND optimizer files
+    if recover_step:
+        logger.info("***** Recover model: %d *****", recover_step)
+        args.model_recover_path = os.path.join(args.output_dir, "model.{0}.bin".format(recover_step))
     model = build_model(args, device)
     if distributed:
         model = DDP(model, device_ids=[args.local_rank], output_device=args.local_rank, find_unused_parameters=True)
     optimizer = build_optimizer(args, model, t_total)
     global_step = 0
+    if recover_step:                                         # :428-437
+        logger.info("***** Recover optimizer: %d *****", recover_step)
+        optimizer.load_state_dict(torch.load(os.path.join(args.output_dir, "optim.{0}.bin".format(recover_step)), map_location=device))
+        if args.loss_scale == 0:
+            optimizer.dynamic_loss_scale = True
+        global_step = math.floor(recover_step * t_total * 1. / args.num_train_epochs)      # :337-338
     logger.info("***** Running training *****  batch %d, steps %d", args.train_batch_size, t_total)
     model.train()
-    for i_epoch in range(1, args.num_train_epochs + 1):
+    stop_after = args.stop_after_epoch if args.stop_after_epoch > 0 else args.num_train_epochs
+    for i_epoch in range((recover_step or 0) + 1, min(args.num_train_epochs, stop_after) + 1):
         t0 = time.time()
         losses = []
         for step, batch in enumerate(synthetic_batches(args, device, steps_per_epoch, args.global_rank)):
@@ -281,6 +303,9 @@ def main(argv=None):
                                                                         ["%.3f" % l for l in losses[-3:]]))
             to_save = model.module if hasattr(model, "module") else model
             torch.save(copy.deepcopy(to_save).cpu().state_dict(), os.path.join(args.output_dir, "model.{0}.bin".format(i_epoch)))
+            # the reference disabled this line ("need to sanitize state and ship everything back to cpu", :599); here the optimizer
+            # state is three flat fp32 buffers per group + a few scalars, shipped to the host as they are
+            torch.save(_to_cpu(optimizer.state_dict()), os.path.join(args.output_dir, "optim.{0}.bin".format(i_epoch)))
         if args.world_size > 1:
             torch.distributed.barrier()
     if distributed:
