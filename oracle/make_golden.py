@@ -227,7 +227,7 @@ def loader_raw_inputs(seed, Nv=100):
     return bbox, cls, feat, tokens
 
 
-def run_reference_loader_case(mode, n_tokens, seed, max_len_b=20, Nv=100):
+def run_reference_loader_case(mode, n_tokens, seed, max_len_b=20, Nv=100, always_truncate_tail=True, trunc_seg="b", max_pred=3, mask_prob=0.15):
     """Runs the UNMODIFIED Preprocess4Seq2seq.__call__ on the synthetic raw arrays, served by the in-memory h5py of ref_loader."""
     import random
     L = ref_loader.load_reference_loader()
@@ -238,8 +238,8 @@ def run_reference_loader_case(mode, n_tokens, seed, max_len_b=20, Nv=100):
     ref_loader.H5_REGISTRY["bbox.h5"] = {img_id: bbox.copy()}
     vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + ["w%d" % i for i in range(200)]
     idx = {w: i for i, w in enumerate(vocab)}
-    proc = L.Preprocess4Seq2seq(3, 0.15, vocab, lambda toks: [idx[t] for t in toks], max_len=Nv + max_len_b + 3, new_segment_ids=True,
-                                truncate_config={"max_len_b": max_len_b, "trunc_seg": "b", "always_truncate_tail": True}, mode=mode,
+    proc = L.Preprocess4Seq2seq(max_pred, mask_prob, vocab, lambda toks: [idx[t] for t in toks], max_len=Nv + max_len_b + 3, new_segment_ids=True,
+                                truncate_config={"max_len_b": max_len_b, "trunc_seg": trunc_seg, "always_truncate_tail": always_truncate_tail}, mode=mode,
                                 len_vis_input=Nv, enable_butd=True, region_bbox_file="bbox.h5", region_det_file_prefix="det")
     random.seed(seed)
     out = proc(("/data/" + img_id + ".jpg", ["w%d" % int(t) for t in tokens[:n_tokens]]))

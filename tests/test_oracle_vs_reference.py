@@ -162,3 +162,27 @@ def test_loader_oracle_vs_reference(mode, n_tokens, seed):
     assert vis_pe.shape == (100, 1607) and np.abs(vis_pe.numpy() - mine).max() < 2e-4
     assert np.array_equal(img.numpy(), feat.astype(np.float32)) and task_idx == (3 if mode == "s2s" else 0) and is_next == -1
     assert all(100 + 2 <= p < 100 + 2 + nb + 1 for p in masked_pos if p)
+
+
+@pytest.mark.parametrize("mode,n_tokens,seed,tail,max_pred,mask_prob", [("s2s", 9, 1, True, 3, 0.15), ("bi", 14, 2, True, 3, 0.15),
+                                                                      ("s2s", 31, 3, False, 5, 0.5), ("s2s", 40, 4, False, 8, 0.7)])
+def test_text_preprocessor_reproduces_reference_sample_stream(mode, n_tokens, seed, tail, max_pred, mask_prob):
+    """vlp_amd.data.TextPreprocessor (N3) against the UNMODIFIED Preprocess4Seq2seq.__call__ with the same `random` seed: identical
+    token ids, segment ids, masked positions / labels / weights (truncation coin flips, shuffle, 80/10/10 rule in the same order)."""
+    import random
+    from oracle.make_golden import loader_raw_inputs
+    from vlp_amd.data import TextPreprocessor
+    from vlp_amd.input_prep import MaskSpec
+    out, _, _, _, nb = _loader_case(mode, n_tokens, seed, always_truncate_tail=tail, max_pred=max_pred, mask_prob=mask_prob)
+    input_ids, segment_ids, input_mask, masked_ids, masked_pos, masked_weights, _, task_idx = out[:8]
+    tokens = loader_raw_inputs(seed)[3][:n_tokens]
+    vocab_size = 5 + 200                                   # [PAD] [UNK] [CLS] [SEP] [MASK] + w0..w199 in the reference-side test vocabulary
+    tp = TextPreprocessor(max_pred, mask_prob, vocab_size, cls_id=2, sep_id=3, mask_id=4, unk_id=1, max_len=123, max_len_b=20, mode=mode,
+                          len_vis_input=100, new_segment_ids=True, trunc_seg="b", always_truncate_tail=tail)
+    random.seed(seed)
+    t = tp([5 + int(w) for w in tokens])
+    assert t["input_ids"] == list(input_ids) and t["segment_ids"] == list(segment_ids)
+    assert t["masked_ids"] == list(masked_ids) and t["masked_pos"] == list(masked_pos) and t["masked_weights"] == list(masked_weights)
+    assert t["task_idx"] == task_idx and t["len_b"] == nb
+    spec = MaskSpec.from_lengths(t["len_a"], [t["len_b"]], [t["is_s2s"]])
+    assert torch.equal(spec.dense(123)[0], input_mask)

@@ -120,6 +120,9 @@ def build_parser():
     # vlp_amd additions
     p.add_argument("--synthetic", type=int, default=0, metavar="STEPS_PER_EPOCH",
                    help="train on seeded synthetic batches (vlp_amd/synthetic.py) for this many steps per epoch")
+    p.add_argument("--packed_features", default="", help="directory of a vlp_amd.data packed region store (write_packed / pack_from_h5)")
+    p.add_argument("--token_file", default="", help="json list of [image id, [caption token ids]] (captions pre-tokenised with the "
+                                                     "reference's WordPiece vocabulary); used with --packed_features")
     p.add_argument("--num_hidden_layers", type=int, default=None, help="override the config's depth (plumbing tests)")
     p.add_argument("--stop_after_epoch", type=int, default=0, help="stop after this epoch (schedule still spans --num_train_epochs); 0 = off")
     p.add_argument("--log_every", type=int, default=100, help="steps between loss read-backs (each read-back is a host sync)")
@@ -225,6 +228,23 @@ def train_step(model, optimizer, batch, lr_this_step, mask_image_regions=False, 
     return loss_tuple
 
 
+def build_packed_loader(args, device):
+    """Img2txtDataset + Preprocess4Seq2seq (vlp/seq2seq_loader.py:62-359, run_img2txt_dist.py:248-300) on a packed region store:
+    s2s / bidirectional preprocessors drawn per sample with --s2s_prob / --bi_prob, rank r of W takes every W-th example."""
+    from .data import BatchPrefetcher, PackedRegionStore, TextPreprocessor
+    store = PackedRegionStore(args.packed_features)
+    with open(args.token_file) as f:
+        examples = [(e[0], e[1]) for e in json.load(f)]
+    if args.world_size > 1:
+        examples = examples[max(args.global_rank, 0)::args.world_size]
+    kw = dict(max_pred=args.max_pred, mask_prob=args.mask_prob, vocab_size=KNOWN_VOCABS.get(args.bert_model, 28996), cls_id=synthetic.CLS_ID,
+              sep_id=synthetic.SEP_ID, mask_id=synthetic.MASK_ID, unk_id=synthetic.UNK_ID, max_len=args.max_seq_length, max_len_b=args.max_len_b,
+              len_vis_input=args.len_vis_input, new_segment_ids=args.new_segment_ids, trunc_seg=args.trunc_seg,
+              always_truncate_tail=args.always_truncate_tail)
+    return BatchPrefetcher(store, examples, args.train_batch_size, TextPreprocessor(mode="s2s", **kw), TextPreprocessor(mode="bi", **kw),
+                           s2s_prob=args.s2s_prob, device=device, seed=args.seed)
+
+
 def synthetic_batches(args, device, steps, rank):
     """Device-resident synthetic batches (a small rotating pool, seeded per rank like a DistributedSampler shard)."""
     pool = []
@@ -259,10 +279,15 @@ def main(argv=None):
     torch.manual_seed(args.seed)
     torch.cuda.manual_seed_all(args.seed)
 
-    if not args.synthetic:
-        raise NotImplementedError("the dataset pipeline (vlp/seq2seq_loader.py: h5 region features, tokenizer) is SURVEY.md 8(f) row N3 "
-                                  "and not built yet; run with --synthetic STEPS_PER_EPOCH")
-    steps_per_epoch = args.synthetic
+    loader = None
+    if args.packed_features:
+        loader = build_packed_loader(args, device)
+        steps_per_epoch = loader.steps
+    elif args.synthetic:
+        steps_per_epoch = args.synthetic
+    else:
+        raise NotImplementedError("give --packed_features DIR --token_file FILE (vlp_amd.data; the reference's h5 files are converted once "
+                                  "with vlp_amd.data.pack_from_h5) or --synthetic STEPS_PER_EPOCH; the tokenizer itself is out of scope")
     t_total = int(steps_per_epoch * args.num_train_epochs * 1. / args.gradient_accumulation_steps)
 
     recover_step = _get_max_epoch_model(args.output_dir)     # :310: resume from the newest epoch that has model AND optimizer files
@@ -286,7 +311,9 @@ def main(argv=None):
     for i_epoch in range((recover_step or 0) + 1, min(args.num_train_epochs, stop_after) + 1):
         t0 = time.time()
         losses = []
-        for step, batch in enumerate(synthetic_batches(args, device, steps_per_epoch, args.global_rank)):
+        if loader is not None:
+            loader.seed = args.seed + i_epoch                                                         # new shuffle every epoch
+        for step, batch in enumerate(loader if loader is not None else synthetic_batches(args, device, steps_per_epoch, args.global_rank)):
             acc = (step + 1) % args.gradient_accumulation_steps != 0
             lr = args.learning_rate * warmup_linear(global_step / t_total, args.warmup_proportion)
             lt = train_step(model, optimizer, batch, lr, drop_worst_ratio=args.max_drop_worst_ratio if i_epoch > args.drop_after else 0,
