@@ -22,8 +22,8 @@ M32 = 0xFFFFFFFF
 # ---- python mirror of csrc/common.h's dropout hash (uint32 arithmetic on int64 tensors) -----------------
 def _mix32(x):
     x = x & M32
-    x = x ^ (x >> 16); x = (x * 0x7feb352d) & M32
-    x = x ^ (x >> 15); x = (x * 0x846ca68b) & M32
+    x = x ^ (x >> 15); x = ((x & 0xFFFFFF) * 0xd3833f + (x >> 7)) & M32
+    x = x ^ (x >> 13); x = ((x & 0xFFFFFF) * 0x7a6b35 + (x >> 9)) & M32
     x = x ^ (x >> 16)
     return x
 
@@ -33,18 +33,19 @@ def _mul64(a, b):
 
 
 def drop_mult_ref(p, seed, stream, rows, cols, device=DEV):
-    """[len(rows), len(cols)] multiplier tensor (0 or 1/(1-p)) for elements (row, col)."""
+    """[len(rows), len(cols)] multiplier tensor (0 or 1/(1-p)) for elements (row, col): one hash per column pair, the even column
+    takes the low 16 bits, the odd one the high 16 bits, dropped when that half is below round(p * 65536)."""
     if p <= 0:
         return torch.ones(len(rows), len(cols), device=device)
     s = (_mul64(seed, 0x9E3779B97F4A7C15) + _mul64(stream, 0xD1B54A32D192ED03) + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF
     k0, k1 = s & M32, ((s >> 32) & M32) | 1
-    t = p * 4294967296.0
-    thresh = 0xFFFFFFFF if t >= 4294967295.0 else int(t)
+    thresh = min(65535, max(1, int(p * 65536.0 + 0.5)))
     rows = torch.as_tensor(rows, dtype=torch.int64, device=device)
     cols = torch.as_tensor(cols, dtype=torch.int64, device=device)
     rk = (_mix32((rows & M32) ^ k0) + _mix32(((rows >> 32) & M32) + k1)) & M32
-    h = _mix32((rk[:, None] + (cols[None, :] * 0x9E3779B9 & M32)) & M32)
-    return torch.where(h < thresh, torch.zeros((), device=device), torch.full((), 1.0 / (1.0 - p), device=device))
+    h = _mix32((rk[:, None] + ((cols[None, :] >> 1) * 0x9E3779B9 & M32)) & M32)
+    half = torch.where((cols[None, :] & 1) == 1, h >> 16, h & 0xFFFF)
+    return torch.where(half < thresh, torch.zeros((), device=device), torch.full((), 1.0 / (1.0 - p), device=device))
 
 
 def rel(a, b):

@@ -13,7 +13,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvlp_hip.so")
+LIB_PATH = os.environ.get("VLP_HIP_LIB") or os.path.join(_HERE, "libvlp_hip.so")      # VLP_HIP_LIB: A/B runs against another build of the SAME ABI
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 MUL_NONE, MUL_GELU_GRAD, MUL_RELU_MASK = 0, 1, 2

@@ -159,14 +159,21 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(AttnParams p) 
         f16x8 pf[NT / 2];
         // dropout element = (row (b, h, q), col key)
         const uint32_t rk = p.drop.thresh ? drop_rowkey(p.drop, ((uint64_t)b * p.heads + h) * (uint64_t)Lq + (uint64_t)qc) : 0u;
+        // columns (keys) of tile t held by this lane: 16t + 4g + {0..3} = two hash pairs; pair key advances by 8*PHI per tile
+        const uint32_t pk0 = drop_pairkey(rk, (uint32_t)(4 * gq));
 #pragma unroll
         for (int u = 0; u < NT / 2; ++u)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int t = 2 * u + (e >> 2), r = e & 3;
-                float pv = s[t][r] * inv;
-                if (p.drop.thresh) pv *= drop_mult(p.drop, rk, (uint32_t)(t * 16 + 4 * gq + r));
-                pf[u][e] = (f16)pv;
+            for (int hh = 0; hh < 2; ++hh) {
+                const int t = 2 * u + hh;
+                float m4[4] = {1.f, 1.f, 1.f, 1.f};
+                if (p.drop.thresh) {
+                    const uint32_t h0 = mix32(pk0 + (uint32_t)(8 * t) * VLP_PHI), h1 = mix32(pk0 + (uint32_t)(8 * t + 1) * VLP_PHI);
+                    m4[0] = drop_mult_h(p.drop, h0, 0u); m4[1] = drop_mult_h(p.drop, h0, 1u);
+                    m4[2] = drop_mult_h(p.drop, h1, 0u); m4[3] = drop_mult_h(p.drop, h1, 1u);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pf[u][hh * 4 + r] = (f16)(s[t][r] * inv * m4[r]);
             }
 
         // O^T tiles: rows = head-dim 16n + 4g + reg, col = query
@@ -233,6 +240,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams 
 
         const uint8_t* mrow = p.mask + ((int64_t)b * L + qc) * p.Lp;
         const uint32_t rk = p.drop.thresh ? drop_rowkey(p.drop, ((uint64_t)b * p.heads + h) * (uint64_t)L + (uint64_t)qc) : 0u;
+        const uint32_t pk0 = drop_pairkey(rk, (uint32_t)(4 * gq));
         f16x8 dsf[NT / 2];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -246,11 +254,16 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams 
             }
             float ma[4];
             mask4(mrow, t * 16 + 4 * gq, p.Lp, ma);
+            float m4[4] = {1.f, 1.f, 1.f, 1.f};
+            if (p.drop.thresh) {
+                const uint32_t h0 = mix32(pk0 + (uint32_t)(8 * t) * VLP_PHI), h1 = mix32(pk0 + (uint32_t)(8 * t + 1) * VLP_PHI);
+                m4[0] = drop_mult_h(p.drop, h0, 0u); m4[1] = drop_mult_h(p.drop, h0, 1u);
+                m4[2] = drop_mult_h(p.drop, h1, 0u); m4[3] = drop_mult_h(p.drop, h1, 1u);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pr = __expf(s[r] * p.scale + ma[r] - lse);     // 0 for keys >= L (-inf)
-                float dpr = dp[r];
-                if (p.drop.thresh) dpr *= drop_mult(p.drop, rk, (uint32_t)(t * 16 + 4 * gq + r));
+                const float dpr = dp[r] * m4[r];
                 const float ds = pr * (dpr - dl) * p.scale;
                 dsf[t >> 1][(t & 1) * 4 + r] = (f16)ds;
             }
@@ -285,6 +298,7 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_bwd_dkv_kernel(AttnParams
     f16* dOs = Qs + LP * HD;                        // [LP][64] swizzled
     float* lse_s = reinterpret_cast<float*>(dOs + LP * HD);   // [LP]
     float* dl_s = lse_s + LP;                                  // [LP]
+    uint32_t* rk_s = reinterpret_cast<uint32_t*>(dl_s + LP);   // [LP] dropout row keys of the queries
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
@@ -301,6 +315,7 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_bwd_dkv_kernel(AttnParams
         const int64_t stat = ((int64_t)b * p.heads + h) * L + min(i, L - 1);
         lse_s[i] = p.lse[stat];
         dl_s[i] = p.delta[stat];
+        rk_s[i] = p.drop.thresh ? drop_rowkey(p.drop, (uint64_t)stat) : 0u;      // dropout element = (row (b, h, q), col key)
     }
     __syncthreads();
 
@@ -319,8 +334,7 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_bwd_dkv_kernel(AttnParams
         const uint8_t* mtr = p.mask_t + ((int64_t)b * p.Lp + min(key, p.Lp - 1)) * p.Lp + 4 * g;
         auto mload = [&](int qt) -> uint32_t { return (qt * 16 < p.Lp) ? *reinterpret_cast<const uint32_t*>(mtr + 16 * qt) : 0x02020202u; };
         uint32_t mcur[2] = {mload(0), mload(1)};
-        const uint32_t rk_row0 = 0;
-        (void)rk_row0;
+        const uint32_t keyphi = ((uint32_t)key >> 1) * VLP_PHI, kodd = (uint32_t)key & 1u;
         f32x4 dk[4], dv[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) { dk[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -347,14 +361,14 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_bwd_dkv_kernel(AttnParams
                 const int q0 = qt * 16 + 4 * gq;
                 const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_s + q0);
                 const f32x4 dl4 = *reinterpret_cast<const f32x4*>(dl_s + q0);
+                const u32x4 rk4 = *reinterpret_cast<const u32x4*>(rk_s + q0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const uint32_t mv = (mcur[half] >> (8 * r)) & 0xffu;
                     const float madd = mv == 1u ? 0.f : (mv == 0u ? -10000.f : -INFINITY);
                     const float pr = __expf(s[r] * p.scale + madd - lse4[r]);     // excluded (padding) -> exp(-inf) = 0
                     float mult = 1.f;
-                    if (p.drop.thresh)
-                        mult = drop_mult(p.drop, drop_rowkey(p.drop, ((uint64_t)b * p.heads + h) * (uint64_t)L + (uint64_t)(q0 + r)), (uint32_t)key);
+                    if (p.drop.thresh) mult = drop_mult_h(p.drop, mix32(rk4[r] + keyphi), kodd);
                     pdf[half * 4 + r] = (f16)(pr * mult);
                     dsf[half * 4 + r] = (f16)(pr * (dp[r] * mult - dl4[r]) * p.scale);
                 }
@@ -465,7 +479,7 @@ extern "C" int vlp_attn_bwd(const vlp_attn_bwd_args* a, void* stream) {
     p.drop = make_drop(a->dropout_p, a->seed, a->rng_stream);
     const int LP = lp_of(a->L);
     const size_t smem_dq = (size_t)2 * LP * HD * 2;
-    const size_t smem_dkv = (size_t)2 * LP * HD * 2 + (size_t)2 * LP * 4;
+    const size_t smem_dkv = (size_t)2 * LP * HD * 2 + (size_t)3 * LP * 4;
     dim3 grid(a->B * a->heads), block(ATT_THREADS);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_BWD(NT_)                                                                                              \

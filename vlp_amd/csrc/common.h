@@ -37,14 +37,20 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // mask instead of storing it.  (The reference uses torch's Philox stream, which cannot be matched
 // bit-for-bit anyway -- parity tests run with p = 0; see DESIGN.md.)
 // ---------------------------------------------------------------------------------------------
-DEVFN uint32_t mix32(uint32_t x) {   // "lowbias32" finalizer
-    x ^= x >> 16; x *= 0x7feb352du;
-    x ^= x >> 15; x *= 0x846ca68bu;
+// Mixer: two rounds of xorshift + 24-bit multiply-add.  Every instruction is full rate on CDNA4 (v_mad_u32_u24), whereas the
+// 32-bit multiplies of the usual murmur / lowbias32 finalizers run at quarter rate -- with one hash per element those multiplies were
+// the single largest VALU cost of the attention kernels.  Avalanche measured over 2e5 random inputs: every output bit flips with
+// probability 0.5 +- 0.008 for every input bit (lowbias32: +- 0.004); keep-rate, adjacent-element and 2-D autocorrelation of the
+// resulting masks are at the sampling-noise level (tools/mixer_eval.py).
+DEVFN uint32_t mix32(uint32_t x) {
+    x ^= x >> 15; x = __umul24(x, 0xd3833fu) + (x >> 7);
+    x ^= x >> 13; x = __umul24(x, 0x7a6b35u) + (x >> 9);
     x ^= x >> 16;
     return x;
 }
+#define VLP_PHI 0x9E3779B9u
 struct DropCtx {
-    uint32_t k0, k1, thresh;   // drop when hash < thresh
+    uint32_t k0, k1, thresh;   // 16-bit threshold: an element is dropped when its 16-bit hash half < thresh (0 = dropout off)
     float scale;               // 1/(1-p)
 };
 static inline DropCtx make_drop(float p, uint64_t seed, uint32_t stream) {
@@ -52,21 +58,36 @@ static inline DropCtx make_drop(float p, uint64_t seed, uint32_t stream) {
     uint64_t s = seed * 0x9E3779B97F4A7C15ull + (uint64_t)stream * 0xD1B54A32D192ED03ull + 0x632BE59BD9B4E019ull;
     d.k0 = (uint32_t)s;
     d.k1 = (uint32_t)(s >> 32) | 1u;
-    double t = (double)p * 4294967296.0;
-    d.thresh = p <= 0.f ? 0u : (t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t);
+    double t = (double)p * 65536.0 + 0.5;
+    d.thresh = p <= 0.f ? 0u : (t >= 65535.0 ? 65535u : (t < 1.0 ? 1u : (uint32_t)t));
     d.scale = p <= 0.f ? 1.f : 1.f / (1.f - p);
     return d;
 }
-// The mask of element (row, col) of a logical 2-D tensor: a 32-bit row key (computed once per row) mixed
-// with the column.  Forward and backward of an op must agree on what (row, col) mean -- each kernel
-// documents it.
+// The mask of element (row, col) of a logical 2-D tensor: a 32-bit row key (computed once per row) mixed with the column PAIR
+// col >> 1; the even column takes the low 16 bits of the hash, the odd one the high 16 bits (drop probability resolution 2^-16).
+// Forward and backward of an op must agree on what (row, col) mean -- each kernel documents it.
 DEVFN uint32_t drop_rowkey(const DropCtx& d, uint64_t row) {
     return mix32((uint32_t)row ^ d.k0) + mix32((uint32_t)(row >> 32) + d.k1);
 }
-// returns the multiplier (0 or 1/(1-p))
+// pair key of columns (2j, 2j+1): kernels that walk consecutive columns compute it once and add VLP_PHI per pair
+DEVFN uint32_t drop_pairkey(uint32_t rowkey, uint32_t col) { return rowkey + (col >> 1) * VLP_PHI; }
+// multiplier (0 or 1/(1-p)) of the even (odd = 0) / odd (odd = 1) column of a hashed pair
+DEVFN float drop_mult_h(const DropCtx& d, uint32_t h, uint32_t odd) {
+    const uint32_t v = odd ? (h >> 16) : (h & 0xffffu);
+    return v < d.thresh ? 0.f : d.scale;
+}
 DEVFN float drop_mult(const DropCtx& d, uint32_t rowkey, uint32_t col) {
-    const uint32_t h = mix32(rowkey + col * 0x9E3779B9u);
-    return h < d.thresh ? 0.f : d.scale;
+    return drop_mult_h(d, mix32(drop_pairkey(rowkey, col)), col & 1u);
+}
+// 8 consecutive columns starting at the (even) column col0: 4 hashes
+DEVFN void drop_mult8(const DropCtx& d, uint32_t rowkey, uint32_t col0, float* vv) {
+    const uint32_t base = drop_pairkey(rowkey, col0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t h = mix32(base + (uint32_t)j * VLP_PHI);
+        vv[2 * j] *= drop_mult_h(d, h, 0u);
+        vv[2 * j + 1] *= drop_mult_h(d, h, 1u);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

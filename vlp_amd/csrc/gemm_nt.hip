@@ -236,8 +236,7 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, ((VARIANT == 2 || B
                 }
             }
             if (p.drop.thresh) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) vv[j] *= drop_mult(p.drop, rkey, (uint32_t)(nc + j));
+                drop_mult8(p.drop, rkey, (uint32_t)nc, vv);
             }
             if (p.residual) {
                 f16x8 r = ld8(p.residual + (int64_t)m * p.ldr + nc);

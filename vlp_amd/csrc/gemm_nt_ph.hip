@@ -78,8 +78,7 @@ DEVFN void nt_epilogue8(const GemmNtParams& p, int m, int nc, float* vv, uint32_
         }
     }
     if (p.drop.thresh) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) vv[j] *= drop_mult(p.drop, rkey, (uint32_t)(nc + j));
+        drop_mult8(p.drop, rkey, (uint32_t)nc, vv);
     }
     if (p.residual) {
         const f16x8 r = ld8(p.residual + (int64_t)m * p.ldr + nc);

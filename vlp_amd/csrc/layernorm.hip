@@ -56,12 +56,10 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(
             const int c = lane + 64 * j;
             if (c < nch) {
                 f16x8 gv = ld8(gamma + c * 8), bv = ld8(beta + c * 8), o;
+                float m8[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+                if (drop.thresh) drop_mult8(drop, rkey, (uint32_t)(c * 8), m8);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float t = (float)gv[e] * ((v[j][e] - mu) * rs) + (float)bv[e];
-                    if (drop.thresh) t *= drop_mult(drop, rkey, (uint32_t)(c * 8 + e));
-                    o[e] = (f16)t;
-                }
+                for (int e = 0; e < 8; ++e) o[e] = (f16)(((float)gv[e] * ((v[j][e] - mu) * rs) + (float)bv[e]) * m8[e]);
                 st8(yr + c * 8, o);
             }
         }
@@ -143,10 +141,11 @@ __global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(
             const int c = lane + 64 * j;
             if (c < nch) {
                 const f16x8 xv = xc[j], dv = dc[j];
+                float m8[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+                if (dyd.thresh) drop_mult8(dyd, rk_dy, (uint32_t)(c * 8), m8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    float dd = (float)dv[e];
-                    if (dyd.thresh) dd *= drop_mult(dyd, rk_dy, (uint32_t)(c * 8 + e));
+                    const float dd = (float)dv[e] * m8[e];
                     xh[j][e] = ((float)xv[e] - mu) * rs;
                     dg[j][e] += dd * xh[j][e];
                     db[j][e] += dd;
@@ -166,11 +165,13 @@ __global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(
             const int c = lane + 64 * j;
             if (c < nch) {
                 f16x8 o, od;
+                float m8[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+                if (dxd) drop_mult8(outd, rk_out, (uint32_t)(c * 8), m8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float t = rs * (d[j][e] - s1 - xh[j][e] * s2);
                     o[e] = (f16)t;
-                    if (dxd) od[e] = (f16)(t * drop_mult(outd, rk_out, (uint32_t)(c * 8 + e)));
+                    od[e] = (f16)(t * m8[e]);
                 }
                 st8(dx + (int64_t)row * lddx + c * 8, o);
                 if (dxd) st8(dxd + (int64_t)row * lddxd + c * 8, od);
