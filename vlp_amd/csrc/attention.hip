@@ -21,8 +21,12 @@
 #include "common.h"
 
 #define HD 64            // head dim
-#define ATT_THREADS 256
+#define ATT_THREADS 256         // dQ kernel (240 VGPRs: 2 workgroups of 4 waves per CU)
 #define ATT_WAVES 4
+// forward and dK/dV kernels fit 128 VGPRs: 8 waves per workgroup, 2 workgroups per CU -> 4 waves per SIMD to hide the global / LDS
+// latency chain of a tile, and the 11 tiles of L = 167 take 2 rounds over the waves instead of 3
+#define ATT_THREADS8 512
+#define ATT_WAVES8 8
 
 DEVFN int swzk(int r) { return r & 7; }
 
@@ -47,8 +51,8 @@ struct AttnParams {
 
 // ---- LDS staging helpers ---------------------------------------------------------------------
 // row-major, 128-B rows, chunk-swizzled: dst[key][64]; rows >= L are zero.
-DEVFN void stage_rowmajor(f16* dst, const f16* src, int64_t ld, int L, int Lp, int tid) {
-    for (int idx = tid; idx < Lp * 8; idx += ATT_THREADS) {
+DEVFN void stage_rowmajor(f16* dst, const f16* src, int64_t ld, int L, int Lp, int tid, int nthreads = ATT_THREADS) {
+    for (int idx = tid; idx < Lp * 8; idx += nthreads) {
         const int r = idx >> 3, c = idx & 7;
         u32x4 v = (u32x4){0, 0, 0, 0};
         if (r < L) v = *reinterpret_cast<const u32x4*>(src + (int64_t)r * ld + c * 8);
@@ -82,11 +86,35 @@ DEVFN void mask4(const uint8_t* mrow, int key0, int Lp, float out[4]) {
     }
 }
 
+// log2-domain variant used by the kernels: out[e] = c0 + c1 * [byte == 1] (byte in {0, 1}), -inf for byte 2.  c1 = 10000*log2(e), c0 =
+// -10000*log2(e) (+ a per-row offset such as -lse).  `full` (uniform) says that no byte of the word can be 2: one v_cvt_f32_ubyteN and
+// one fma per element instead of shift / compare / select chains.
+#define LOG2E_F 1.4426950408889634f
+#define LN2_F 0.6931471805599453f
+#define MASK_C1 (10000.0f * LOG2E_F)
+// 4 mask bytes of one row at columns key0..key0+3, branch-free (the address is clamped into the row; columns past the row read as 2)
+DEVFN uint32_t mask_word(const uint8_t* mrow, int key0, int Lp) {
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(mrow + min(key0, Lp - 4));
+    return key0 < Lp ? w : 0x02020202u;
+}
+DEVFN void mask4w(uint32_t w, bool full, float c0, float out[4]) {
+    if (full) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = fmaf((float)((w >> (8 * e)) & 0xffu), MASK_C1, c0);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t v = (w >> (8 * e)) & 0xffu;
+            out[e] = v == 1u ? c0 + MASK_C1 : (v == 0u ? c0 : -INFINITY);
+        }
+    }
+}
+
 // =================================================================================================
 // forward
 // =================================================================================================
 template <int NT>   // NT = LP / 16 key tiles (4, 8, 12 or 16)
-__global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(ATT_THREADS8, NT <= 12 ? 4 : 2) void attn_fwd_kernel(AttnParams p) {   // (threads, min waves per SIMD)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int LP = NT * 16;
     f16* Ks = reinterpret_cast<f16*>(smem_raw);            // [LP][64] swizzled
@@ -101,12 +129,12 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(AttnParams p) 
     const f16* kbase = p.k + (int64_t)b * p.bs_kv * p.ld_kv + h * HD;
     const f16* vbase = p.v + (int64_t)b * p.bs_kv * p.ld_kv + h * HD;
 
-    stage_rowmajor(Ks, kbase, p.ld_kv, L, LP, tid);
-    stage_rowmajor(Vs, vbase, p.ld_kv, L, LP, tid);
+    stage_rowmajor(Ks, kbase, p.ld_kv, L, LP, tid, ATT_THREADS8);
+    stage_rowmajor(Vs, vbase, p.ld_kv, L, LP, tid, ATT_THREADS8);
     __syncthreads();
 
     const int nqt = (Lq + 15) / 16;
-    for (int qt = wid; qt < nqt; qt += ATT_WAVES) {
+    for (int qt = wid; qt < nqt; qt += ATT_WAVES8) {
         const int q = qt * 16 + li;             // this lane's query (column of every transposed tile)
         const int qc = min(q, Lq - 1);
         int gq = g;                             // opaque copy: keeps per-key index math inside the loop (no LICM + spills)
@@ -116,6 +144,11 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(AttnParams p) 
         qf[0] = ld8(qrow + g * 8);
         qf[1] = ld8(qrow + 32 + g * 8);
 
+        // mask words of this query for all key tiles: independent loads issued before the MFMAs (one L2 round trip, not NT)
+        const uint8_t* mrow = p.mask + ((int64_t)b * Lq + qc) * p.Lp;
+        uint32_t mw[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) mw[t] = mask_word(mrow, t * 16 + 4 * gq, p.Lp);
         // S^T tiles: rows = keys 16t + 4g + reg, col = query
         f32x4 s[NT];
 #pragma unroll
@@ -128,15 +161,16 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(AttnParams p) 
                 s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], s[t], 0, 0, 0);
             }
         }
-        const uint8_t* mrow = p.mask + ((int64_t)b * Lq + qc) * p.Lp;
+        // scores in the log2 domain: s2 = s * scale * log2(e) + mask term; softmax = exp2(s2 - max) / sum
+        const float sc2 = p.scale * LOG2E_F;
         float mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float ma[4];
-            mask4(mrow, t * 16 + 4 * gq, p.Lp, ma);
+            mask4w(mw[t], t * 16 + 16 <= L, -MASK_C1, ma);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                s[t][r] = s[t][r] * p.scale + ma[r];
+                s[t][r] = fmaf(s[t][r], sc2, ma[r]);
                 mx = fmaxf(mx, s[t][r]);
             }
         }
@@ -147,15 +181,16 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(AttnParams p) 
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                s[t][r] = __expf(s[t][r] - mx);
+                s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - mx);
                 sum += s[t][r];
             }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.f / sum;
-        if (p.lse && g == 0 && q < Lq) p.lse[((int64_t)b * p.heads + h) * Lq + q] = mx + __logf(sum);
+        // the normalisation and the dropout scale 1/(1-p) are applied to the 16 outputs of the lane instead of its 4*NT probabilities
+        const float inv = p.drop.scale / sum;
+        if (p.lse && g == 0 && q < Lq) p.lse[((int64_t)b * p.heads + h) * Lq + q] = (mx + __builtin_amdgcn_logf(sum)) * LN2_F;
 
-        // P^T (normalised, dropout applied) as fp16 B-operand fragments: pair u = tiles (2u, 2u+1)
+        // P^T (UNnormalised exp2 values in (0, 1], dropped entries zeroed) as fp16 B-operand fragments: pair u = tiles (2u, 2u+1)
         f16x8 pf[NT / 2];
         // dropout element = (row (b, h, q), col key)
         const uint32_t rk = p.drop.thresh ? drop_rowkey(p.drop, ((uint64_t)b * p.heads + h) * (uint64_t)Lq + (uint64_t)qc) : 0u;
@@ -166,14 +201,16 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(AttnParams p) 
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int t = 2 * u + hh;
-                float m4[4] = {1.f, 1.f, 1.f, 1.f};
                 if (p.drop.thresh) {
                     const uint32_t h0 = mix32(pk0 + (uint32_t)(8 * t) * VLP_PHI), h1 = mix32(pk0 + (uint32_t)(8 * t + 1) * VLP_PHI);
-                    m4[0] = drop_mult_h(p.drop, h0, 0u); m4[1] = drop_mult_h(p.drop, h0, 1u);
-                    m4[2] = drop_mult_h(p.drop, h1, 0u); m4[3] = drop_mult_h(p.drop, h1, 1u);
-                }
+                    pf[u][hh * 4 + 0] = (f16)(((h0 & 0xffffu) < p.drop.thresh) ? 0.f : s[t][0]);
+                    pf[u][hh * 4 + 1] = (f16)(((h0 >> 16) < p.drop.thresh) ? 0.f : s[t][1]);
+                    pf[u][hh * 4 + 2] = (f16)(((h1 & 0xffffu) < p.drop.thresh) ? 0.f : s[t][2]);
+                    pf[u][hh * 4 + 3] = (f16)(((h1 >> 16) < p.drop.thresh) ? 0.f : s[t][3]);
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pf[u][hh * 4 + r] = (f16)(s[t][r] * inv * m4[r]);
+                    for (int r = 0; r < 4; ++r) pf[u][hh * 4 + r] = (f16)s[t][r];
+                }
             }
 
         // O^T tiles: rows = head-dim 16n + 4g + reg, col = query
@@ -184,7 +221,7 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(AttnParams p) 
             for (int u = 0; u < NT / 2; ++u)
                 o = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(Vs, 32 * u, 32 * u + 16, 16 * n, g, li), pf[u], o, 0, 0, 0);
             if (q < Lq) {
-                f16x4 ov = (f16x4){(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
+                f16x4 ov = (f16x4){(f16)(o[0] * inv), (f16)(o[1] * inv), (f16)(o[2] * inv), (f16)(o[3] * inv)};
                 st4(p.ctx + ((int64_t)b * Lq + q) * p.ld_ctx + h * HD + n * 16 + 4 * g, ov);
             }
         }
@@ -239,8 +276,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams 
         if (g == 0 && q < L) p.delta[stat] = dl;
 
         const uint8_t* mrow = p.mask + ((int64_t)b * L + qc) * p.Lp;
+        uint32_t mw[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) mw[t] = mask_word(mrow, t * 16 + 4 * gq, p.Lp);
         const uint32_t rk = p.drop.thresh ? drop_rowkey(p.drop, ((uint64_t)b * p.heads + h) * (uint64_t)L + (uint64_t)qc) : 0u;
         const uint32_t pk0 = drop_pairkey(rk, (uint32_t)(4 * gq));
+        const float sc2 = p.scale * LOG2E_F, c0 = -MASK_C1 - lse * LOG2E_F;      // P = exp2(s * sc2 + mask term - lse * log2(e))
         f16x8 dsf[NT / 2];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -253,7 +294,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams 
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld8(Vs + off), dof[ks], dp, 0, 0, 0);
             }
             float ma[4];
-            mask4(mrow, t * 16 + 4 * gq, p.Lp, ma);
+            mask4w(mw[t], t * 16 + 16 <= L, c0, ma);
             float m4[4] = {1.f, 1.f, 1.f, 1.f};
             if (p.drop.thresh) {
                 const uint32_t h0 = mix32(pk0 + (uint32_t)(8 * t) * VLP_PHI), h1 = mix32(pk0 + (uint32_t)(8 * t + 1) * VLP_PHI);
@@ -262,7 +303,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams 
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pr = __expf(s[r] * p.scale + ma[r] - lse);     // 0 for keys >= L (-inf)
+                const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, ma[r]));     // 0 for keys >= L (-inf)
                 const float dpr = dp[r] * m4[r];
                 const float ds = pr * (dpr - dl) * p.scale;
                 dsf[t >> 1][(t & 1) * 4 + r] = (f16)ds;
@@ -291,7 +332,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams 
 // loads of a key tile are issued before its query loop.
 // =================================================================================================
 template <int NT>
-__global__ __launch_bounds__(ATT_THREADS, 3) void attn_bwd_dkv_kernel(AttnParams p) {
+__global__ __launch_bounds__(ATT_THREADS8, 4) void attn_bwd_dkv_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int LP = NT * 16;
     f16* Qs = reinterpret_cast<f16*>(smem_raw);     // [LP][64] swizzled
@@ -309,18 +350,18 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_bwd_dkv_kernel(AttnParams
     const f16* vbase = qbase + 2 * p.H;
     const f16* dobase = p.dctx + (int64_t)b * L * p.ld_dctx + h * HD;
 
-    stage_rowmajor(Qs, qbase, p.ld_qkv, L, LP, tid);
-    stage_rowmajor(dOs, dobase, p.ld_dctx, L, LP, tid);
-    for (int i = tid; i < LP; i += ATT_THREADS) {
+    stage_rowmajor(Qs, qbase, p.ld_qkv, L, LP, tid, ATT_THREADS8);
+    stage_rowmajor(dOs, dobase, p.ld_dctx, L, LP, tid, ATT_THREADS8);
+    for (int i = tid; i < LP; i += ATT_THREADS8) {
         const int64_t stat = ((int64_t)b * p.heads + h) * L + min(i, L - 1);
-        lse_s[i] = p.lse[stat];
+        lse_s[i] = p.lse[stat] * LOG2E_F;
         dl_s[i] = p.delta[stat];
         rk_s[i] = p.drop.thresh ? drop_rowkey(p.drop, (uint64_t)stat) : 0u;      // dropout element = (row (b, h, q), col key)
     }
     __syncthreads();
 
     const int nkt = (L + 15) / 16;
-    for (int kt = wid; kt < nkt; kt += ATT_WAVES) {
+    for (int kt = wid; kt < nkt; kt += ATT_WAVES8) {
         const int key = kt * 16 + li;            // this lane's key (column)
         const int kc = min(key, L - 1);
         f16x8 kf[2], vf[2];
@@ -332,9 +373,13 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_bwd_dkv_kernel(AttnParams
         // mask bytes of this key for queries 16*qt + 4g .. +3 (rows >= L / keys >= L hold 2 = excluded); the words of the
         // next query-tile pair are fetched one iteration ahead
         const uint8_t* mtr = p.mask_t + ((int64_t)b * p.Lp + min(key, p.Lp - 1)) * p.Lp + 4 * g;
-        auto mload = [&](int qt) -> uint32_t { return (qt * 16 < p.Lp) ? *reinterpret_cast<const uint32_t*>(mtr + 16 * qt) : 0x02020202u; };
+        auto mload = [&](int qt) -> uint32_t {       // branch-free: clamp the address, select afterwards
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(mtr + min(16 * qt, p.Lp - 16));
+            return (qt * 16 < p.Lp) ? w : 0x02020202u;
+        };
         uint32_t mcur[2] = {mload(0), mload(1)};
         const uint32_t keyphi = ((uint32_t)key >> 1) * VLP_PHI, kodd = (uint32_t)key & 1u;
+        const float sc2 = p.scale * LOG2E_F;
         f32x4 dk[4], dv[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) { dk[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -362,11 +407,11 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_bwd_dkv_kernel(AttnParams
                 const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_s + q0);
                 const f32x4 dl4 = *reinterpret_cast<const f32x4*>(dl_s + q0);
                 const u32x4 rk4 = *reinterpret_cast<const u32x4*>(rk_s + q0);
+                float ma[4];
+                mask4w(mcur[half], qt * 16 + 16 <= L && kt * 16 + 16 <= L, -MASK_C1, ma);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const uint32_t mv = (mcur[half] >> (8 * r)) & 0xffu;
-                    const float madd = mv == 1u ? 0.f : (mv == 0u ? -10000.f : -INFINITY);
-                    const float pr = __expf(s[r] * p.scale + madd - lse4[r]);     // excluded (padding) -> exp(-inf) = 0
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, ma[r] - lse4[r]));     // lse_s holds lse * log2(e); excluded (padding) -> exp2(-inf) = 0
                     float mult = 1.f;
                     if (p.drop.thresh) mult = drop_mult_h(p.drop, mix32(rk4[r] + keyphi), kodd);
                     pdf[half * 4 + r] = (f16)(pr * mult);
@@ -410,7 +455,7 @@ static inline int lp_of(int L) { return L <= 64 ? 64 : (L <= 128 ? 128 : (L <= 1
 static int launch_attn_fwd(AttnParams& p, hipStream_t s) {
     const int LP = lp_of(p.Lk);
     const size_t smem = (size_t)2 * LP * HD * 2;
-    dim3 grid(p.B * p.heads), block(ATT_THREADS);
+    dim3 grid(p.B * p.heads), block(ATT_THREADS8);
 #define LAUNCH_FWD(NT_)                                                                                              \
     do {                                                                                                             \
         static bool attr = false;                                                                                    \
@@ -491,7 +536,7 @@ extern "C" int vlp_attn_bwd(const vlp_attn_bwd_args* a, void* stream) {
             attr = true;                                                                                             \
         }                                                                                                            \
         hipLaunchKernelGGL(attn_bwd_dq_kernel<NT_>, grid, block, smem_dq, s, p);                                     \
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<NT_>, grid, block, smem_dkv, s, p);                                   \
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<NT_>, grid, dim3(ATT_THREADS8), smem_dkv, s, p);                                   \
     } while (0)
     if (LP == 64) LAUNCH_BWD(4); else if (LP == 128) LAUNCH_BWD(8); else if (LP == 192) LAUNCH_BWD(12); else LAUNCH_BWD(16);
 #undef LAUNCH_BWD
