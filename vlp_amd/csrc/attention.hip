@@ -75,18 +75,9 @@ DEVFN f16x8 tr_frag(const f16* tile, int r_first, int r_second, int col0, int g,
     return (f16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
-// additive mask term for 4 consecutive keys of one query row.  Mask bytes (vlp_mask_pack): 1 = attend (+0),
-// 0 = masked (-10000, modeling.py:832), 2 = padding column past L (excluded: -inf).  Rows are Lp bytes.
-DEVFN void mask4(const uint8_t* mrow, int key0, int Lp, float out[4]) {
-    const uint32_t w = (key0 < Lp) ? *reinterpret_cast<const uint32_t*>(mrow + key0) : 0x02020202u;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const uint32_t v = (w >> (8 * e)) & 0xffu;
-        out[e] = v == 1u ? 0.f : (v == 0u ? -10000.f : -INFINITY);
-    }
-}
-
-// log2-domain variant used by the kernels: out[e] = c0 + c1 * [byte == 1] (byte in {0, 1}), -inf for byte 2.  c1 = 10000*log2(e), c0 =
+// Mask bytes (vlp_mask_pack): 1 = attend (+0), 0 = masked (-10000, modeling.py:832), 2 = padding column past L (excluded: -inf).
+// Rows are Lp bytes.
+// Additive mask term of 4 consecutive keys, in the log2 domain: out[e] = c0 + c1 * [byte == 1] (byte in {0, 1}), -inf for byte 2.  c1 = 10000*log2(e), c0 =
 // -10000*log2(e) (+ a per-row offset such as -lse).  `full` (uniform) says that no byte of the word can be 2: one v_cvt_f32_ubyteN and
 // one fma per element instead of shift / compare / select chains.
 #define LOG2E_F 1.4426950408889634f
@@ -146,9 +137,12 @@ __global__ __launch_bounds__(ATT_THREADS8, NT <= 12 ? 4 : 2) void attn_fwd_kerne
 
         // mask words of this query for all key tiles: independent loads issued before the MFMAs (one L2 round trip, not NT)
         const uint8_t* mrow = p.mask + ((int64_t)b * Lq + qc) * p.Lp;
-        uint32_t mw[NT];
+        constexpr bool PRELOAD = NT <= 12;           // L > 192: the words would push the kernel into spills -- fetch them per tile there
+        uint32_t mw[PRELOAD ? NT : 1];
+        if (PRELOAD) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) mw[t] = mask_word(mrow, t * 16 + 4 * gq, p.Lp);
+            for (int t = 0; t < NT; ++t) mw[t] = mask_word(mrow, t * 16 + 4 * gq, p.Lp);
+        }
         // S^T tiles: rows = keys 16t + 4g + reg, col = query
         f32x4 s[NT];
 #pragma unroll
@@ -167,7 +161,7 @@ __global__ __launch_bounds__(ATT_THREADS8, NT <= 12 ? 4 : 2) void attn_fwd_kerne
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float ma[4];
-            mask4w(mw[t], t * 16 + 16 <= L, -MASK_C1, ma);
+            mask4w(PRELOAD ? mw[PRELOAD ? t : 0] : mask_word(mrow, t * 16 + 4 * gq, p.Lp), t * 16 + 16 <= L, -MASK_C1, ma);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 s[t][r] = fmaf(s[t][r], sc2, ma[r]);
@@ -276,9 +270,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams 
         if (g == 0 && q < L) p.delta[stat] = dl;
 
         const uint8_t* mrow = p.mask + ((int64_t)b * L + qc) * p.Lp;
-        uint32_t mw[NT];
+        constexpr bool PRELOAD = NT <= 12;           // L > 192: the words would push the kernel into spills -- fetch them per tile there
+        uint32_t mw[PRELOAD ? NT : 1];
+        if (PRELOAD) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) mw[t] = mask_word(mrow, t * 16 + 4 * gq, p.Lp);
+            for (int t = 0; t < NT; ++t) mw[t] = mask_word(mrow, t * 16 + 4 * gq, p.Lp);
+        }
         const uint32_t rk = p.drop.thresh ? drop_rowkey(p.drop, ((uint64_t)b * p.heads + h) * (uint64_t)L + (uint64_t)qc) : 0u;
         const uint32_t pk0 = drop_pairkey(rk, (uint32_t)(4 * gq));
         const float sc2 = p.scale * LOG2E_F, c0 = -MASK_C1 - lse * LOG2E_F;      // P = exp2(s * sc2 + mask term - lse * log2(e))
@@ -294,7 +291,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams 
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld8(Vs + off), dof[ks], dp, 0, 0, 0);
             }
             float ma[4];
-            mask4w(mw[t], t * 16 + 16 <= L, c0, ma);
+            mask4w(PRELOAD ? mw[PRELOAD ? t : 0] : mask_word(mrow, t * 16 + 4 * gq, p.Lp), t * 16 + 16 <= L, c0, ma);
             float m4[4] = {1.f, 1.f, 1.f, 1.f};
             if (p.drop.thresh) {
                 const uint32_t h0 = mix32(pk0 + (uint32_t)(8 * t) * VLP_PHI), h1 = mix32(pk0 + (uint32_t)(8 * t + 1) * VLP_PHI);
