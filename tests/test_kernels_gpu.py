@@ -82,7 +82,7 @@ def test_gemm_nt_plain(variant, M, N, K, gen):
         assert float(y[:, N:].abs().max()) == 0.0        # padding columns are written as zero
 
 
-@pytest.mark.parametrize("variant", [6, 7, 14, 15, 22, 23, 54])
+@pytest.mark.parametrize("variant", [6, 7, 14, 15, 22, 23, 54, 19, 27])
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 768, 768), (77, 1000, 192), (256, 2304, 768), (515, 520, 1664),
                                    (10688, 768, 3072), (10688, 2304, 768)])
 def test_gemm_nt_phased(variant, M, N, K, gen):
@@ -102,8 +102,13 @@ def test_gemm_nt_phased(variant, M, N, K, gen):
             first = y.clone()
         else:
             assert torch.equal(first, y), "variant %d: run %d differs from run 0" % (variant, it)
-    with pytest.raises(RuntimeError):
-        K.gemm_nt(x[:, :64], w[:, :64], y, M, N, 64, ldx=Kd, ldw=Kd, variant=variant)       # K < 128 is refused, not mis-computed
+    if variant & 7 in (6, 7):
+        with pytest.raises(RuntimeError):
+            K.gemm_nt(x[:, :64], w[:, :64], y, M, N, 64, ldx=Kd, ldw=Kd, variant=variant)       # K < 128 is refused, not mis-computed
+    else:                                       # ring variants (19, 27): a single k tile works too (clamped refills)
+        y1 = torch.zeros(M, ldy, device=DEV, dtype=torch.half)
+        K.gemm_nt(x[:, :64], w[:, :64], y1, M, N, 64, ldx=Kd, ldw=Kd, variant=variant)
+        assert rel(y1[:, :N].float(), x[:, :64].float() @ w[:, :64].float().t()) < 1.5e-3
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3])
@@ -117,7 +122,7 @@ def test_gemm_nt_asymmetric_identity(variant):
     assert torch.equal(y, w.t().contiguous())
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, 6, 7, 19])
 def test_gemm_nt_epilogues(variant, gen):
     M, N, Kd = 200, 384, 256
     x, w = h16(M, Kd, gen=gen), h16(N, Kd, scale=0.06, gen=gen)

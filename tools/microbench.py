@@ -44,7 +44,7 @@ def main():
         ldy = (n + 63) // 64 * 64
         y = torch.empty(m, ldy, device=DEV, dtype=torch.half)
         bias = r(ldy)
-        for var in ((6, 22, 7, 23, 31, 13, 11) if '--ph' in sys.argv else (1, 2, 4, 5, 6, 7, 9, 11, 12, 13, 14, 15)):
+        for var in ((19, 27, 3, 11, 13) if '--ph' in sys.argv else (1, 2, 4, 5, 6, 7, 9, 11, 12, 13, 14, 15)):
             us = timeit(lambda: K.gemm_nt(x, w, y, m, n, k, bias=bias, variant=var))
             res["gemm_nt/%s/v%d" % (name, var)] = {"us": us, "tflops": 2.0 * m * n * k / us / 1e6}
         if name == "ffn1":

@@ -29,9 +29,13 @@ DEVFN int swz_w(int r) { return (((r >> 4) & 3) << 1) | ((r >> 1) & 1); }
 
 // VARIANT 0: register-staged, double-buffered   1: LDS-DMA, double-buffered   2: LDS-DMA, single buffer (32 KiB -> up to
 // 4 workgroups per CU; overlap comes from co-resident workgroups instead of an in-block pipeline)
+// 3: LDS-DMA ring of 3 stages (256x128 tile: 144 KiB, one workgroup per CU), counted vmcnt: the DMA queue is never drained inside
+//    the loop -- 2 stages stay in flight across the single raw s_barrier of a k tile.  Measured equal to variant 1 on the step's
+//    shapes (793 vs 776 TFLOP/s at K = 3072): the 2-stage kernels are not bound by the DMA round trip, which is a useful negative
+//    result; kept as variant 19 / 27, not among the autotune candidates.
 // BM_T: rows of the block tile (128 -> 4 waves 2x2, 256 -> 8 waves 4x2); the wave tile is always 64x64.
 template <int VARIANT, int BM_T, int BN_T>
-__global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, ((VARIANT == 2 || BN_T == 256) ? 4 : 2)) void gemm_nt_kernel(GemmNtParams p) {
+__global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BM_T / 128) : ((VARIANT == 2 || BN_T == 256) ? 4 : 2))) void gemm_nt_kernel(GemmNtParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     f16* smem = reinterpret_cast<f16*>(smem_raw);
     constexpr int WN_ = BN_T / 64;        // waves along n
@@ -165,7 +169,7 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, ((VARIANT == 2 || B
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-    } else {
+    } else if (VARIANT == 2) {
         for (int kt = 0; kt < nk; ++kt) {
             glds(kt, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -173,6 +177,25 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, ((VARIANT == 2 || B
             compute(0);
             __syncthreads();
         }
+    } else {
+        // ring of NS stages.  Iteration kt: (1) wait until this wave's pieces of stage kt have landed -- the NS-2 younger stages may
+        // stay in flight; (2) barrier: every wave's pieces have landed AND every wave has finished the MFMAs (hence the ds_reads) of
+        // stage kt-1, whose buffer is therefore free; (3) refill that buffer with stage kt+NS-1; (4) compute stage kt.
+        // k tiles past the end are clamped to the last one (dummy reloads into buffers nobody reads again) so the count stays constant.
+        constexpr int NS = (BM_T == 256) ? 3 : 4;
+        constexpr int LPS = XP + WP;                 // DMA instructions per thread per stage
+#pragma unroll
+        for (int st = 0; st < NS - 1; ++st) glds(min(st, nk - 1), st);
+        int buf = 0, nbuf = NS - 1;
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS * (NS - 2)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            glds(min(kt + NS - 1, nk - 1), nbuf);
+            compute(buf);
+            buf = (buf + 1 == NS) ? 0 : buf + 1;
+            nbuf = (nbuf + 1 == NS) ? 0 : nbuf + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the clamped tail reloads must land before the LDS is released
     }
 
     // ---- epilogue: lane owns row m (per tm) and 16 consecutive n -------------------------------
@@ -298,8 +321,8 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
             break;
         }
         case 0: LAUNCH_NT(0, 128, 128, 2); break;
+        case 3: if (a->variant & 16) LAUNCH_NT(3, 256, 128, 3); else LAUNCH_NT(1, 256, 128, 2); break;
         case 2: LAUNCH_NT(2, 128, 128, 1); break;
-        case 3: LAUNCH_NT(1, 256, 128, 2); break;
         case 4: LAUNCH_NT(2, 256, 128, 1); break;
         case 5: LAUNCH_NT(1, 256, 256, 2); break;
         default: LAUNCH_NT(1, 128, 128, 2); break;
