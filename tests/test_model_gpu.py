@@ -149,6 +149,30 @@ def test_plumbing_config_8_regions():
         assert abs(float(params[n].grad.double().norm()) - float(v.norm())) <= 2e-2 * float(v.norm()) + 2e-3 * gscale, n
 
 
+@pytest.mark.parametrize("max_len_b,min_len_b,B", [(153, 120, 2), (1, 1, 3), (89, 1, 3)])
+def test_extreme_sequence_lengths(max_len_b, min_len_b, B):
+    """Edge sizes of the path: the longest sequence the attention kernels take (L = 256: 100 regions + 153 tokens + 3), the shortest
+    (one caption token, L = 104) and a ragged batch (captions of 1..89 tokens, L = 192 exactly on a key-tile boundary); mixed seq2seq /
+    bidirectional masks.  Forward logits, loss and every gradient norm against the oracle on the same device."""
+    p = O.init_params(vocab_size=1024, layers=2, tasks="img2txt", seed=41)
+    batch = S.make_batch(B, max_len_b=max_len_b, min_len_b=min_len_b, vocab_size=1024, max_pred=3, s2s_prob=0.5, seed=50 + max_len_b)
+    assert batch.input_ids.shape[1] == max_len_b + 103
+    m = build(p, dict(vocab_size=1024, layers=2, tasks="img2txt")).eval()
+    losses = run_model(m, batch)
+    (losses[0] + losses[1] + losses[2]).sum().backward()
+    truth, gt = oracle_on_device(p, batch, "img2txt", torch.float32, grads=True)
+    ref16, _ = oracle_on_device(p, batch, "img2txt", torch.float16)
+    t = truth["mlm_logits"].detach()
+    assert relmax(m.last_mlm_logits.float(), t) <= relmax(ref16["mlm_logits"].float(), t) + 1e-3
+    assert abs(float(losses[0]) - float(truth["mlm_loss"])) < 2e-3 * float(truth["mlm_loss"])
+    params = dict(m.named_parameters())
+    gscale = max(float(v.norm()) for v in gt.values() if v is not None)
+    for n, v in gt.items():
+        if v is None or n in m.engine.unused_parameter_names():
+            continue
+        assert abs(float(params[n].grad.double().norm()) - float(v.norm())) <= 2e-2 * float(v.norm()) + 2e-3 * gscale, n
+
+
 def test_vqa_inference_and_drop_worst():
     p = O.init_params(vocab_size=1024, layers=2, tasks="vqa2", seed=5)
     batch = S.make_batch(5, max_len_b=20, vocab_size=1024, tasks="vqa2", max_pred=1, seed=9)
