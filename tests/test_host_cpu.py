@@ -172,3 +172,22 @@ def test_synthetic_batch_contract():
             assert torch.equal(m[0], (torch.arange(L) < n_tok).long())
         w = b.masked_weights[i].bool()
         assert ((b.masked_pos[i][w] >= Nv + 2) & (b.masked_pos[i][w] < n_tok)).all()
+
+
+def test_compat_import_paths():
+    """vlp_amd.compat.install(): the reference's import lines (run_img2txt_dist.py:23-30,405-406) resolve to the HIP implementation."""
+    import subprocess
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import vlp_amd.compat as c; c.install()\n"
+        "from pytorch_pretrained_bert.modeling import BertForPreTrainingLossMask, BertForSeq2SeqDecoder, BertConfig\n"
+        "from pytorch_pretrained_bert.optimization import BertAdam, warmup_linear\n"
+        "from pytorch_pretrained_bert.optimization_fp16 import FP16_Optimizer_State\n"
+        "from apex.optimizers import FusedAdam\n"
+        "import pytorch_pretrained_bert as P, vlp_amd.modeling as M, vlp_amd.optimization_fp16 as F\n"
+        "assert BertForPreTrainingLossMask is M.BertForPreTrainingLossMask and P.BertForSeq2SeqDecoder is M.BertForSeq2SeqDecoder\n"
+        "assert FusedAdam is F.FusedAdam and FP16_Optimizer_State is F.FP16_Optimizer_State and warmup_linear(0.05, 0.1) == 0.5\n"
+        "c.uninstall(); assert 'pytorch_pretrained_bert' not in sys.modules\n"
+        "print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
