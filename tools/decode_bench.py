@@ -1,0 +1,42 @@
+"""N1 measurement: captions/s of the K/V-cache decoder (12 layers, vocab 28 996, 100 regions, 20 generated tokens), greedy and beam."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from vlp_amd import synthetic as S  # noqa: E402
+from vlp_amd.modeling import BertConfig, BertForSeq2SeqDecoder  # noqa: E402
+
+dev = torch.device("cuda:0")
+B, T, Nv = int(os.environ.get("B", 64)), 20, 100
+torch.manual_seed(0)
+cfg = BertConfig(28996, num_hidden_layers=12, type_vocab_size=6)
+out = {"batch": B, "new_tokens": T, "layers": 12}
+g = torch.Generator().manual_seed(0)
+img = torch.randn(B, Nv, 2048, generator=g).abs().half().to(dev)
+vis_pe = torch.rand(B, Nv, 1607, generator=g).half().to(dev)
+in_len, out_len = Nv + 2, Nv + 2 + T
+input_ids = torch.tensor([[S.CLS_ID] + [S.UNK_ID] * Nv + [S.SEP_ID]] * B).to(dev)
+token_type = torch.tensor([[4] * in_len + [5] * T] * B).to(dev)
+pos = torch.arange(out_len).unsqueeze(0).expand(B, -1).contiguous().to(dev)
+am = torch.zeros(B, out_len, out_len, dtype=torch.long)
+am[:, :, :in_len] = 1
+am[:, in_len:, in_len:] = torch.tril(torch.ones(T, T, dtype=torch.long))
+am = am.to(dev)
+for name, kw in (("greedy", dict(search_beam_size=1)), ("beam3", dict(search_beam_size=3)), ("beam5", dict(search_beam_size=5))):
+    m = BertForSeq2SeqDecoder(cfg, mask_word_id=S.MASK_ID, eos_id=S.SEP_ID, enable_butd=True, len_vis_input=Nv, allow_random_fc7=True, **kw).half().to(dev).eval()
+    for _ in range(2):
+        m(img, vis_pe, input_ids, token_type, pos, am)
+    torch.cuda.synchronize()
+    n = 5
+    t0 = time.perf_counter()
+    for _ in range(n):
+        r = m(img, vis_pe, input_ids, token_type, pos, am)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    out[name] = {"ms_per_batch": round(dt * 1e3, 2), "captions_per_s": round(B / dt, 1), "ms_per_token_step": round(dt * 1e3 / T, 3)}
+    del m
+print(json.dumps(out))
