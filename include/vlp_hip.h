@@ -71,7 +71,7 @@ typedef struct {
                                             6 / 7 = phased 256x256 / 256x128 kernels (gemm_nt_ph.hip: half-tile LDS-DMA pipeline with
                                             counted vmcnt, 128x64 / 64x64 wave tiles, two staggered wave groups; need K >= 128;
                                             +16 = one barrier per phase, compiler-scheduled, +48 = no stagger);
-                                            19 = variant 3 with a 3-stage LDS-DMA ring and counted vmcnt;
+                                            17 / 19 = variants 1 / 3 with a 4- / 3-stage LDS-DMA ring and counted vmcnt (17: latency hiding for skinny M);
                                             +8 = XCD-aware tile order.  Every variant computes the same result. */
 } vlp_gemm_nt_args;
 int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream);

@@ -82,7 +82,7 @@ def test_gemm_nt_plain(variant, M, N, K, gen):
         assert float(y[:, N:].abs().max()) == 0.0        # padding columns are written as zero
 
 
-@pytest.mark.parametrize("variant", [6, 7, 14, 15, 22, 23, 54, 19, 27])
+@pytest.mark.parametrize("variant", [6, 7, 14, 15, 22, 23, 54, 17, 19, 27])
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 768, 768), (77, 1000, 192), (256, 2304, 768), (515, 520, 1664),
                                    (10688, 768, 3072), (10688, 2304, 768)])
 def test_gemm_nt_phased(variant, M, N, K, gen):
@@ -105,7 +105,7 @@ def test_gemm_nt_phased(variant, M, N, K, gen):
     if variant & 7 in (6, 7):
         with pytest.raises(RuntimeError):
             K.gemm_nt(x[:, :64], w[:, :64], y, M, N, 64, ldx=Kd, ldw=Kd, variant=variant)       # K < 128 is refused, not mis-computed
-    else:                                       # ring variants (19, 27): a single k tile works too (clamped refills)
+    else:                                       # ring variants (17, 19, 27): a single k tile works too (clamped refills)
         y1 = torch.zeros(M, ldy, device=DEV, dtype=torch.half)
         K.gemm_nt(x[:, :64], w[:, :64], y1, M, N, 64, ldx=Kd, ldw=Kd, variant=variant)
         assert rel(y1[:, :N].float(), x[:, :64].float() @ w[:, :64].float().t()) < 1.5e-3

@@ -29,10 +29,11 @@ DEVFN int swz_w(int r) { return (((r >> 4) & 3) << 1) | ((r >> 1) & 1); }
 
 // VARIANT 0: register-staged, double-buffered   1: LDS-DMA, double-buffered   2: LDS-DMA, single buffer (32 KiB -> up to
 // 4 workgroups per CU; overlap comes from co-resident workgroups instead of an in-block pipeline)
-// 3: LDS-DMA ring of 3 stages (256x128 tile: 144 KiB, one workgroup per CU), counted vmcnt: the DMA queue is never drained inside
-//    the loop -- 2 stages stay in flight across the single raw s_barrier of a k tile.  Measured equal to variant 1 on the step's
-//    shapes (793 vs 776 TFLOP/s at K = 3072): the 2-stage kernels are not bound by the DMA round trip, which is a useful negative
-//    result; kept as variant 19 / 27, not among the autotune candidates.
+// 3: LDS-DMA ring of NS stages (3 for the 256x128 tile = 144 KiB, 4 for 128x128 = 128 KiB; one workgroup per CU), counted vmcnt: the
+//    DMA queue is never drained inside the loop -- NS-1 stages stay in flight across the single raw s_barrier of a k tile.
+//    On the training shapes (thousands of workgroups) it equals variant 1 (793 vs 776 TFLOP/s at K = 3072): those loops are not
+//    bound by the DMA round trip.  On the decoder's skinny GEMMs (M = 128..640: a few dozen workgroups, each alone on its CU and
+//    paying one L2 round trip per k tile) the 128x128 ring (variant 17) is the latency-hiding kernel; the autotuner picks it there.
 // BM_T: rows of the block tile (128 -> 4 waves 2x2, 256 -> 8 waves 4x2); the wave tile is always 64x64.
 template <int VARIANT, int BM_T, int BN_T>
 __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BM_T / 128) : ((VARIANT == 2 || BN_T == 256) ? 4 : 2))) void gemm_nt_kernel(GemmNtParams p) {
@@ -321,6 +322,7 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
             break;
         }
         case 0: LAUNCH_NT(0, 128, 128, 2); break;
+        case 1: if (a->variant & 16) LAUNCH_NT(3, 128, 128, 4); else LAUNCH_NT(1, 128, 128, 2); break;
         case 3: if (a->variant & 16) LAUNCH_NT(3, 256, 128, 3); else LAUNCH_NT(1, 256, 128, 2); break;
         case 2: LAUNCH_NT(2, 128, 128, 1); break;
         case 4: LAUNCH_NT(2, 256, 128, 1); break;

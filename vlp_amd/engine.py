@@ -47,6 +47,7 @@ class _State(object):
 class Engine(object):
     GEMM_NT_VARIANT = None   # None -> autotune per (M, N, K) on first use among NT_CANDIDATES; or force an int
     NT_CANDIDATES = (1, 2, 4, 5, 9, 10, 11, 12, 13)   # LDS-DMA variants (+8 = XCD-aware tile order); see include/vlp_hip.h
+    NT_CANDIDATES_SKINNY = (1, 2, 9, 10, 11, 17)      # M <= 1024 (decoding, LM head): few workgroups, latency-bound -> also the 4-stage ring
     GEMM_TN_VARIANT = 2      # ds_read_b64_tr_b16 fragment reads + LDS-DMA staging
     # weight-gradient GEMMs of the encoder layers on a second HIP stream, concurrent with the dgrad chain: +1.5-2 % step
     # throughput on one MI355X (4706 vs 4637 samples/s); off by default so that per-kernel timings (bench.py roofline,
@@ -307,16 +308,17 @@ class Engine(object):
         if v is not None:
             return v
         best, best_t = self.NT_CANDIDATES[0], float("inf")
-        if M * N >= 128 * 128 * 8:          # tiny problems: not worth timing
+        cands = self.NT_CANDIDATES_SKINNY if M <= 1024 else self.NT_CANDIDATES
+        if M * N >= 128 * 128 * 4:          # tiny problems: not worth timing
             torch.cuda.synchronize()        # nothing else (e.g. side-stream wgrads) may run while candidates are timed
             for rnd in range(2):              # two interleaved rounds, best-of: robust against clock / neighbour noise
-                for cand in self.NT_CANDIDATES:
+                for cand in cands:
                     if cand & 7 == 5 and N < 1024:
                         continue                  # 256-wide n tiles leave most CUs idle on narrow outputs
                     K.gemm_nt(x, w, y, M, N, Kd, variant=cand, **kw)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    for _ in range(4):
+                    for _ in range(4 if M > 1024 else 12):
                         K.gemm_nt(x, w, y, M, N, Kd, variant=cand, **kw)
                     e1.record()
                     e1.synchronize()
