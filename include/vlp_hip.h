@@ -75,6 +75,11 @@ typedef struct {
                                             +8 = XCD-aware tile order.  Every variant computes the same result. */
 } vlp_gemm_nt_args;
 int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream);
+/* Split-K form for skinny problems (incremental decoding, M = 128..640 rows: only N/128 output tiles): the k range is cut into `splits`
+ * slices computed by separate workgroups into an fp32 workspace of vlp_gemm_nt_splitk_workspace_bytes(M, N, splits) bytes; a second
+ * kernel sums the slices in a fixed order (deterministic) and applies the same fused epilogue.  `variant` is ignored. */
+int64_t vlp_gemm_nt_splitk_workspace_bytes(int32_t M, int32_t N, int32_t splits);
+int vlp_gemm_nt_splitk(const vlp_gemm_nt_args* a, int32_t splits, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * dW[N,K] (+)= A[M,N]^T . B[M,K]          (wgrad: A = dY, B = layer input; contraction over rows M)

@@ -111,6 +111,34 @@ def test_gemm_nt_phased(variant, M, N, K, gen):
         assert rel(y1[:, :N].float(), x[:, :64].float() @ w[:, :64].float().t()) < 1.5e-3
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(128, 768, 3072, 8), (128, 2304, 768, 4), (640, 768, 768, 3), (77, 1000, 192, 2), (320, 3072, 768, 12),
+                                            (128, 768, 768, 64)])
+def test_gemm_nt_splitk(M, N, K, splits, gen):
+    """Split-K NT GEMM for the decoder's skinny shapes: plain result, fused epilogues after the slice reduction, determinism."""
+    Kd = K
+    from vlp_amd import _lib as K
+    x, w = h16(M, Kd, gen=gen), h16(N, Kd, scale=0.05, gen=gen)
+    ldy = (N + 7) // 8 * 8
+    ws = torch.full((K.gemm_nt_splitk_workspace_bytes(M, N, splits) // 4,), float("nan"), device=DEV)     # stale scratch must not matter
+    ref = x.float() @ w.float().t()
+    y = torch.full((M, ldy), 7.0, device=DEV, dtype=torch.half)
+    K.gemm_nt_splitk(x, w, y, M, N, Kd, splits, ws)
+    assert rel(y[:, :N].float(), ref) < 1.5e-3
+    if ldy > N:
+        assert float(y[:, N:].abs().max()) == 0.0
+    y2 = torch.empty_like(y)
+    K.gemm_nt_splitk(x, w, y2, M, N, Kd, splits, ws)
+    assert torch.equal(y, y2)
+    bias, res = h16(N, gen=gen), h16(M, ldy, gen=gen)
+    K.gemm_nt_splitk(x, w, y, M, N, Kd, splits, ws, bias=bias, act=K.ACT_GELU)
+    lin = ref + bias.float()
+    assert rel(y[:, :N].float(), lin * 0.5 * (1 + torch.erf(lin / math.sqrt(2)))) < 2e-3
+    K.gemm_nt_splitk(x, w, y, M, N, Kd, splits, ws, bias=bias, residual=res, alpha=0.5)
+    assert rel(y[:, :N].float(), 0.5 * ref + bias.float() + res[:, :N].float()) < 2e-3
+    with pytest.raises(RuntimeError):
+        K.gemm_nt_splitk(x, w, y, M, N, Kd, splits, ws[:16])                # workspace too small is refused
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_gemm_nt_asymmetric_identity(variant):
     """A = I against an asymmetric B catches swapped row/col in the MFMA C-layout handling."""

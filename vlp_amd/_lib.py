@@ -127,6 +127,8 @@ SYMBOLS = {
     "vlp_version": (C.c_int, []),
     "vlp_last_error_string": (C.c_char_p, []),
     "vlp_gemm_nt": (C.c_int, [C.POINTER(GemmNtArgs), vp]),
+    "vlp_gemm_nt_splitk_workspace_bytes": (C.c_int64, [i32, i32, i32]),
+    "vlp_gemm_nt_splitk": (C.c_int, [C.POINTER(GemmNtArgs), i32, vp, i64, vp]),
     "vlp_gemm_tn_workspace_bytes": (i64, [i32, i32, i32]),
     "vlp_gemm_tn": (C.c_int, [C.POINTER(GemmTnArgs), vp]),
     "vlp_colsum_workspace_bytes": (i64, [i32, i32]),
@@ -225,6 +227,22 @@ def gemm_nt(x, w, y, M, N, K, ldx=None, ldw=None, ldy=None, bias=None, residual=
                    ptr(mul_src), (ldm if ldm is not None else (mul_src.stride(0) if mul_src is not None else 0)),
                    M, N, K, act, mul_mode, alpha, dropout_p, seed, rng_stream, variant)
     _check(load().vlp_gemm_nt(C.byref(a), stream_ptr()))
+
+
+def gemm_nt_splitk_workspace_bytes(M, N, splits):
+    return int(load().vlp_gemm_nt_splitk_workspace_bytes(M, N, splits))
+
+
+def gemm_nt_splitk(x, w, y, M, N, K, splits, workspace, ldx=None, ldw=None, ldy=None, bias=None, residual=None, ldr=None, preact=None, ldp=None,
+                   mul_src=None, ldm=None, act=ACT_NONE, mul_mode=MUL_NONE, alpha=1.0, dropout_p=0.0, seed=0, rng_stream=0):
+    _req_cuda(x, w, y, workspace)
+    a = GemmNtArgs(ptr(x), ldx if ldx is not None else x.stride(0), ptr(w), ldw if ldw is not None else w.stride(0),
+                   ptr(y), ldy if ldy is not None else y.stride(0), ptr(bias),
+                   ptr(residual), (ldr if ldr is not None else (residual.stride(0) if residual is not None else 0)),
+                   ptr(preact), (ldp if ldp is not None else (preact.stride(0) if preact is not None else 0)),
+                   ptr(mul_src), (ldm if ldm is not None else (mul_src.stride(0) if mul_src is not None else 0)),
+                   M, N, K, act, mul_mode, alpha, dropout_p, seed, rng_stream, 0)
+    _check(load().vlp_gemm_nt_splitk(C.byref(a), splits, ptr(workspace), workspace.numel() * workspace.element_size(), stream_ptr()))
 
 
 def gemm_tn_workspace_bytes(M, N, K):

@@ -275,7 +275,7 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BM
     }
 }
 
-extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
+int vlp_gemm_nt_fill_params(const vlp_gemm_nt_args* a, GemmNtParams& p) {
     VLP_CHECK_ARG(a != nullptr, "vlp_gemm_nt: null args");
     VLP_CHECK_ARG(a->X && a->W && a->Y, "vlp_gemm_nt: null operand");
     VLP_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "vlp_gemm_nt: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
@@ -293,7 +293,6 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
     VLP_CHECK_ARG(a->act >= VLP_ACT_NONE && a->act <= VLP_ACT_TANH, "vlp_gemm_nt: bad act %d", a->act);
     VLP_CHECK_ARG(a->dropout_p >= 0.f && a->dropout_p < 1.f, "vlp_gemm_nt: bad dropout p");
 
-    GemmNtParams p;
     p.X = (const f16*)a->X; p.ldx = a->ldx;
     p.W = (const f16*)a->W; p.ldw = a->ldw;
     p.Y = (f16*)a->Y; p.ldy = a->ldy;
@@ -305,6 +304,15 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
     p.act = a->act; p.mulmode = a->mul_mode;
     p.alpha = a->alpha;
     p.drop = make_drop(a->dropout_p, a->seed, a->rng_stream);
+    p.tiles_n = 0;
+    p.xcd_remap = 0;
+    return VLP_OK;
+}
+
+extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
+    GemmNtParams p;
+    const int frc = vlp_gemm_nt_fill_params(a, p);
+    if (frc != VLP_OK) return frc;
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_NT(V, BMT, BNT, NBUF)                                                                                    \
     do {                                                                                                                \
@@ -332,4 +340,12 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
 #undef LAUNCH_NT
     VLP_CHECK_LAUNCH("vlp_gemm_nt");
     return VLP_OK;
+}
+
+// split-K form for skinny M (gemm_nt_splitk.hip); same arguments, plus the slice count and an fp32 workspace
+extern "C" int vlp_gemm_nt_splitk(const vlp_gemm_nt_args* a, int32_t splits, void* workspace, int64_t workspace_bytes, void* stream) {
+    GemmNtParams p;
+    const int frc = vlp_gemm_nt_fill_params(a, p);
+    if (frc != VLP_OK) return frc;
+    return vlp_gemm_nt_splitk_launch(p, splits, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -342,6 +342,42 @@ class Engine(object):
         e1.record()
         self.prof.append((e0, e1, 2.0 * M * N * Kd))
 
+    SKINNY_SPLITS = (2, 3, 4, 6, 8, 12, 16)
+    _skinny_choice = {}      # (M, N, K) -> ("v", variant) | ("s", splits)
+
+    def _nt_skinny(self, x, w, y, M, N, Kd, skws, **kw):
+        """NT GEMM of the incremental decoder (M = sequences x 2 rows): the ordinary kernels have only N/128 workgroups to run, so the
+        split-K form (vlp_gemm_nt_splitk) is timed against the best ordinary variant once per shape."""
+        if M > 1024 or N > 4096 or Kd < 256:
+            return self._nt(x, w, y, M, N, Kd, **kw)
+        key = (M, N, Kd)
+        ch = Engine._skinny_choice.get(key)
+        if ch is None:
+            v = self._nt_variant(x, w, y, M, N, Kd, kw)
+
+            def timed(fn):
+                fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(12):
+                    fn()
+                e1.record()
+                e1.synchronize()
+                return e0.elapsed_time(e1)
+            torch.cuda.synchronize()
+            ch, best_t = ("v", v), timed(lambda: K.gemm_nt(x, w, y, M, N, Kd, variant=v, **kw))
+            for sp in self.SKINNY_SPLITS:
+                if Kd // 64 < sp:
+                    continue
+                t = timed(lambda: K.gemm_nt_splitk(x, w, y, M, N, Kd, sp, skws, **kw))
+                if t < best_t:
+                    ch, best_t = ("s", sp), t
+            Engine._skinny_choice[key] = ch
+        if ch[0] == "v":
+            K.gemm_nt(x, w, y, M, N, Kd, variant=ch[1], **kw)
+        else:
+            K.gemm_nt_splitk(x, w, y, M, N, Kd, ch[1], skws, **kw)
+
     def forward(self, vis_feats, vis_pe, input_ids, token_type_ids, attention_mask, masked_pos, train, want_mlm, want_vqa):
         """Runs embeddings + encoder (+ heads' forward up to the logits).  Returns the _State."""
         self.pack()
@@ -477,15 +513,15 @@ class Engine(object):
     # ------------------------------------------------------------------------------------------
     # incremental greedy decoding with a K/V cache (modeling.py:1189-1253, :856-875, :386-394)
     # ------------------------------------------------------------------------------------------
-    def _decode_workspace(self, B, T0, Lcap, K=1):
-        key = ("dec", B, T0, Lcap, K)
+    def _decode_workspace(self, B, T0, Lcap, Kb=1):
+        key = ("dec", B, T0, Lcap, Kb)
         ws = self._ws.get(key)
         if ws is not None:
             return ws
         model = self._model()
         cfg = model.config
         H, I, NL, Nv, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, model.len_vis_input, cfg.vocab_size
-        R = B * K                                     # sequences decoded in parallel after the first step
+        R = B * Kb                                    # sequences decoded in parallel after the first step
         M, Mv, dev = max(B * T0, R * 2), B * Nv, self.device
 
         def h(*s):
@@ -502,11 +538,13 @@ class Engine(object):
                   img16=h(Mv, 2048), vpe_in=h(Mv, PE_PAD), wpe_pad=h(H, PE_PAD), h1=h(Mv, 2048), vis_h=h(Mv, H), vispe_h=h(Mv, H),
                   emb_pre=h(M, H), xa=h(M, H), xb=h(M, H), qkv=h(M, 3 * H), ctx=h(M, H), pre=h(M, H), x1=h(M, H), g=h(M, I),
                   kv=[h(B, Lcap, 2 * H) for _ in range(NL)],        # per layer: K | V of every position decoded so far
-                  sel=h(R, H), tg=h(R, H), tln=h(R, H), logits=h(R, Vp), last=i64(R, 1), xids=i64(R, 2))
-        if K > 1:
+                  sel=h(R, H), tg=h(R, H), tln=h(R, H), logits=h(R, Vp), last=i64(R, 1), xids=i64(R, 2),
+                  sk_ws=torch.empty(K.gemm_nt_splitk_workspace_bytes(min(M, 1024), max(I, 3 * H), max(self.SKINNY_SPLITS)), device=dev,
+                                    dtype=torch.uint8))
+        if Kb > 1:
             # beams: two caches per layer (select_beam_items permutes rows: gather from one into the other, then swap)
             ws.update(kvA=[h(R, Lcap, 2 * H) for _ in range(NL)], kvB=[h(R, Lcap, 2 * H) for _ in range(NL)],
-                      kk_s=f(R, K), kk_i=i64(R, K), src_rows=i64(R))
+                      kk_s=f(R, Kb), kk_i=i64(R, Kb), src_rows=i64(R))
         self._ws[key] = ws
         return ws
 
@@ -566,16 +604,16 @@ class Engine(object):
         for i in range(NL):
             Ln = "bert.encoder.layer.%d." % i
             kv = caches[i]
-            self._nt(x, self.P(Ln + "attention.self.query.weight"), ws["qkv"], M, 3 * H, H, bias=self.P(Ln + "attention.self.query.bias"))
+            self._nt_skinny(x, self.P(Ln + "attention.self.query.weight"), ws["qkv"], M, 3 * H, H, ws["sk_ws"], bias=self.P(Ln + "attention.self.query.bias"))
             K.kv_append(ws["qkv"], 3 * H, kv, Lcap, R, T, st, H)
             K.attn_decode(ws["qkv"], 3 * H, T, kv, kv[:, :, H:], 2 * H, Lcap, maskb, ws["ctx"], R, T, Lk, A, scale)
-            self._nt(ws["ctx"], self.P(Ln + "attention.output.dense.weight"), ws["pre"], M, H, H, bias=self.P(Ln + "attention.output.dense.bias"),
+            self._nt_skinny(ws["ctx"], self.P(Ln + "attention.output.dense.weight"), ws["pre"], M, H, H, ws["sk_ws"], bias=self.P(Ln + "attention.output.dense.bias"),
                      residual=x)
             K.layernorm_fwd(ws["pre"], self.P(Ln + "attention.output.LayerNorm.weight"), self.P(Ln + "attention.output.LayerNorm.bias"),
                             ws["x1"], M, H)
-            self._nt(ws["x1"], self.P(Ln + "intermediate.dense.weight"), ws["g"], M, I, H, bias=self.P(Ln + "intermediate.dense.bias"),
+            self._nt_skinny(ws["x1"], self.P(Ln + "intermediate.dense.weight"), ws["g"], M, I, H, ws["sk_ws"], bias=self.P(Ln + "intermediate.dense.bias"),
                      act=K.ACT_GELU)
-            self._nt(ws["g"], self.P(Ln + "output.dense.weight"), ws["pre"], M, H, I, bias=self.P(Ln + "output.dense.bias"), residual=ws["x1"])
+            self._nt_skinny(ws["g"], self.P(Ln + "output.dense.weight"), ws["pre"], M, H, I, ws["sk_ws"], bias=self.P(Ln + "output.dense.bias"), residual=ws["x1"])
             K.layernorm_fwd(ws["pre"], self.P(Ln + "output.LayerNorm.weight"), self.P(Ln + "output.LayerNorm.bias"), alt, M, H)
             x, alt = alt, x
         # ---- LM head on the [MASK] slot (:1226-1228 / :1293-1296) ----------------------------------
