@@ -192,7 +192,7 @@ def main():
                           "global_batch": world * args.batch, "parallelism": "dp%d" % world, "final_loss": round(loss, 4),
                           "loss_scale": opt.cur_scale, "skipped_steps": opt.skipped_steps},
                "roofline": roof}
-        if os.environ.get("VLP_DEBUG_TUNE") == "1":
+        if os.environ.get("VLP_DEBUG_TUNE") == "1":  # noqa
             from vlp_amd.engine import Engine
             print("nt choices (M,N,K)->variant:", sorted(Engine._nt_choice.items()), file=sys.stderr)
             print("tn choices (M,N,K)->(variant,splits):", sorted(Engine._tn_choice.items()), file=sys.stderr)

@@ -43,3 +43,6 @@ for name, kw in MODES:
                  "host_enqueue_ms": round(t_enq * 1e3, 2)}
     del m
 print(json.dumps(out))
+if os.environ.get("VLP_DEBUG_TUNE") == "1":
+    from vlp_amd.engine import Engine
+    print("skinny choices:", sorted(Engine._skinny_choice.items()), file=sys.stderr)

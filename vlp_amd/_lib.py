@@ -175,9 +175,58 @@ SYMBOLS = {
 _lib = None
 
 
+# ---- launch plans ----------------------------------------------------------------------------------------------------
+# The incremental decoder issues ~160 tiny launches per token step whose arguments (workspace pointers, shapes) are identical from
+# call to call; building the ctypes structs and looking up strides every time made it host-bound (7 us per launch).  record() collects
+# the C calls a block of Python makes, replay() re-issues them: ~1 us per launch.  A plan holds its argument objects alive; it is only
+# valid while every buffer it points to is (the engine keeps plans inside the workspace they were recorded against).
+_recording = None
+
+
+class _Recorder(object):
+    """Stands in for the loaded library while recording: every C call is executed AND appended to the plan."""
+
+    def __init__(self, lib, plan):
+        self._lib, self._plan = lib, plan
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+
+        def call(*args):
+            self._plan.append((fn, args))
+            return fn(*args)
+        return call
+
+
+class record(object):
+    """with _lib.record() as plan: ...   (plan = list of (cfunc, args))"""
+
+    def __enter__(self):
+        global _recording
+        if _recording is not None:
+            raise RuntimeError("vlp_amd._lib.record(): already recording")
+        self.plan = []
+        _recording = _Recorder(load(), self.plan)
+        return self.plan
+
+    def __exit__(self, *exc):
+        global _recording
+        _recording = None
+        return False
+
+
+def replay(plan):
+    for fn, args in plan:
+        rc = fn(*args)
+        if rc:
+            _check(rc)
+
+
 def load():
     """Load libvlp_hip.so (built by vlp_amd/build.py).  Raises if it is absent: there is no fallback."""
     global _lib
+    if _recording is not None:
+        return _recording
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
@@ -196,7 +245,8 @@ def load():
 
 def _check(rc):
     if rc != 0:
-        raise RuntimeError("libvlp_hip: %s (status %d)" % (load().vlp_last_error_string().decode(), rc))
+        lib = _lib if _lib is not None else load()
+        raise RuntimeError("libvlp_hip: %s (status %d)" % (lib.vlp_last_error_string().decode(), rc))
 
 
 def stream_ptr():

@@ -345,33 +345,41 @@ class Engine(object):
     SKINNY_SPLITS = (2, 3, 4, 6, 8, 12, 16)
     _skinny_choice = {}      # (M, N, K) -> ("v", variant) | ("s", splits)
 
-    def _nt_skinny(self, x, w, y, M, N, Kd, skws, **kw):
+    def _nt_skinny(self, x, w, y, M, N, Kd, skws, tune_ws=None, **kw):
         """NT GEMM of the incremental decoder (M = sequences x 2 rows): the ordinary kernels have only N/128 workgroups to run, so the
-        split-K form (vlp_gemm_nt_splitk) is timed against the best ordinary variant once per shape."""
+        split-K form (vlp_gemm_nt_splitk) and every ordinary variant are timed once per shape.  `tune_ws()` returns same-shaped weight
+        tensors (the same projection in all layers) to cycle through while timing: in a real token step every weight is read once, i.e.
+        from HBM / Infinity Cache, not from a warm L2 -- timing one weight back to back would rank the candidates for the wrong regime."""
         if M > 1024 or N > 4096 or Kd < 256:
             return self._nt(x, w, y, M, N, Kd, **kw)
         key = (M, N, Kd)
         ch = Engine._skinny_choice.get(key)
         if ch is None:
-            v = self._nt_variant(x, w, y, M, N, Kd, kw)
+            wl = list(tune_ws()) if tune_ws is not None else [w]
+            reps = max(12, len(wl))
 
             def timed(fn):
-                fn()
+                fn(wl[0])
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for _ in range(12):
-                    fn()
+                for i in range(reps):
+                    fn(wl[i % len(wl)])
                 e1.record()
                 e1.synchronize()
                 return e0.elapsed_time(e1)
             torch.cuda.synchronize()
-            ch, best_t = ("v", v), timed(lambda: K.gemm_nt(x, w, y, M, N, Kd, variant=v, **kw))
+            ch, best_t = None, float("inf")
+            for v in self.NT_CANDIDATES_SKINNY:
+                t = timed(lambda ww, v=v: K.gemm_nt(x, ww, y, M, N, Kd, variant=v, **kw))
+                if t < best_t:
+                    ch, best_t = ("v", v), t
             for sp in self.SKINNY_SPLITS:
                 if Kd // 64 < sp:
                     continue
-                t = timed(lambda: K.gemm_nt_splitk(x, w, y, M, N, Kd, sp, skws, **kw))
+                t = timed(lambda ww, sp=sp: K.gemm_nt_splitk(x, ww, y, M, N, Kd, sp, skws, **kw))
                 if t < best_t:
                     ch, best_t = ("s", sp), t
+            K.gemm_nt(x, w, y, M, N, Kd, variant=1, **kw)        # leave y as computed from the caller's weight
             Engine._skinny_choice[key] = ch
         if ch[0] == "v":
             K.gemm_nt(x, w, y, M, N, Kd, variant=ch[1], **kw)
@@ -538,13 +546,18 @@ class Engine(object):
                   img16=h(Mv, 2048), vpe_in=h(Mv, PE_PAD), wpe_pad=h(H, PE_PAD), h1=h(Mv, 2048), vis_h=h(Mv, H), vispe_h=h(Mv, H),
                   emb_pre=h(M, H), xa=h(M, H), xb=h(M, H), qkv=h(M, 3 * H), ctx=h(M, H), pre=h(M, H), x1=h(M, H), g=h(M, I),
                   kv=[h(B, Lcap, 2 * H) for _ in range(NL)],        # per layer: K | V of every position decoded so far
-                  sel=h(R, H), tg=h(R, H), tln=h(R, H), logits=h(R, Vp), last=i64(R, 1), xids=i64(R, 2),
+                  sel=h(R, H), tg=h(R, H), tln=h(R, H), logits=h(R, Vp), xids=i64(R, 2),
+                  last_first=torch.full((R, 1), T0 - 1, device=dev, dtype=torch.long), last_step=torch.full((R, 1), 1, device=dev, dtype=torch.long),
+                  # static copies of the caller's per-position inputs, so that the launches of a token step have call-invariant arguments
+                  mask_static=i64(R, Lcap, Lcap), tt_steps=i64(Lcap, R, 2), pid_steps=i64(Lcap, R, 2),
+                  out_ids=i64(B, Lcap), out_val=f(B, Lcap), plans={}, calls=0, plan_stream=None,
                   sk_ws=torch.empty(K.gemm_nt_splitk_workspace_bytes(min(M, 1024), max(I, 3 * H), max(self.SKINNY_SPLITS)), device=dev,
                                     dtype=torch.uint8))
         if Kb > 1:
             # beams: two caches per layer (select_beam_items permutes rows: gather from one into the other, then swap)
             ws.update(kvA=[h(R, Lcap, 2 * H) for _ in range(NL)], kvB=[h(R, Lcap, 2 * H) for _ in range(NL)],
-                      kk_s=f(R, Kb), kk_i=i64(R, Kb), src_rows=i64(R))
+                      kk_s=f(R, Kb), kk_i=i64(R, Kb), src_rows=i64(R), tot=f(Lcap, B, Kb), wids=i64(Lcap, B, Kb), ptrs=i64(Lcap, B, Kb),
+                      eos=f(Lcap, B, Kb))
         self._ws[key] = ws
         return ws
 
@@ -601,27 +614,76 @@ class Engine(object):
                     position_ids=pid)
         x, alt = ws["xa"], ws["xb"]
         K.layernorm_fwd(ws["emb_pre"], self.P(E + "LayerNorm.weight"), self.P(E + "LayerNorm.bias"), x, M, H)
+        def same_in_all_layers(suffix):
+            return lambda: [self.P("bert.encoder.layer.%d.%s" % (j, suffix)) for j in range(NL)]
         for i in range(NL):
             Ln = "bert.encoder.layer.%d." % i
             kv = caches[i]
-            self._nt_skinny(x, self.P(Ln + "attention.self.query.weight"), ws["qkv"], M, 3 * H, H, ws["sk_ws"], bias=self.P(Ln + "attention.self.query.bias"))
+            self._nt_skinny(x, self.P(Ln + "attention.self.query.weight"), ws["qkv"], M, 3 * H, H, ws["sk_ws"], tune_ws=same_in_all_layers("attention.self.query.weight"), bias=self.P(Ln + "attention.self.query.bias"))
             K.kv_append(ws["qkv"], 3 * H, kv, Lcap, R, T, st, H)
             K.attn_decode(ws["qkv"], 3 * H, T, kv, kv[:, :, H:], 2 * H, Lcap, maskb, ws["ctx"], R, T, Lk, A, scale)
-            self._nt_skinny(ws["ctx"], self.P(Ln + "attention.output.dense.weight"), ws["pre"], M, H, H, ws["sk_ws"], bias=self.P(Ln + "attention.output.dense.bias"),
+            self._nt_skinny(ws["ctx"], self.P(Ln + "attention.output.dense.weight"), ws["pre"], M, H, H, ws["sk_ws"], tune_ws=same_in_all_layers("attention.output.dense.weight"), bias=self.P(Ln + "attention.output.dense.bias"),
                      residual=x)
             K.layernorm_fwd(ws["pre"], self.P(Ln + "attention.output.LayerNorm.weight"), self.P(Ln + "attention.output.LayerNorm.bias"),
                             ws["x1"], M, H)
-            self._nt_skinny(ws["x1"], self.P(Ln + "intermediate.dense.weight"), ws["g"], M, I, H, ws["sk_ws"], bias=self.P(Ln + "intermediate.dense.bias"),
+            self._nt_skinny(ws["x1"], self.P(Ln + "intermediate.dense.weight"), ws["g"], M, I, H, ws["sk_ws"], tune_ws=same_in_all_layers("intermediate.dense.weight"), bias=self.P(Ln + "intermediate.dense.bias"),
                      act=K.ACT_GELU)
-            self._nt_skinny(ws["g"], self.P(Ln + "output.dense.weight"), ws["pre"], M, H, I, ws["sk_ws"], bias=self.P(Ln + "output.dense.bias"), residual=ws["x1"])
+            self._nt_skinny(ws["g"], self.P(Ln + "output.dense.weight"), ws["pre"], M, H, I, ws["sk_ws"], tune_ws=same_in_all_layers("output.dense.weight"), bias=self.P(Ln + "output.dense.bias"), residual=ws["x1"])
             K.layernorm_fwd(ws["pre"], self.P(Ln + "output.LayerNorm.weight"), self.P(Ln + "output.LayerNorm.bias"), alt, M, H)
             x, alt = alt, x
         # ---- LM head on the [MASK] slot (:1226-1228 / :1293-1296) ----------------------------------
-        ws["last"][:R].fill_(T - 1)
-        K.gather_rows(x, H, ws["last"], ws["sel"], H, R, 1, T, H)
+        K.gather_rows(x, H, ws["last_first"] if first else ws["last_step"], ws["sel"], H, R, 1, T, H)
         self._nt(ws["sel"], self.P(C + "transform.dense.weight"), ws["tg"], R, H, H, bias=self.P(C + "transform.dense.bias"), act=K.ACT_GELU)
         K.layernorm_fwd(ws["tg"], self.P(C + "transform.LayerNorm.weight"), self.P(C + "transform.LayerNorm.bias"), ws["tln"], R, H)
         self._nt(ws["tln"], self.P("bert.embeddings.word_embeddings.weight"), ws["logits"], R, V, H, bias=self.P(C + "bias"), ldy=ws["Vp"])
+
+    def _decode_static_inputs(self, ws, token_type_ids, position_ids, attention_mask, in_len, out_len, rep):
+        """Copies the caller's per-position inputs of the token steps s >= 1 into workspace buffers (one torch op each), so that the
+        launches of those steps take the same arguments on every call (launch plans).  rep = beams per sample (first_expand)."""
+        n = out_len - in_len - 1                     # steps 1 .. n_steps-1 use the position window (in_len+s-1, in_len+s)
+        if n > 0:
+            tt = token_type_ids.unfold(1, 2, 1)[:, in_len:in_len + n].transpose(0, 1)      # [n, B, 2]
+            pid = position_ids.unfold(1, 2, 1)[:, in_len:in_len + n].transpose(0, 1)
+            if rep > 1:
+                tt, pid = tt.repeat_interleave(rep, dim=1), pid.repeat_interleave(rep, dim=1)
+            ws["tt_steps"][1:n + 1].copy_(tt)
+            ws["pid_steps"][1:n + 1].copy_(pid)
+        am = attention_mask[:, :out_len, :out_len]
+        ws["mask_static"].copy_(am.repeat_interleave(rep, dim=0) if rep > 1 else am)
+
+    DECODE_GRAPHS = os.environ.get("VLP_DECODE_GRAPHS", "1") == "1"
+
+    def _run_planned(self, ws, key, fn):
+        """Token steps s >= 1 launch ~200 small kernels with call-invariant arguments; at ~4.5 us of HIP launch cost each the host, not
+        the GPU, bounded decoding.  Call 1 of a workspace runs (and autotunes) normally; call 2 captures each step into a hipGraph
+        (torch.cuda.CUDAGraph over the launches our C ABI puts on the capture stream) and replays it; later calls only replay.
+        If capture is unavailable the recorded ctypes plan (no Python argument marshalling) is the fallback."""
+        stream = torch.cuda.current_stream().cuda_stream
+        item = ws["plans"].get(key)
+        if item is not None and ws["plan_stream"] == stream:
+            if isinstance(item, list):
+                K.replay(item)
+            else:
+                item.replay()
+            return
+        if ws["calls"] == 0:
+            fn()
+            return
+        ws["plan_stream"] = stream
+        if self.DECODE_GRAPHS:
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    fn()
+                g.replay()
+                ws["plans"][key] = g
+                return
+            except Exception:                    # capture not possible here: fall back to the ctypes plan
+                torch.cuda.synchronize()
+                Engine.DECODE_GRAPHS = False
+        with K.record() as plan:
+            fn()
+        ws["plans"][key] = plan
 
     def decode_greedy(self, vis_feats, vis_pe, input_ids, token_type_ids, position_ids, attention_mask, mask_word_id, sample=False):
         """Greedy incremental decoding.  Step s feeds the tokens that are new since step s-1 plus one [MASK] slot, projects them
@@ -636,22 +698,14 @@ class Engine(object):
         ws = self._decode_workspace(B, T0, out_len)
         dev = self.device
         attention_mask = attention_mask.to(torch.long)
-        if attention_mask.stride(2) != 1:
-            attention_mask = attention_mask.contiguous()
         token_type_ids, position_ids = token_type_ids.to(torch.long), position_ids.to(torch.long)
         self._decode_regions(ws, vis_feats, vis_pe)
-        out_ids = torch.empty(B, n_steps, device=dev, dtype=torch.long)
-        out_val = torch.empty(B, n_steps, device=dev, dtype=torch.float32)
+        self._decode_static_inputs(ws, token_type_ids, position_ids, attention_mask, in_len, out_len, 1)
+        out_ids, out_val, am = ws["out_ids"], ws["out_val"], ws["mask_static"]
         x_first = torch.cat((input_ids.to(torch.long), torch.full((B, 1), int(mask_word_id), device=dev, dtype=torch.long)), dim=1).contiguous()
         ws["xids"][:, 1] = int(mask_word_id)
-        next_pos = in_len
-        for s in range(n_steps):
-            first = s == 0
-            T = T0 if first else 2
-            st = next_pos + 1 - T
-            Lk = next_pos + 1
-            self._decode_model_step(ws, ws["kv"], out_len, x_first if first else ws["xids"], token_type_ids[:, st:Lk].contiguous(),
-                                    position_ids[:, st:Lk].contiguous(), attention_mask[:, st:Lk, :Lk], B, T, st, first)
+
+        def pick(s):
             if sample:
                 self.step_seed += 1
                 for dst in (out_ids[:, s], ws["xids"][:, 0]):                   # same (seed, stream) -> same draw; 2nd = next input token
@@ -659,8 +713,24 @@ class Engine(object):
             else:
                 K.argmax_rows(ws["logits"], ws["Vp"], B, V, out_ids[:, s], out_val[:, s])
                 K.argmax_rows(ws["logits"], ws["Vp"], B, V, ws["xids"][:, 0], out_val[:, s])      # next step's first input token
-            next_pos += 1
-        return out_ids, out_val
+
+        # step 0: the whole prefix + [MASK]
+        self._decode_model_step(ws, ws["kv"], out_len, x_first, token_type_ids[:, :T0].contiguous(), position_ids[:, :T0].contiguous(),
+                                am[:, :T0, :T0], B, T0, 0, True)
+        pick(0)
+        for s in range(1, n_steps):
+            st = in_len + s - 1
+
+            def step(s=s, st=st):
+                self._decode_model_step(ws, ws["kv"], out_len, ws["xids"], ws["tt_steps"][s], ws["pid_steps"][s], am[:, st:st + 2, :st + 2],
+                                        B, 2, st, False)
+                pick(s)
+            if sample:
+                step()                       # the seed changes every step: not plannable
+            else:
+                self._run_planned(ws, ("greedy", s), step)
+        ws["calls"] += 1
+        return out_ids[:, :n_steps].clone(), out_val[:, :n_steps].clone()
 
     def decode_beam(self, vis_feats, vis_pe, input_ids, token_type_ids, position_ids, attention_mask, mask_word_id, beam_size, eos_id,
                     min_len=0, forbid_fn=None):
@@ -687,46 +757,48 @@ class Engine(object):
             attention_mask = attention_mask.contiguous()
         token_type_ids, position_ids = token_type_ids.to(torch.long), position_ids.to(torch.long)
         self._decode_regions(ws, vis_feats, vis_pe)
-        tot = torch.empty(n_steps, B, Kb, device=dev, dtype=torch.float32)
-        wids = torch.empty(n_steps, B, Kb, device=dev, dtype=torch.long)
-        ptrs = torch.empty(n_steps, B, Kb, device=dev, dtype=torch.long)
-        eos = torch.empty(n_steps, B, Kb, device=dev, dtype=torch.float32)
+        self._decode_static_inputs(ws, token_type_ids, position_ids, attention_mask, in_len, out_len, Kb)     # first_expand (:1361-1365)
+        tot, wids, ptrs, eos, am = ws["tot"], ws["wids"], ws["ptrs"], ws["eos"], ws["mask_static"]
         x_first = torch.cat((input_ids.to(torch.long), torch.full((B, 1), int(mask_word_id), device=dev, dtype=torch.long)), dim=1).contiguous()
         ws["xids"][:, 1] = int(mask_word_id)
-        cur, other = ws["kvA"], ws["kvB"]
+        bufs = (ws["kvA"], ws["kvB"])
         forbid = None
-        next_pos = in_len
-        for s in range(n_steps):
-            first = s == 0
-            T = T0 if first else 2
-            st = next_pos + 1 - T
-            Lk = next_pos + 1
-            rows = B if first else R
-            self._decode_model_step(ws, ws["kv"] if first else cur, out_len, x_first if first else ws["xids"],
-                                    token_type_ids[:, st:Lk].contiguous(), position_ids[:, st:Lk].contiguous(), attention_mask[:, st:Lk, :Lk],
-                                    rows, T, st, first)
-            block_eos = bool(min_len) and (next_pos - in_len + 1 <= min_len)
+
+        def frame(s, rows, first, forbid, block_eos):
             K.logsoftmax_topk(ws["logits"], ws["Vp"], rows, V, Kb, ws["kk_s"], ws["kk_i"], forbid=forbid, eos_id=int(eos_id), block_eos=block_eos)
             K.beam_select(ws["kk_s"], ws["kk_i"], None if first else tot[s - 1], None if first else eos[s - 1], tot[s], wids[s], ptrs[s], eos[s],
                           ws["src_rows"], ws["xids"][:, 0], B, Kb, first, int(eos_id))
-            if first:
-                # first_expand (:1325-1332, 1361-1365): caches, and the per-sample inputs of all later steps
-                for i in range(NL):
-                    K.kv_gather(ws["kv"][i], out_len, cur[i], out_len, ws["src_rows"], R, 0, in_len, 2 * H)
-                    K.kv_gather(ws["kv"][i], out_len, other[i], out_len, ws["src_rows"], R, 0, in_len, 2 * H)
-                token_type_ids = token_type_ids.repeat_interleave(Kb, dim=0)
-                position_ids = position_ids.repeat_interleave(Kb, dim=0)
-                attention_mask = attention_mask.repeat_interleave(Kb, dim=0)
-            elif s + 1 < n_steps:
-                # select_beam_items (:1334-1359): generated positions in_len .. next_pos-1 follow their beam
-                for i in range(NL):
-                    K.kv_gather(cur[i], out_len, other[i], out_len, ws["src_rows"], R, in_len, next_pos, 2 * H)
-                cur, other = other, cur
+
+        # step 0: B sequences; then first_expand of the caches (:1325-1332) into both ping-pong buffers
+        self._decode_model_step(ws, ws["kv"], out_len, x_first, token_type_ids[:, :T0].contiguous(), position_ids[:, :T0].contiguous(),
+                                attention_mask[:, :T0, :T0], B, T0, 0, True)
+        frame(0, B, True, None, bool(min_len) and (1 <= min_len))
+        for i in range(NL):
+            K.kv_gather(ws["kv"][i], out_len, bufs[0][i], out_len, ws["src_rows"], R, 0, in_len, 2 * H)
+            K.kv_gather(ws["kv"][i], out_len, bufs[1][i], out_len, ws["src_rows"], R, 0, in_len, 2 * H)
+        if forbid_fn is not None:
+            fm = forbid_fn(wids[0].tolist(), ptrs[0].tolist(), True)
+            forbid = None if fm is None else torch.from_numpy(fm).to(dev)
+        for s in range(1, n_steps):
+            st = in_len + s - 1
+            cur, other = bufs[(s - 1) & 1], bufs[s & 1]            # the caches swap after every step >= 1
+            block_eos = bool(min_len) and (s + 1 <= min_len)
+
+            def step(s=s, st=st, cur=cur, other=other, block_eos=block_eos, forbid=forbid):
+                self._decode_model_step(ws, cur, out_len, ws["xids"], ws["tt_steps"][s], ws["pid_steps"][s], am[:, st:st + 2, :st + 2], R, 2, st,
+                                        False)
+                frame(s, R, False, forbid, block_eos)
+                if s + 1 < n_steps:      # select_beam_items (:1334-1359): generated positions in_len .. st follow their beam
+                    for i in range(NL):
+                        K.kv_gather(cur[i], out_len, other[i], out_len, ws["src_rows"], R, in_len, st + 1, 2 * H)
             if forbid_fn is not None:
-                fm = forbid_fn(wids[s].tolist(), ptrs[s].tolist(), first)
+                step()                   # the forbid mask is a fresh tensor every step: not plannable
+                fm = forbid_fn(wids[s].tolist(), ptrs[s].tolist(), False)
                 forbid = None if fm is None else torch.from_numpy(fm).to(dev)
-            next_pos += 1
-        return tot, wids, ptrs
+            else:
+                self._run_planned(ws, ("beam", s, int(eos_id), block_eos), step)
+        ws["calls"] += 1
+        return tot[:n_steps].clone(), wids[:n_steps].clone(), ptrs[:n_steps].clone()
 
     # ------------------------------------------------------------------------------------------
     # backward
