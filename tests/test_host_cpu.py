@@ -191,3 +191,36 @@ def test_compat_import_paths():
         "print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def test_launch_plan_record_and_replay(monkeypatch):
+    """_lib.record() executes AND collects the C calls of a block; replay() re-issues them and surfaces a failing status."""
+    from vlp_amd import _lib
+    calls = []
+
+    class FakeLib(object):
+        def vlp_a(self, x, y):
+            calls.append(("a", x, y))
+            return 0
+
+        def vlp_b(self, x):
+            calls.append(("b", x))
+            return 0 if x != 13 else -2
+
+        def vlp_last_error_string(self):
+            return b"boom"
+
+    monkeypatch.setattr(_lib, "_lib", FakeLib())
+    with _lib.record() as plan:
+        assert _lib.load().vlp_a(1, 2) == 0 and _lib.load().vlp_b(5) == 0
+        with pytest.raises(RuntimeError):
+            with _lib.record():
+                pass                                    # no nesting
+    assert calls == [("a", 1, 2), ("b", 5)] and len(plan) == 2
+    assert _lib.load() is _lib._lib                     # recording ended
+    _lib.replay(plan)
+    assert calls == [("a", 1, 2), ("b", 5)] * 2
+    with _lib.record() as bad:
+        _lib.load().vlp_b(13)
+    with pytest.raises(RuntimeError, match="boom"):
+        _lib.replay(bad)
