@@ -272,7 +272,7 @@ def test_sample_mode_end_to_end():
 from oracle.make_golden import BEAM_CASES                  # noqa: E402  (pure data)
 
 
-@pytest.mark.parametrize("rows,V,Kb", [(5, 1000, 3), (64, 28996, 5), (2, 50, 50)])
+@pytest.mark.parametrize("rows,V,Kb", [(5, 1000, 3), (64, 28996, 5), (2, 50, 50), (7, 28996, 8), (3, 100, 16), (2, 17, 16), (1, 300, 1)])
 def test_logsoftmax_topk(rows, V, Kb):
     Vp = (V + 63) // 64 * 64
     g = torch.Generator().manual_seed(V + Kb)

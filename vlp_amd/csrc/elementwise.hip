@@ -657,11 +657,96 @@ __global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const f16* logits,
         __syncthreads();
     }
 }
+// Two-pass variant for K <= KMAX (<= 16): pass 1 = max / sum-exp, pass 2 = every thread keeps the KMAX best of its strided elements in
+// registers (sorted; an element is first tested against the thread's worst entry, so almost all cost one compare), then K rounds of a
+// 256-candidate block arg-max over the threads' heads.  Same results as the K+2-pass kernel above (value descending, index ascending).
+template <int KMAX>
+__global__ __launch_bounds__(256) void logsoftmax_topk_small_kernel(const f16* logits, int64_t ld, int V, int K, const uint8_t* forbid, int eos_id,
+                                                                    int block_eos, float* out_scores, int64_t* out_ids) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const f16* x = logits + (int64_t)row * ld;
+    const uint8_t* fb = forbid ? forbid + (int64_t)row * V : nullptr;
+    float mx = -INFINITY;
+    for (int v = tid; v < V; v += 256) mx = fmaxf(mx, (float)x[v]);
+    sv[tid] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) sv[tid] = fmaxf(sv[tid], sv[tid + o]);
+        __syncthreads();
+    }
+    mx = sv[0];
+    __syncthreads();
+    float sum = 0.f;
+    for (int v = tid; v < V; v += 256) sum += __expf((float)x[v] - mx);
+    sv[tid] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) sv[tid] += sv[tid + o];
+        __syncthreads();
+    }
+    const float lse = mx + __logf(sv[0]);
+    __syncthreads();
+    float lv[KMAX];
+    int lidx[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) { lv[j] = -INFINITY; lidx[j] = 0x7fffffff; }
+    for (int v = tid; v < V; v += 256) {
+        float val = (float)x[v] - lse;
+        if (fb && fb[v]) val += -10000.0f;
+        if (block_eos && v == eos_id) val = -10000.0f;
+        if (val > lv[KMAX - 1] || (val == lv[KMAX - 1] && v < lidx[KMAX - 1])) {
+            int vi = v;
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j) {         // insertion into the sorted list (compare-and-swap down the chain)
+                const bool better = val > lv[j] || (val == lv[j] && vi < lidx[j]);
+                const float tv = better ? lv[j] : val;
+                const int ti = better ? lidx[j] : vi;
+                lv[j] = better ? val : lv[j];
+                lidx[j] = better ? vi : lidx[j];
+                val = tv;
+                vi = ti;
+            }
+        }
+    }
+    for (int k = 0; k < K; ++k) {
+        sv[tid] = lv[0];
+        si[tid] = lidx[0];
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) {
+                const float f = sv[tid + o];
+                const int j = si[tid + o];
+                if (f > sv[tid] || (f == sv[tid] && j < si[tid])) { sv[tid] = f; si[tid] = j; }
+            }
+            __syncthreads();
+        }
+        const float wv = sv[0];
+        const int wi = si[0];
+        if (tid == 0) { out_scores[(int64_t)row * K + k] = wv; out_ids[(int64_t)row * K + k] = wi; }
+        if (lidx[0] == wi) {                         // the winner pops its head
+#pragma unroll
+            for (int j = 0; j + 1 < KMAX; ++j) { lv[j] = lv[j + 1]; lidx[j] = lidx[j + 1]; }
+            lv[KMAX - 1] = -INFINITY;
+            lidx[KMAX - 1] = 0x7fffffff;
+        }
+        __syncthreads();
+    }
+}
 extern "C" int vlp_logsoftmax_topk(const void* logits, int64_t ld, int32_t rows, int32_t V, int32_t K, const uint8_t* forbid, int32_t eos_id,
                                    int32_t block_eos, float* out_scores, int64_t* out_ids, void* stream) {
     VLP_CHECK_ARG(logits && out_scores && out_ids && rows > 0 && V > 0 && K > 0 && K <= V && ld >= V, "vlp_logsoftmax_topk: bad args");
-    hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const f16*)logits, ld, V, K, forbid, eos_id, block_eos,
-                       out_scores, out_ids);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_TOPK(KM) hipLaunchKernelGGL(logsoftmax_topk_small_kernel<KM>, dim3(rows), dim3(256), 0, s, (const f16*)logits, ld, V, K, forbid, eos_id, \
+                                           block_eos, out_scores, out_ids)
+    if (K <= 4) LAUNCH_TOPK(4);
+    else if (K <= 8) LAUNCH_TOPK(8);
+    else if (K <= 16) LAUNCH_TOPK(16);
+    else
+        hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(rows), dim3(256), 0, s, (const f16*)logits, ld, V, K, forbid, eos_id, block_eos,
+                           out_scores, out_ids);
+#undef LAUNCH_TOPK
     VLP_CHECK_LAUNCH("vlp_logsoftmax_topk");
     return VLP_OK;
 }
