@@ -149,6 +149,13 @@ typedef struct {
     void* ctx; int64_t ld_ctx;
     int32_t B, Lq, Lk, heads;
     float scale;
+    /* beam search: key/value rows [0, n_prefix) of sequence b are read from a cache SHARED by the `beams` sequences of one sample
+     * (row b / beams of k_prefix / v_prefix, kv-style [*, prefix_rows_per_batch, ld_kv] layout), rows >= n_prefix from k / v.
+     * The prefix (regions + [SEP]) is identical for all beams (select_beam_items only permutes generated positions), so it is
+     * stored and streamed once per sample.  n_prefix = 0: everything comes from k / v. */
+    const void* k_prefix; const void* v_prefix;
+    int64_t prefix_rows_per_batch;
+    int32_t n_prefix, beams;
 } vlp_attn_decode_args;
 int vlp_attn_decode(const vlp_attn_decode_args* a, void* stream);
 

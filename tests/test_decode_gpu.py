@@ -101,6 +101,28 @@ def test_attn_decode_vs_torch(B, Lq, Lk, Lcap, heads):
     assert err < 4e-3, err
 
 
+def test_attn_decode_shared_prefix():
+    """Beam form: rows < n_prefix from the per-sample cache, the rest from the per-beam cache == everything from one expanded cache."""
+    B, Kb, Lq, Lk, Lcap, heads, npre = 2, 3, 2, 110, 122, 12, 102
+    H, R = heads * 64, 2 * 3
+    g = torch.Generator().manual_seed(9)
+    q = (torch.randn(R * Lq, 3 * H, generator=g) * 0.8).half().to(DEV)
+    sample_cache = (torch.randn(B, Lcap, 2 * H, generator=g) * 0.8).half().to(DEV)
+    beam_cache = (torch.randn(R, Lcap, 2 * H, generator=g) * 0.8).half().to(DEV)      # its rows < npre are garbage on purpose
+    full = beam_cache.clone()
+    full[:, :npre] = sample_cache.repeat_interleave(Kb, dim=0)[:, :npre]
+    mask = (torch.rand(R, Lq, Lk, generator=g) < 0.8).long().to(DEV)
+    mask[:, :, 0] = 1
+    Lkp = (Lk + 31) // 32 * 32
+    mb = torch.empty(R, Lq, Lkp, dtype=torch.uint8, device=DEV)
+    K.mask_pack_rect(mask, mb, R, Lq, Lk, Lkp)
+    ref, got = torch.zeros(R * Lq, H, dtype=torch.float16, device=DEV), torch.zeros(R * Lq, H, dtype=torch.float16, device=DEV)
+    K.attn_decode(q, 3 * H, Lq, full, full[:, :, H:], 2 * H, Lcap, mb, ref, R, Lq, Lk, heads, 0.125)
+    K.attn_decode(q, 3 * H, Lq, beam_cache, beam_cache[:, :, H:], 2 * H, Lcap, mb, got, R, Lq, Lk, heads, 0.125, k_prefix=sample_cache,
+                  v_prefix=sample_cache[:, :, H:], prefix_rows=Lcap, n_prefix=npre, beams=Kb)
+    assert torch.equal(ref, got)
+
+
 def test_embed_position_ids():
     B, T, H, V = 3, 2, 128, 50
     g = torch.Generator().manual_seed(3)

@@ -75,7 +75,8 @@ class EmbedFwdArgs(C.Structure):
 
 class AttnDecodeArgs(C.Structure):
     _fields_ = [("q", vp), ("ld_q", i64), ("q_rows_per_batch", i64), ("k", vp), ("v", vp), ("ld_kv", i64), ("kv_rows_per_batch", i64),
-                ("mask", vp), ("ctx", vp), ("ld_ctx", i64), ("B", i32), ("Lq", i32), ("Lk", i32), ("heads", i32), ("scale", f32)]
+                ("mask", vp), ("ctx", vp), ("ld_ctx", i64), ("B", i32), ("Lq", i32), ("Lk", i32), ("heads", i32), ("scale", f32),
+                ("k_prefix", vp), ("v_prefix", vp), ("prefix_rows_per_batch", i64), ("n_prefix", i32), ("beams", i32)]
 
 
 class VisPePrepArgs(C.Structure):
@@ -332,9 +333,11 @@ def attn_bwd(qkv, mask, mask_t, ctx, dctx, lse, dqkv, delta, B, L, heads, scale,
     _check(load().vlp_attn_bwd(C.byref(a), stream_ptr()))
 
 
-def attn_decode(q, ld_q, q_rows, k, v, ld_kv, kv_rows, mask, ctx, B, Lq, Lk, heads, scale):
-    _req_cuda(q, k, v, mask, ctx)
-    a = AttnDecodeArgs(ptr(q), ld_q, q_rows, ptr(k), ptr(v), ld_kv, kv_rows, ptr(mask), ptr(ctx), ctx.stride(0), B, Lq, Lk, heads, scale)
+def attn_decode(q, ld_q, q_rows, k, v, ld_kv, kv_rows, mask, ctx, B, Lq, Lk, heads, scale, k_prefix=None, v_prefix=None, prefix_rows=0,
+                n_prefix=0, beams=1):
+    _req_cuda(q, k, v, mask, ctx, k_prefix, v_prefix)
+    a = AttnDecodeArgs(ptr(q), ld_q, q_rows, ptr(k), ptr(v), ld_kv, kv_rows, ptr(mask), ptr(ctx), ctx.stride(0), B, Lq, Lk, heads, scale,
+                       ptr(k_prefix), ptr(v_prefix), prefix_rows, n_prefix, beams)
     _check(load().vlp_attn_decode(C.byref(a), stream_ptr()))
 
 

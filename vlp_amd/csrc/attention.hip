@@ -47,15 +47,19 @@ struct AttnParams {
     const f16* q; int64_t ld_q; int64_t bs_q;      // row (b, i) at q + (b*bs_q + i)*ld_q   (+ h*64)
     const f16* k; const f16* v; int64_t ld_kv; int64_t bs_kv;
     int Lq, Lk;
+    // decode with beams: rows [0, n_prefix) of sequence b come from the per-SAMPLE cache k2 / v2 (row b / beams), the rest from k / v
+    const f16* k2; const f16* v2; int64_t bs_kv2; int n_prefix, beams;
 };
 
 // ---- LDS staging helpers ---------------------------------------------------------------------
 // row-major, 128-B rows, chunk-swizzled: dst[key][64]; rows >= L are zero.
-DEVFN void stage_rowmajor(f16* dst, const f16* src, int64_t ld, int L, int Lp, int tid, int nthreads = ATT_THREADS) {
+// rows < n_first come from src_first (shared prefix of a beam group), the others from src
+DEVFN void stage_rowmajor(f16* dst, const f16* src, int64_t ld, int L, int Lp, int tid, int nthreads = ATT_THREADS, const f16* src_first = nullptr,
+                          int n_first = 0) {
     for (int idx = tid; idx < Lp * 8; idx += nthreads) {
         const int r = idx >> 3, c = idx & 7;
         u32x4 v = (u32x4){0, 0, 0, 0};
-        if (r < L) v = *reinterpret_cast<const u32x4*>(src + (int64_t)r * ld + c * 8);
+        if (r < L) v = *reinterpret_cast<const u32x4*>((r < n_first ? src_first : src) + (int64_t)r * ld + c * 8);
         *reinterpret_cast<u32x4*>(dst + r * HD + ((c ^ swzk(r)) << 3)) = v;
     }
 }
@@ -120,8 +124,10 @@ __global__ __launch_bounds__(ATT_THREADS8, NT <= 12 ? 4 : 2) void attn_fwd_kerne
     const f16* kbase = p.k + (int64_t)b * p.bs_kv * p.ld_kv + h * HD;
     const f16* vbase = p.v + (int64_t)b * p.bs_kv * p.ld_kv + h * HD;
 
-    stage_rowmajor(Ks, kbase, p.ld_kv, L, LP, tid, ATT_THREADS8);
-    stage_rowmajor(Vs, vbase, p.ld_kv, L, LP, tid, ATT_THREADS8);
+    const f16* kpre = p.n_prefix ? p.k2 + (int64_t)(b / p.beams) * p.bs_kv2 * p.ld_kv + h * HD : nullptr;
+    const f16* vpre = p.n_prefix ? p.v2 + (int64_t)(b / p.beams) * p.bs_kv2 * p.ld_kv + h * HD : nullptr;
+    stage_rowmajor(Ks, kbase, p.ld_kv, L, LP, tid, ATT_THREADS8, kpre, p.n_prefix);
+    stage_rowmajor(Vs, vbase, p.ld_kv, L, LP, tid, ATT_THREADS8, vpre, p.n_prefix);
     __syncthreads();
 
     const int nqt = (Lq + 15) / 16;
@@ -499,6 +505,13 @@ extern "C" int vlp_attn_decode(const vlp_attn_decode_args* a, void* stream) {
     p.q = (const f16*)a->q; p.ld_q = a->ld_q; p.bs_q = a->q_rows_per_batch;
     p.k = (const f16*)a->k; p.v = (const f16*)a->v; p.ld_kv = a->ld_kv; p.bs_kv = a->kv_rows_per_batch;
     p.Lq = a->Lq; p.Lk = a->Lk;
+    if (a->n_prefix > 0) {
+        VLP_CHECK_ARG(a->k_prefix && a->v_prefix && a->beams > 0 && a->n_prefix <= a->Lk && a->prefix_rows_per_batch >= a->n_prefix &&
+                          a->B % a->beams == 0 && ((uintptr_t)a->k_prefix | (uintptr_t)a->v_prefix) % 16 == 0,
+                      "vlp_attn_decode: bad shared-prefix arguments");
+        p.k2 = (const f16*)a->k_prefix; p.v2 = (const f16*)a->v_prefix; p.bs_kv2 = a->prefix_rows_per_batch;
+        p.n_prefix = a->n_prefix; p.beams = a->beams;
+    }
     return launch_attn_fwd(p, (hipStream_t)stream);
 }
 

@@ -595,10 +595,12 @@ class Engine(object):
         self._nt(ws["h1"], self.P("vis_embed.2.weight"), ws["vis_h"], Mv, H, 2048, bias=self.P("vis_embed.2.bias"), act=K.ACT_RELU)
         self._nt(ws["vpe_in"], ws["wpe_pad"], ws["vispe_h"], Mv, H, PE_PAD, bias=self.P("vis_pe_embed.0.bias"), act=K.ACT_RELU)
 
-    def _decode_model_step(self, ws, caches, Lcap, xids, tt, pid, mask_view, R, T, st, first):
+    def _decode_model_step(self, ws, caches, Lcap, xids, tt, pid, mask_view, R, T, st, first, prefix=None):
         """One incremental forward of R sequences x T new tokens at absolute positions st..st+T-1: Q/K/V projection of the new
         tokens, K|V appended to the per-layer caches, attention over positions 0..st+T-1, LM head on the last ([MASK]) slot.
-        Leaves the logits [R, V] in ws['logits'] (pitch ws['Vp'])."""
+        Leaves the logits [R, V] in ws['logits'] (pitch ws['Vp']).  prefix = (per-sample caches, n_prefix, beams): beam search keeps
+        the positions < n_prefix (regions + [SEP], identical for all beams of a sample) once per sample; `caches` then hold only
+        the generated positions of every beam."""
         model = self._model()
         cfg = model.config
         H, I, A, NL, Nv, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers, model.len_vis_input, cfg.vocab_size
@@ -621,7 +623,12 @@ class Engine(object):
             kv = caches[i]
             self._nt_skinny(x, self.P(Ln + "attention.self.query.weight"), ws["qkv"], M, 3 * H, H, ws["sk_ws"], tune_ws=same_in_all_layers("attention.self.query.weight"), bias=self.P(Ln + "attention.self.query.bias"))
             K.kv_append(ws["qkv"], 3 * H, kv, Lcap, R, T, st, H)
-            K.attn_decode(ws["qkv"], 3 * H, T, kv, kv[:, :, H:], 2 * H, Lcap, maskb, ws["ctx"], R, T, Lk, A, scale)
+            if prefix is None:
+                K.attn_decode(ws["qkv"], 3 * H, T, kv, kv[:, :, H:], 2 * H, Lcap, maskb, ws["ctx"], R, T, Lk, A, scale)
+            else:
+                pk = prefix[0][i]
+                K.attn_decode(ws["qkv"], 3 * H, T, kv, kv[:, :, H:], 2 * H, Lcap, maskb, ws["ctx"], R, T, Lk, A, scale, k_prefix=pk,
+                              v_prefix=pk[:, :, H:], prefix_rows=Lcap, n_prefix=prefix[1], beams=prefix[2])
             self._nt_skinny(ws["ctx"], self.P(Ln + "attention.output.dense.weight"), ws["pre"], M, H, H, ws["sk_ws"], tune_ws=same_in_all_layers("attention.output.dense.weight"), bias=self.P(Ln + "attention.output.dense.bias"),
                      residual=x)
             K.layernorm_fwd(ws["pre"], self.P(Ln + "attention.output.LayerNorm.weight"), self.P(Ln + "attention.output.LayerNorm.bias"),
@@ -736,7 +743,8 @@ class Engine(object):
                     min_len=0, forbid_fn=None):
         """Beam search frames (modeling.py:1255-1430) on the K/V-cache decoder.  The first step runs B sequences; its cache rows are
         replicated to the B*K beams (first_expand), afterwards every step decodes B*K sequences and the caches follow the back
-        pointers (select_beam_items) -- only the generated positions, the prefix is identical for all beams of a sample.
+        pointers (select_beam_items) -- only the generated positions; the prefix is identical for all beams of a sample and is kept,
+        and streamed by the attention kernel, once per sample.
         `forbid_fn(step_ids [B,K] list, back_ptrs [B,K] list, first)` -> uint8 [B*K, V] numpy mask or None implements the host-side
         n-gram blocking (:1367-1430); when given, ids / pointers are copied to the host every step exactly as the reference does.
         Returns (total_scores, step_ids, back_ptrs) as [frames, B, K] tensors on the device."""
@@ -769,13 +777,12 @@ class Engine(object):
             K.beam_select(ws["kk_s"], ws["kk_i"], None if first else tot[s - 1], None if first else eos[s - 1], tot[s], wids[s], ptrs[s], eos[s],
                           ws["src_rows"], ws["xids"][:, 0], B, Kb, first, int(eos_id))
 
-        # step 0: B sequences; then first_expand of the caches (:1325-1332) into both ping-pong buffers
+        # step 0: B sequences.  first_expand (:1325-1332) is implicit: the prefix K|V of a sample stays in its per-sample cache and is
+        # shared by its beams inside the attention kernel; the per-beam caches only ever hold generated positions
         self._decode_model_step(ws, ws["kv"], out_len, x_first, token_type_ids[:, :T0].contiguous(), position_ids[:, :T0].contiguous(),
                                 attention_mask[:, :T0, :T0], B, T0, 0, True)
         frame(0, B, True, None, bool(min_len) and (1 <= min_len))
-        for i in range(NL):
-            K.kv_gather(ws["kv"][i], out_len, bufs[0][i], out_len, ws["src_rows"], R, 0, in_len, 2 * H)
-            K.kv_gather(ws["kv"][i], out_len, bufs[1][i], out_len, ws["src_rows"], R, 0, in_len, 2 * H)
+        prefix = (ws["kv"], in_len, Kb)
         if forbid_fn is not None:
             fm = forbid_fn(wids[0].tolist(), ptrs[0].tolist(), True)
             forbid = None if fm is None else torch.from_numpy(fm).to(dev)
@@ -786,7 +793,7 @@ class Engine(object):
 
             def step(s=s, st=st, cur=cur, other=other, block_eos=block_eos, forbid=forbid):
                 self._decode_model_step(ws, cur, out_len, ws["xids"], ws["tt_steps"][s], ws["pid_steps"][s], am[:, st:st + 2, :st + 2], R, 2, st,
-                                        False)
+                                        False, prefix=prefix)
                 frame(s, R, False, forbid, block_eos)
                 if s + 1 < n_steps:      # select_beam_items (:1334-1359): generated positions in_len .. st follow their beam
                     for i in range(NL):
