@@ -368,17 +368,16 @@ class Engine(object):
                 e1.synchronize()
                 return e0.elapsed_time(e1)
             torch.cuda.synchronize()
-            ch, best_t = None, float("inf")
-            for v in self.NT_CANDIDATES_SKINNY:
-                t = timed(lambda ww, v=v: K.gemm_nt(x, ww, y, M, N, Kd, variant=v, **kw))
-                if t < best_t:
-                    ch, best_t = ("v", v), t
-            for sp in self.SKINNY_SPLITS:
-                if Kd // 64 < sp:
-                    continue
-                t = timed(lambda ww, sp=sp: K.gemm_nt_splitk(x, ww, y, M, N, Kd, sp, skws, **kw))
-                if t < best_t:
-                    ch, best_t = ("s", sp), t
+            cands = [("v", v) for v in self.NT_CANDIDATES_SKINNY] + [("s", sp) for sp in self.SKINNY_SPLITS if Kd // 64 >= sp]
+            score = {c: float("inf") for c in cands}
+            for rnd in range(3):                     # interleaved rounds, best-of per candidate: these are 5-40 us kernels, one noisy
+                for c in cands:                      # sample would otherwise pin a bad choice for the life of the process
+                    if c[0] == "v":
+                        t = timed(lambda ww, v=c[1]: K.gemm_nt(x, ww, y, M, N, Kd, variant=v, **kw))
+                    else:
+                        t = timed(lambda ww, sp=c[1]: K.gemm_nt_splitk(x, ww, y, M, N, Kd, sp, skws, **kw))
+                    score[c] = min(score[c], t)
+            ch = min(cands, key=lambda c: score[c])
             K.gemm_nt(x, w, y, M, N, Kd, variant=1, **kw)        # leave y as computed from the caller's weight
             Engine._skinny_choice[key] = ch
         if ch[0] == "v":
