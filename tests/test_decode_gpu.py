@@ -8,7 +8,6 @@ exceeds the fp16 evaluation noise (MARGIN_TOL); a flip is only tolerated at a st
 and the sample is then compared only up to that step (later inputs differ).  The returned scores (max logits)
 must agree to SCORE_TOL relative.
 """
-import math
 import os
 
 import numpy as np

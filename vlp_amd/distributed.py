@@ -17,7 +17,6 @@ autograd graph, so the reducer lives here instead:
   * reduction is the MEAN over ranks (torch DDP semantics) -- ReduceOp.AVG on RCCL; on
     backends without AVG (gloo, used by the CPU tests) SUM followed by a 1/world scale.
 """
-import torch
 import torch.distributed as dist
 from torch import nn
 
