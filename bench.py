@@ -30,12 +30,13 @@ MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16 MFMA peak, /opt/skills/guid
 FLOP_PER_SAMPLE = 92.805e9         # fwd+bwd dense contractions at L=167
 
 
-def cpu_baseline_worker(seconds_budget, threads):
-    """oracle (kind 'port'): fp32 forward + backward + BertAdam on the host cores, B=8, L=167, 12 layers."""
+def cpu_baseline_worker(seconds_budget, threads, B=16):
+    """oracle (kind 'port'): fp32 forward + backward + BertAdam on the host cores, B=16 (BASELINE.md section 3 protocol), L=167,
+    12 layers.  /root/reference does not exist on the GPU box, so this is the oracle restatement (pinned to the unmodified
+    reference in tests/test_oracle_vs_reference.py), not the reference's own code: "reference_code": false."""
     torch.set_num_threads(threads)
     from oracle import vlp_oracle as O
     from vlp_amd import synthetic as S
-    B = 8
     p = O.init_params(vocab_size=28996, layers=12, tasks="img2txt", seed=0)
     p = {k: v.requires_grad_(True) for k, v in p.items()}
     batch = S.make_batch(B, max_len_b=64, vocab_size=28996, max_pred=3, seed=1234)
@@ -62,7 +63,7 @@ def cpu_baseline_worker(seconds_budget, threads):
     dt = time.time() - t0
     if n == 0:
         n, dt = 1, warm
-    return {"value": round(B * n / dt, 3), "unit": "samples/s", "cores": threads, "kind": "port",
+    return {"value": round(B * n / dt, 3), "unit": "samples/s", "cores": threads, "kind": "port", "reference_code": False, "batch": B,
             "sample": "%d steps of B=%d, L=167, 12 layers, fp32 fwd+bwd+BertAdam (oracle/vlp_oracle.py), %d of %d host threads"
                       % (n, B, threads, os.cpu_count() or 1)}
 
@@ -93,6 +94,10 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE: 64)")
     ap.add_argument("--max_len_b", type=int, default=64)
     ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--tasks", default="img2txt", choices=["img2txt", "vqa2"],
+                    help="img2txt = BASELINE configs[1-3] (masked-LM head); vqa2 = configs[4] (bidirectional, P=1, answer classifier + BCE)")
+    ap.add_argument("--s2s_prob", type=float, default=1.0, help="per-sample probability of a seq2seq mask (1.0 = COCO fine-tune, "
+                                                                "0.75 = Conceptual Captions pre-training shape, configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL + the DDP wrapper even for one rank (path check)")
@@ -124,7 +129,7 @@ def main():
 
     torch.manual_seed(0)
     cfg = BertConfig(28996, num_hidden_layers=args.layers, type_vocab_size=6, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
-    model = BertForPreTrainingLossMask(cfg, num_labels=2, enable_butd=True, len_vis_input=100, tasks="img2txt", allow_random_fc7=True)
+    model = BertForPreTrainingLossMask(cfg, num_labels=2, enable_butd=True, len_vis_input=100, tasks=args.tasks, allow_random_fc7=True)
     model.half().to(dev)
     eng = model.engine
     if use_dist:
@@ -135,8 +140,8 @@ def main():
               {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": 0.0}]
     opt = FP16_Optimizer_State(FusedAdam(groups, lr=3e-5, bias_correction=False, max_grad_norm=1.0), dynamic_loss_scale=True)
     model.train()
-    pool = [S.batch_to(S.make_batch(args.batch, max_len_b=args.max_len_b, vocab_size=28996, max_pred=3, s2s_prob=1.0,
-                                    seed=1234 + 100 * rank + i), dev, half=True) for i in range(2)]
+    pool = [S.batch_to(S.make_batch(args.batch, max_len_b=args.max_len_b, vocab_size=28996, max_pred=1 if args.tasks == "vqa2" else 3,
+                                    s2s_prob=args.s2s_prob, tasks=args.tasks, seed=1234 + 100 * rank + i), dev, half=True) for i in range(2)]
     t_total = 100000
 
     def one(i):
@@ -162,24 +167,35 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
-    loss = float(lt[0].detach())
+    loss = float((lt[0] + lt[1] + lt[2]).sum().detach())
     prof, eng.prof = eng.prof, None
 
+    if args.tasks == "vqa2":
+        shape_name = "VQA 2.0 fine-tune shape (bidirectional masks, P=1, answer-classifier head + BCE)"
+    elif args.s2s_prob < 1.0:
+        shape_name = "Conceptual Captions pre-training shape (per-sample seq2seq w.p. %.2f / bidirectional masks)" % args.s2s_prob
+    else:
+        shape_name = "COCO Captions fine-tune shape"
     if rank == 0:
         roof = None
         if prof:
             ms = [a.elapsed_time(b) for a, b, _ in prof]
             flops = [f for _, _, f in prof]
             achieved = (sum(flops) / len(flops)) / (sum(ms) / len(ms) * 1e-3) / 1e12
-            traffic = None
-            tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            if os.path.exists(tf):
-                try:
-                    traffic = json.load(open(tf)).get("gemm_nt_bytes_per_launch")
-                except Exception:
-                    traffic = None
+            # HBM traffic of the same kernel comes from a separate rocprofv3 --pmc pass (counters cannot be read inside this
+            # process): profiles/<round>_pmc_traffic.json, produced by tools/gpu_pmc_bench.sh on the same command; the field
+            # `traffic_source` says so.  null when no such file is committed.
+            traffic, traffic_src = None, None
+            for name in ("r02_pmc_traffic.json",):
+                tf = os.path.join(ROOT, "profiles", name)
+                if os.path.exists(tf):
+                    try:
+                        traffic = json.load(open(tf)).get("gemm_nt_bytes_per_launch")
+                        traffic_src = "profiles/" + name + " (separate rocprofv3 --pmc run of the same command; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"
+                    except Exception:
+                        traffic = None
             roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (all forward + dgrad GEMMs; every %dth launch bracketed by HIP events)" % eng.PROF_EVERY, "achieved": round(achieved, 1),
-                    "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launches_per_step": len(prof) * eng.PROF_EVERY // max(args.steps, 1), "sampled_launches": len(prof),
                     "avg_launch_us": round(sum(ms) / len(ms) * 1e3, 2),
                     "avg_gflop_per_launch": round(sum(flops) / len(flops) / 1e9, 3),
@@ -187,10 +203,11 @@ def main():
         out = {"metric": METRIC, "value": round(world * args.batch * args.steps / dt, 2), "unit": "samples/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-               "config": {"workload": "COCO Captions fine-tune shape: BERT-base %dL, 100 regions x 2048-d, seq_len %d (L=%d), bs %d/GPU, "
-                                      "fwd+bwd+FP16 FusedAdam, dropout 0.1, dynamic loss scale" % (args.layers, args.max_len_b, args.max_len_b + 103, args.batch),
+               "config": {"workload": "%s: BERT-base %dL, 100 regions x 2048-d, seq_len %d (L=%d), bs %d/GPU, "
+                                      "fwd+bwd+FP16 FusedAdam, dropout 0.1, dynamic loss scale" % (shape_name, args.layers, args.max_len_b, args.max_len_b + 103, args.batch),
                           "global_batch": world * args.batch, "parallelism": "dp%d" % world, "final_loss": round(loss, 4),
-                          "loss_scale": opt.cur_scale, "skipped_steps": opt.skipped_steps},
+                          "loss_scale": opt.cur_scale, "skipped_steps": opt.skipped_steps,
+                          "rccl_ranks": dist.get_world_size() if use_dist else 1},
                "roofline": roof}
         if os.environ.get("VLP_DEBUG_TUNE") == "1":  # noqa
             from vlp_amd.engine import Engine

@@ -69,23 +69,88 @@ def test_prefetcher_delivers_exact_batches(tmp_path):
             assert np.array_equal(g[10].bbox[j].numpy(), box[r])
 
 
-def test_training_from_the_prefetcher(tmp_path):
-    store, examples, *_ = make_store(tmp_path, n=16, seed=1)
-    p_s2s, p_bi = procs()
+def _clone_batch(batch):
+    """Device-resident copy of a prefetcher batch (plain tensors + MaskSpec / RawRegions of fresh tensors)."""
+    out = []
+    for t in batch:
+        if torch.is_tensor(t):
+            out.append(t.clone())
+        else:
+            out.append(type(t)(*(x.clone() for x in t)))
+    return tuple(out)
+
+
+def _tiny_model_and_opt(lr):
+    torch.manual_seed(0)
     cfg = BertConfig(2048, num_hidden_layers=2, type_vocab_size=6)
     model = BertForPreTrainingLossMask(cfg, enable_butd=True, len_vis_input=100, tasks="img2txt", allow_random_fc7=True).half().to(DEV).train()
     named = list(model.named_parameters())
     nd = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
     groups = [{"params": [p for n, p in named if not any(x in n for x in nd)], "weight_decay": 0.01},
               {"params": [p for n, p in named if any(x in n for x in nd)], "weight_decay": 0.0}]
-    opt = FP16_Optimizer_State(FusedAdam(groups, lr=3e-4, bias_correction=False, max_grad_norm=1.0), dynamic_loss_scale=True)
+    return model, FP16_Optimizer_State(FusedAdam(groups, lr=lr, bias_correction=False, max_grad_norm=1.0), dynamic_loss_scale=True)
+
+
+def test_training_from_the_prefetcher(tmp_path):
+    """A training step fed by the prefetcher (compact MaskSpec / RawRegions inputs arriving over the copy stream) equals, BIT FOR
+    BIT, the same step fed the same batch as resident tensors -- losses of every step and every parameter after the last one.
+    (Deterministic in outcome: no trend assertion over fresh random batches.)"""
+    store, examples, *_ = make_store(tmp_path, n=16, seed=1)
+    p_s2s, p_bi = procs()
+    model_a, opt_a = _tiny_model_and_opt(3e-4)
+    model_b, opt_b = _tiny_model_and_opt(3e-4)
     random.seed(5)
-    losses = []
-    for batch in BatchPrefetcher(store, examples, 8, p_s2s, p_bi, s2s_prob=0.75, device=DEV, steps=12, seed=1):
+    la, lb = [], []
+    for batch in BatchPrefetcher(store, examples, 8, p_s2s, p_bi, s2s_prob=0.75, device=DEV, steps=6, seed=1):
         assert isinstance(batch[2], MaskSpec) and isinstance(batch[10], RawRegions) and batch[8].dtype == torch.float16
-        lt = train_step(model, opt, batch, 3e-4)
-        losses.append(float(lt[0].detach()))
-    assert all(l == l for l in losses) and sum(losses[-3:]) < sum(losses[:3]), losses
+        resident = _clone_batch(batch)
+        la.append(train_step(model_a, opt_a, batch, 3e-4)[0].detach().clone())
+        lb.append(train_step(model_b, opt_b, resident, 3e-4)[0].detach().clone())
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(x).all()) for x in la)
+    for x, y in zip(la, lb):
+        assert torch.equal(x, y), (la, lb)
+    for key in ("decay", "nodecay"):
+        assert torch.equal(model_a.engine.flat[key], model_b.engine.flat[key]), key
+
+
+def test_repeated_prefetcher_batch_is_learned(tmp_path):
+    """The same prefetcher batch 30 times: the model must fit it (the robust criterion of test_30_train_gpu)."""
+    store, examples, *_ = make_store(tmp_path, n=16, seed=1)
+    p_s2s, p_bi = procs()
+    model, opt = _tiny_model_and_opt(2e-4)
+    random.seed(5)
+    batch = _clone_batch(next(iter(BatchPrefetcher(store, examples, 8, p_s2s, p_bi, s2s_prob=0.75, device=DEV, steps=1, seed=1))))
+    losses = [float(train_step(model, opt, batch, 2e-4)[0].detach()) for _ in range(30)]
+    assert all(l == l for l in losses)
+    assert sum(losses[-5:]) / 5 < 0.7 * sum(losses[:5]) / 5, losses
+
+
+def test_prefetcher_with_a_slow_consumer(tmp_path):
+    """a loader that is much faster than the training step must not overwrite a pinned host buffer whose H2D copy is
+    still queued.  The consumer stream is stalled (device-side sleep) before every use and never synchronises the host, so the
+    worker thread runs several batches ahead; every delivered batch must still hold exactly the bytes of its own samples."""
+    store, examples, feats, cls, box, ids = make_store(tmp_path)
+    p_s2s, p_bi = procs()
+    B, steps = 4, 10
+    random.seed(21)
+    got = []
+    for batch in BatchPrefetcher(store, examples, B, p_s2s, p_bi, s2s_prob=1.0, device=DEV, steps=steps, depth=2, seed=9):
+        torch.cuda._sleep(40_000_000)                       # ~20 ms of device time ahead of the consumer's reads
+        got.append((batch[8].clone(), batch[10].cls_prob.clone(), batch[10].bbox.clone(), batch[0].clone()))
+    torch.cuda.synchronize()
+    order = list(range(len(examples)))
+    random.Random(9).shuffle(order)
+    random.seed(21)
+    row = {k: i for i, k in enumerate(ids)}
+    for s in range(steps):
+        for j in range(B):
+            img_id, toks = examples[order[(s * B + j) % len(order)]]
+            t = random.choices([p_s2s, p_bi], weights=[1.0, 0.0])[0](toks)      # same draws from `random` as the worker made
+            r = row[img_id]
+            assert np.array_equal(got[s][0][j].cpu().numpy(), feats[r]), (s, j)
+            assert np.array_equal(got[s][1][j].cpu().numpy(), cls[r]) and np.array_equal(got[s][2][j].cpu().numpy(), box[r])
+            assert got[s][3][j].tolist() == t["input_ids"]
 
 
 def test_entry_script_from_packed_features(tmp_path, monkeypatch):

@@ -64,3 +64,169 @@ def test_grad_reducer_world2_gloo():
         for p in procs:
             p.join(timeout=60)
     assert sorted(results) == [(0, "ok"), (1, "ok")], results
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the REAL 12-layer bucket plan (no GPU needed: Engine.plan_layout is a pure function of the parameter shapes)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_real_12_layer_bucket_plan():
+    from vlp_amd.distributed import coalesce_buckets
+    from vlp_amd.engine import ALIGN, is_no_decay
+    from vlp_amd.modeling import BertConfig, BertForPreTrainingLossMask
+    for tasks in ("img2txt", "vqa2"):
+        cfg = BertConfig(28996, num_hidden_layers=12, type_vocab_size=6)
+        model = BertForPreTrainingLossMask(cfg, enable_butd=True, len_vis_input=100, tasks=tasks, allow_random_fc7=True)
+        lay = model.engine.plan_layout(model)
+        names, offs, sizes, slices = lay["names"], lay["offsets"], lay["sizes"], lay["buckets"]
+        numel = {n: p.numel() for n, p in model.named_parameters()}
+        # every parameter exactly once, decay / no-decay split as the train script's two groups (run_img2txt_dist.py:394-401)
+        assert sorted(names["decay"] + names["nodecay"]) == sorted(numel)
+        assert all(not is_no_decay(n) for n in names["decay"]) and all(is_no_decay(n) for n in names["nodecay"])
+        assert len(numel) == (214 if tasks == "vqa2" else 210)
+        # parameters do not overlap, start on 128-byte boundaries, and lie in list order
+        for grp in ("decay", "nodecay"):
+            end = 0
+            for n in names[grp]:
+                assert offs[grp][n] % ALIGN == 0 and offs[grp][n] >= end, n
+                end = offs[grp][n] + numel[n]
+            assert end <= sizes[grp]
+        # ready-slices: contiguous, in backward-completion order, covering the decay buffer exactly once
+        assert len(slices) == 12 + 2
+        assert slices[0][0] == 0 and slices[-1][1] == sizes["decay"]
+        for (lo, hi), (lo2, _) in zip(slices, slices[1:]):
+            assert lo < hi and hi == lo2
+        # slice 0 = task head, slices 1..12 = layers 11..0 (six weight matrices each), last = embeddings + region projections
+        def owner(n):
+            o = offs["decay"][n]
+            return [i for i, (lo, hi) in enumerate(slices) if lo <= o < hi][0]
+        for i in range(12):
+            L = "bert.encoder.layer.%d." % i
+            for suffix in ("output.dense.weight", "intermediate.dense.weight", "attention.output.dense.weight", "attention.self.query.weight",
+                           "attention.self.key.weight", "attention.self.value.weight"):
+                assert owner(L + suffix) == 12 - i, (L + suffix, owner(L + suffix))
+            q, k, v = (offs["decay"][L + "attention.self.%s.weight" % x] for x in ("query", "key", "value"))
+            assert k == q + 768 * 768 and v == k + 768 * 768           # packed QKV GEMM reads them as one [2304, 768] matrix
+        assert owner("bert.embeddings.word_embeddings.weight") == 13 and owner("vis_embed.0.weight") == 13
+        assert owner("ans_classifier.0.weight" if tasks == "vqa2" else "cls.predictions.transform.dense.weight") == 0
+        # coalescing to <= 50 MB of fp16: every bucket within the cap unless it is a single slice; buckets tile the buffer; a bucket
+        # fires when its last slice is ready, in order
+        cap = int(50.0 * 1024 * 1024 / 2)
+        buckets, fire_at = coalesce_buckets(slices, cap)
+        assert buckets[0][0] == 0 and buckets[-1][1] == sizes["decay"]
+        for (lo, hi), (lo2, _) in zip(buckets, buckets[1:]):
+            assert hi == lo2
+        single = {(lo, hi) for lo, hi in slices}
+        for b in buckets:
+            assert (b[1] - b[0]) <= cap or b in single, b
+        assert sorted(fire_at.values()) == list(range(len(buckets)))
+        fired = [b for _, b in sorted(fire_at.items())]
+        assert fired == sorted(fired)
+        for si, b in fire_at.items():
+            assert slices[si][1] == buckets[b][1]
+        assert 5 <= len(buckets) <= 8, len(buckets)        # 231.9 MB of fp16 gradients in <= 50 MB pieces (+ the 67 MB embedding slice)
+        # rs_ag mode needs bucket sizes divisible by the world size (8)
+        assert all((hi - lo) % 8 == 0 for lo, hi in buckets) and sizes["nodecay"] % 8 == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DistributedDataParallel's hook wiring, world 2 over gloo, through a fake engine (flat CPU buffers, hooks fired in order)
+# ---------------------------------------------------------------------------------------------------------------------
+class _FakeEngine(object):
+    def __init__(self, seed):
+        g = torch.Generator().manual_seed(seed)
+        self.flat = {"decay": torch.randn(4096, generator=g), "nodecay": torch.randn(256, generator=g)}
+        self.gflat = {k: torch.zeros_like(v) for k, v in self.flat.items()}
+        self.buckets = [(0, 1024), (1024, 2048), (2048, 3072), (3072, 4096)]
+        self.grad_ready_hook = None
+        self.post_backward_hook = None
+        self.packed = False
+
+    def pack(self):
+        self.packed = True
+
+    def backward(self, gd, gn):
+        """what Engine.backward does with the hooks: write a slice, announce it; finish after the last."""
+        for i, (lo, hi) in enumerate(self.buckets):
+            self.gflat["decay"][lo:hi] = gd[lo:hi]
+            self.grad_ready_hook(i)
+        self.gflat["nodecay"].copy_(gn)
+        self.post_backward_hook()
+
+
+class _FakeModule(torch.nn.Module):
+    def __init__(self, seed):
+        super(_FakeModule, self).__init__()
+        self.engine = _FakeEngine(seed)
+
+    def forward(self, x):
+        return x + 1
+
+
+def _ddp_worker(rank, world, init_file, mode, q):
+    os.environ["VLP_DDP_MODE"] = mode
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    try:
+        from vlp_amd.distributed import DistributedDataParallel as DDP
+        mod = _FakeModule(seed=10 + rank)               # ranks start from DIFFERENT parameters ...
+        p0 = [t.clone() for t in (mod.engine.flat["decay"], mod.engine.flat["nodecay"])]
+        ddp = DDP(mod, device_ids=None, find_unused_parameters=True, bucket_cap_mb=0.01)
+        eng = mod.engine
+        assert eng.packed and ddp.module is mod and ddp.reducer.mode == mode
+        assert float(ddp(torch.zeros(1))) == 1.0
+        # ... and hold rank 0's after construction (DDP's initial broadcast)
+        ref = [t.clone() for t in p0]
+        for t in ref:
+            dist.broadcast(t, src=0)
+        assert torch.equal(eng.flat["decay"], ref[0]) and torch.equal(eng.flat["nodecay"], ref[1])
+        assert eng.grad_ready_hook is not None and eng.post_backward_hook is not None
+        assert len(ddp.reducer.buckets) == 2               # 4 slices of 1024 fp32 coalesced under a 0.01 MB cap: 2 x 2048
+        for step in range(3):
+            g = torch.Generator().manual_seed(1000 * step + rank)
+            gd, gn = torch.randn(4096, generator=g), torch.randn(256, generator=g)
+            if step == 2 and rank == 1:
+                gd[77] = float("inf")                      # an fp16 overflow on ONE rank ...
+            want_d, want_n = gd.clone(), gn.clone()
+            dist.all_reduce(want_d)
+            dist.all_reduce(want_n)
+            eng.backward(gd, gn)
+            if step < 2:
+                assert torch.allclose(eng.gflat["decay"], want_d / world, atol=1e-6)
+                assert torch.allclose(eng.gflat["nodecay"], want_n / world, atol=1e-6)
+            else:
+                # ... is non-finite in the SAME slot on every rank after the reduction, so every rank's overflow check
+                # (vlp_sumsq's inf/nan flag on the reduced buffer) takes the same skip decision: no extra flag exchange
+                bad = ~torch.isfinite(eng.gflat["decay"])
+                assert bool(bad[77]) and int(bad.sum()) == 1
+                flag = torch.tensor([float(bad.any())])
+                both = [torch.zeros(1) for _ in range(world)]
+                dist.all_gather(both, flag)
+                assert all(float(b) == 1.0 for b in both)
+        q.put((rank, "ok"))
+    except Exception as e:   # pragma: no cover
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_world2(target, *extra):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with tempfile.TemporaryDirectory() as d:
+        init_file = os.path.join(d, "nonexistent_file")
+        procs = [ctx.Process(target=target, args=(r, world, init_file) + extra + (q,)) for r in range(world)]
+        for p in procs:
+            p.start()
+        results = [q.get(timeout=180) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+    assert sorted(results) == [(0, "ok"), (1, "ok")], results
+
+
+def test_ddp_hook_wiring_world2_gloo_allreduce():
+    _run_world2(_ddp_worker, "allreduce")
+
+
+def test_ddp_hook_wiring_world2_gloo_reduce_scatter_all_gather():
+    _run_world2(_ddp_worker, "rs_ag")

@@ -9,7 +9,8 @@ modules, so that the import lines of vlp/run_img2txt_dist.py:23-30,405 and vlp/d
     from pytorch_pretrained_bert.optimization import BertAdam, warmup_linear
     from pytorch_pretrained_bert.optimization_fp16 import FP16_Optimizer_State
 
-and, when apex is not installed, an `apex.optimizers` module exposing `FusedAdam` (run_img2txt_dist.py:406 imports it from there).
+`misc.data_parallel` (DataParallelImbalance, run_img2txt_dist.py:30) resolves to vlp_amd.data_parallel, and, when apex is not
+installed, an `apex.optimizers` module exposing `FusedAdam` is provided (run_img2txt_dist.py:406 imports it from there).
 The tokenizer (`pytorch_pretrained_bert.tokenization`) is NOT provided: it is CPU-side text processing outside the hot path; keep
 using the reference's file for it.  install() refuses to shadow an already imported package of that name unless force=True.
 """
@@ -37,6 +38,15 @@ def install(force=False, with_apex_shim=True):
     pkg.BertAdam = optimization.BertAdam
     pkg.FP16_Optimizer_State = optimization_fp16.FP16_Optimizer_State
     sys.modules[name] = pkg
+    from . import data_parallel
+    misc = sys.modules.get("misc")
+    if misc is None or getattr(misc, "__vlp_amd_alias__", False):
+        misc = types.ModuleType("misc")
+        misc.__vlp_amd_alias__ = True
+        misc.__path__ = []
+        sys.modules["misc"] = misc
+    misc.data_parallel = data_parallel
+    sys.modules["misc.data_parallel"] = data_parallel
     if with_apex_shim:
         try:
             import apex.optimizers  # noqa: F401
@@ -53,8 +63,8 @@ def install(force=False, with_apex_shim=True):
 
 def uninstall():
     for k in [k for k, v in list(sys.modules.items()) if (k == "pytorch_pretrained_bert" or k.startswith("pytorch_pretrained_bert.") or
-                                                           k in ("apex", "apex.optimizers"))
-              and (getattr(v, "__vlp_amd_alias__", False) or k.startswith("pytorch_pretrained_bert."))]:
+                                                           k in ("apex", "apex.optimizers", "misc", "misc.data_parallel"))
+              and (getattr(v, "__vlp_amd_alias__", False) or k.startswith("pytorch_pretrained_bert.") or k == "misc.data_parallel")]:
         if k.startswith("pytorch_pretrained_bert.") and not getattr(sys.modules.get("pytorch_pretrained_bert"), "__vlp_amd_alias__", False):
             continue
         del sys.modules[k]

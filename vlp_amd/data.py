@@ -180,6 +180,10 @@ class BatchPrefetcher(object):
 
     def _fill(self, slot, batch_examples):
         host, dev, ev = slot
+        # The slot's previous H2D copies were only ENQUEUED when it was last filled; they sit on the copy stream, possibly behind a
+        # wait on an unfinished training step.  The pinned buffers below are the DMA source: block this (worker) thread until that
+        # event has completed on the device before touching them (a never-recorded event returns at once).
+        ev.synchronize()
         rows = self.store.rows([e[0] for e in batch_examples])
         self.store.gather(rows, host["feat"].numpy(), host["cls"].numpy(), host["bbox"].numpy())
         for j, (_, toks) in enumerate(batch_examples):

@@ -15,44 +15,78 @@ autograd graph, so the reducer lives here instead:
   * the reference's unused parameters (pooler; LM head in VQA) are static, so there is no per-step
     unused-parameter bitmap exchange: their gradient slots stay zero;
   * reduction is the MEAN over ranks (torch DDP semantics) -- ReduceOp.AVG on RCCL; on
-    backends without AVG (gloo, used by the CPU tests) SUM followed by a 1/world scale.
+    backends without AVG (gloo, used by the CPU tests) SUM followed by a 1/world scale;
+  * `VLP_DDP_MODE=rs_ag` (opt-in) issues every bucket as reduce-scatter + all-gather instead of one all-reduce (SURVEY.md
+    section 5 / 8e: on point-to-point xGMI a direct reduce-scatter/all-gather uses all 7 links of a GPU, a ring is bound by one);
+    same result up to fp16 summation order.  No scaling curve has been measured yet (the driver owns the 8-GPU runs), so
+    all-reduce stays the default.
 """
+import os
+
 import torch.distributed as dist
 from torch import nn
+
+
+def coalesce_buckets(slices, cap):
+    """Adjacent ready-slices [(lo, hi)] (in completion order) -> buckets of <= cap elements (a slice larger than cap stays whole).
+    Returns (buckets, fire_at): bucket b is handed to the collective when slice index fire_at^-1(b) -- its LAST slice -- is ready."""
+    buckets, fire_at = [], {}
+    cur_lo, cur_hi = None, None
+    for i, (lo, hi) in enumerate(slices):
+        if cur_lo is None:
+            cur_lo, cur_hi = lo, hi
+        elif lo == cur_hi and (hi - cur_lo) <= cap:
+            cur_hi = hi
+        else:
+            fire_at[i - 1] = len(buckets)
+            buckets.append((cur_lo, cur_hi))
+            cur_lo, cur_hi = lo, hi
+    if cur_lo is not None:
+        fire_at[len(slices) - 1] = len(buckets)
+        buckets.append((cur_lo, cur_hi))
+    return buckets, fire_at
 
 
 class GradReducer(object):
     """Bucketed asynchronous all-reduce(mean) over slices of flat gradient buffers."""
 
-    def __init__(self, flat_main, slices, flat_tail=None, process_group=None, bucket_cap_mb=50.0):
+    def __init__(self, flat_main, slices, flat_tail=None, process_group=None, bucket_cap_mb=50.0, mode=None):
         """flat_main: 1-D gradient buffer; slices: [(lo, hi)] in the order they become ready;
-        flat_tail: a small buffer reduced at the end (biases / LayerNorm parameters)."""
+        flat_tail: a small buffer reduced at the end (biases / LayerNorm parameters);
+        mode: "allreduce" (default) | "rs_ag" (env VLP_DDP_MODE)."""
         self.flat_main, self.flat_tail, self.pg = flat_main, flat_tail, process_group
+        self.mode = mode or os.environ.get("VLP_DDP_MODE", "allreduce")
+        if self.mode not in ("allreduce", "rs_ag"):
+            raise ValueError("VLP_DDP_MODE must be 'allreduce' or 'rs_ag', got %r" % self.mode)
         self.world = dist.get_world_size(process_group)
         cap = int(bucket_cap_mb * 1024 * 1024 / flat_main.element_size())
-        # coalesce adjacent ready-slices into buckets of <= cap elements (a slice larger than cap stays whole)
-        self.buckets, self.fire_at = [], {}
-        cur_lo, cur_hi = None, None
-        for i, (lo, hi) in enumerate(slices):
-            if cur_lo is None:
-                cur_lo, cur_hi = lo, hi
-            elif lo == cur_hi and (hi - cur_lo) <= cap:
-                cur_hi = hi
-            else:
-                self.fire_at[i - 1] = len(self.buckets)
-                self.buckets.append((cur_lo, cur_hi))
-                cur_lo, cur_hi = lo, hi
-        if cur_lo is not None:
-            self.fire_at[len(slices) - 1] = len(self.buckets)
-            self.buckets.append((cur_lo, cur_hi))
+        self.buckets, self.fire_at = coalesce_buckets(slices, cap)
         self._avg = dist.get_backend(process_group) == "nccl"
         self._work = []
 
     def _reduce(self, t):
-        if self._avg:
+        if self.mode == "rs_ag" and self.world > 1 and t.numel() % self.world == 0:
+            self._reduce_rs_ag(t)
+        elif self._avg:
             self._work.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.pg, async_op=True), None))
         else:
             self._work.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), t))
+
+    def _reduce_rs_ag(self, t):
+        """Bucket = W equal chunks; rank r ends up owning the mean of chunk r (reduce-scatter, in place on its own chunk), then
+        every rank gathers all chunks (all-gather, in place).  Both collectives are asynchronous on RCCL's stream; the all-gather
+        is ordered after the reduce-scatter by that stream."""
+        W, r = self.world, dist.get_rank(self.pg)
+        chunks = t.view(W, -1)
+        if self._avg:
+            self._work.append((dist.reduce_scatter_tensor(chunks[r], t, op=dist.ReduceOp.AVG, group=self.pg, async_op=True), None))
+            self._work.append((dist.all_gather_into_tensor(t, chunks[r], group=self.pg, async_op=True), None))
+        else:
+            # gloo (CPU tests) has no reduce-scatter: W rooted reductions are the same data movement, then scale the owned chunk
+            for dst in range(W):
+                dist.reduce(chunks[dst], dst=dist.get_global_rank(self.pg, dst) if self.pg is not None else dst, op=dist.ReduceOp.SUM, group=self.pg)
+            chunks[r].div_(W)
+            dist.all_gather_into_tensor(t, chunks[r].clone(), group=self.pg)
 
     def bucket_ready(self, slice_index):
         b = self.fire_at.get(slice_index)

@@ -9,8 +9,8 @@ libvlp_hip.so per training step, with
     order* so that a gradient bucket is a contiguous slice that can be handed to RCCL the moment the
     last weight-gradient GEMM of that slice has been launched;
   * gradients written by the kernels straight into matching flat fp16 buffers (`param.grad` are views);
-  * activations kept in a per-shape workspace that is reused every step (288 GB of HBM: nothing is
-    recomputed except dropout masks, which are a pure function of (seed, stream, index));
+  * activations kept in a per-shape workspace that is reused every step (3.4 GB at B = 64, L = 167 -- small against the
+    chip's 288 GB, so nothing is recomputed except dropout masks, which are a pure function of (seed, stream, index));
   * transposed weight shadows for the dgrad GEMMs refreshed once per backward.
 
 PyTorch is used for memory (torch.empty), streams and the autograd hand-off only.  There is no
@@ -23,6 +23,7 @@ import weakref
 import torch
 
 from . import _lib as K
+from . import tuning
 from .input_prep import MaskSpec, RawRegions
 
 ALIGN = 64            # elements; every parameter starts on a 128-byte boundary inside its flat buffer
@@ -45,7 +46,7 @@ class _State(object):
 
 
 class Engine(object):
-    GEMM_NT_VARIANT = None   # None -> autotune per (M, N, K) on first use among NT_CANDIDATES; or force an int
+    GEMM_NT_VARIANT = None   # None -> vlp_amd.tuning (committed table, else shape heuristic; timing search only with VLP_AUTOTUNE=1); or force an int
     NT_CANDIDATES = (1, 2, 4, 5, 9, 10, 11, 12, 13)   # LDS-DMA variants (+8 = XCD-aware tile order); see include/vlp_hip.h
     NT_CANDIDATES_SKINNY = (1, 2, 9, 10, 11, 17)      # M <= 1024 (decoding, LM head): few workgroups, latency-bound -> also the 4-stage ring
     GEMM_TN_VARIANT = 2      # ds_read_b64_tr_b16 fragment reads + LDS-DMA staging
@@ -53,7 +54,7 @@ class Engine(object):
     # throughput on one MI355X (4706 vs 4637 samples/s); off by default so that per-kernel timings (bench.py roofline,
     # rocprofv3) are single-kernel measurements.  VLP_WGRAD_SIDE_STREAM=1 turns it on.
     WGRAD_SIDE_STREAM = os.environ.get("VLP_WGRAD_SIDE_STREAM", "0") == "1"
-    TN_SPLITS = None         # None -> autotune (variant flags, split-M factor) per (M, N, K)
+    TN_SPLITS = None         # None -> vlp_amd.tuning (variant flags, split-M factor) per (M, N, K)
     # split-M factor: the wgrad outputs are small (36..144 tiles of 128x128) and the contraction long (M = 10 688), so the
     # workgroup count tiles*splits has to land just under a multiple of the 256 CUs x 2 resident workgroups: 3 (432 workgroups)
     # beats 4 (576) by 25 % on the FFN wgrads, 14 beats 8 on the 768x768 ones (microbench, profiles/r01_tn_split_sweep.json)
@@ -120,6 +121,28 @@ class Engine(object):
             raise RuntimeError("vlp_amd.Engine: unexpected parameter set (missing %s, unknown %s)" % (sorted(missing), sorted(extra)))
         return decay, nodecay, buckets
 
+    def plan_layout(self, model=None):
+        """Pure function of the parameter shapes (runs on CPU, no device needed): names per flat buffer, element offsets (every
+        parameter on a 128-byte boundary), buffer sizes, and the gradient buckets = contiguous slices of the decay buffer in
+        backward-completion order (head, layer N-1 .. 0, embeddings + region projections)."""
+        model = model if model is not None else self._model()
+        numel = {n: p.numel() for n, p in model.named_parameters()}
+        decay, nodecay, bucket_idx = self._ordered_names(model)
+        names = {"decay": decay, "nodecay": nodecay}
+        offsets, sizes = {}, {}
+        for grp, ns in names.items():
+            off, offs = 0, {}
+            for n in ns:
+                offs[n] = off
+                off += _ru(numel[n], ALIGN)
+            offsets[grp], sizes[grp] = offs, _ru(off, 8)
+        buckets = []
+        for s_, e_ in bucket_idx:
+            lo = offsets["decay"][decay[s_]]
+            hi = offsets["decay"][decay[e_ - 1]] + _ru(numel[decay[e_ - 1]], ALIGN)
+            buckets.append((lo, min(hi, sizes["decay"])))
+        return {"names": names, "offsets": offsets, "sizes": sizes, "buckets": buckets}
+
     def pack(self):
         """Move every parameter into the flat buffers (idempotent).  Needs fp16 parameters on a GPU:
         this is the `model.half(); model.to(device)` state of run_img2txt_dist.py:370-377."""
@@ -135,15 +158,11 @@ class Engine(object):
                 raise RuntimeError("vlp_amd: parameters must be fp16 (`model.half()`, i.e. --fp16): %s is %s. "
                                    "The fp32 path of the reference is not implemented (DESIGN.md, out of scope)." % (n, p.dtype))
         K.load()
-        decay, nodecay, buckets = self._ordered_names(model)
-        self.names = {"decay": decay, "nodecay": nodecay}
-        self.flat, self.gflat, self.offsets, self.sizes = {}, {}, {}, {}
+        lay = self.plan_layout(model)
+        self.names, self.offsets, self.sizes, self.buckets = lay["names"], lay["offsets"], lay["sizes"], lay["buckets"]
+        self.flat, self.gflat = {}, {}
         for grp, names in self.names.items():
-            off, offs = 0, {}
-            for n in names:
-                offs[n] = off
-                off += _ru(params[n].numel(), ALIGN)
-            total = _ru(off, 8)
+            offs, total = self.offsets[grp], self.sizes[grp]
             flat = torch.zeros(total, device=dev, dtype=torch.float16)
             gflat = torch.zeros(total, device=dev, dtype=torch.float16)
             for n in names:
@@ -153,13 +172,7 @@ class Engine(object):
                 p.data = view
                 p.grad = gflat[offs[n]:offs[n] + p.numel()].view(p.shape)
                 p._vlp_engine = self
-            self.flat[grp], self.gflat[grp], self.offsets[grp], self.sizes[grp] = flat, gflat, offs, total
-        # gradient buckets: contiguous slices of the decay buffer in completion order
-        self.buckets = []
-        for s, e in buckets:
-            lo = self.offsets["decay"][decay[s]]
-            hi = self.offsets["decay"][decay[e - 1]] + _ru(params[decay[e - 1]].numel(), ALIGN)
-            self.buckets.append((lo, min(hi, self.sizes["decay"])))
+            self.flat[grp], self.gflat[grp] = flat, gflat
         self._params = params
         self.device = dev
         self.packed = True
@@ -299,13 +312,17 @@ class Engine(object):
     # forward
     # ------------------------------------------------------------------------------------------
     def _nt_variant(self, x, w, y, M, N, Kd, kw):
-        """One-time choice of the GEMM staging/tiling variant for this problem size: every candidate computes the
-        same result, so the real call is simply timed with each (3 launches) the first time a shape is seen."""
+        """Staging/tiling variant for this problem size.  Deterministic (vlp_amd.tuning: committed table, else a shape
+        heuristic) so that every box runs the same kernels and produces the same bits; with VLP_AUTOTUNE=1 every candidate
+        (all compute the same contraction) is timed on the real call the first time a shape is seen."""
         if self.GEMM_NT_VARIANT is not None:
             return self.GEMM_NT_VARIANT
         key = (M, N, Kd)
         v = Engine._nt_choice.get(key)
         if v is not None:
+            return v
+        if not tuning.AUTOTUNE:
+            v = Engine._nt_choice[key] = tuning.nt_variant(M, N, Kd)
             return v
         best, best_t = self.NT_CANDIDATES[0], float("inf")
         cands = self.NT_CANDIDATES_SKINNY if M <= 1024 else self.NT_CANDIDATES
@@ -326,6 +343,7 @@ class Engine(object):
                     if t < best_t:
                         best, best_t = cand, t
         Engine._nt_choice[key] = best
+        tuning.remember("nt", M, N, Kd, best)
         return best
 
     def _nt(self, x, w, y, M, N, Kd, **kw):
@@ -354,6 +372,8 @@ class Engine(object):
             return self._nt(x, w, y, M, N, Kd, **kw)
         key = (M, N, Kd)
         ch = Engine._skinny_choice.get(key)
+        if ch is None and not tuning.AUTOTUNE:
+            ch = Engine._skinny_choice[key] = tuning.skinny_choice(M, N, Kd)
         if ch is None:
             wl = list(tune_ws()) if tune_ws is not None else [w]
             reps = max(12, len(wl))
@@ -380,6 +400,7 @@ class Engine(object):
             ch = min(cands, key=lambda c: score[c])
             K.gemm_nt(x, w, y, M, N, Kd, variant=1, **kw)        # leave y as computed from the caller's weight
             Engine._skinny_choice[key] = ch
+            tuning.remember("sk", M, N, Kd, ch)
         if ch[0] == "v":
             K.gemm_nt(x, w, y, M, N, Kd, variant=ch[1], **kw)
         else:
@@ -816,6 +837,9 @@ class Engine(object):
         sp = Engine._tn_choice.get(key)
         if sp is not None:
             return sp
+        if not tuning.AUTOTUNE:
+            sp = Engine._tn_choice[key] = tuning.tn_choice(M, N, Kd)
+            return sp
         best, best_t = (self.GEMM_TN_VARIANT, 0), float("inf")
         if M >= 1024:
             torch.cuda.synchronize()
@@ -836,6 +860,7 @@ class Engine(object):
                         if t < best_t:
                             best, best_t = (var, cand), t
         Engine._tn_choice[key] = best
+        tuning.remember("tn", M, N, Kd, best)
         return best
 
     def _tn(self, a, b, c, M, N, Kd, ws, beta, bias=None, **kw):

@@ -87,7 +87,7 @@ class BertConfig(object):
 
 def _no_direct_forward(self, *a, **k):
     raise NotImplementedError("%s is a parameter container in vlp_amd: the fused HIP path is entered through "
-                              "BertForPreTrainingLossMask.forward / BertModel.forward" % type(self).__name__)
+                              "BertForPreTrainingLossMask.forward / BertForSeq2SeqDecoder.forward" % type(self).__name__)
 
 
 class BertLayerNorm(nn.Module):
@@ -224,6 +224,71 @@ class BertPreTrainingHeads(nn.Module):   # :506-520
     forward = _no_direct_forward
 
 
+def load_checkpoint_state(model, state_dict):
+    """The checkpoint remapping of the reference's from_pretrained (:651-752), shared by `from_pretrained` and the train
+    script: TF-era gamma/beta names, segment table 2 -> 6 rows, position-table tiling, size-mismatch errors; sets
+    `model.missing_keys`.  Anything whose shape does not fit after the remapping raises (never silently skipped)."""
+    config = model.config
+    state_dict = dict(state_dict)
+    # TF-era names (:651-663)
+    for key in list(state_dict.keys()):
+        new_key = key.replace("gamma", "weight").replace("beta", "bias")
+        if new_key != key:
+            state_dict[new_key] = state_dict.pop(key)
+    H = config.hidden_size
+    # segment table 2 -> 6 rows: rows 2,3,4 start from row 0 and row 5 from row 1 (:665-683)
+    k = "bert.embeddings.token_type_embeddings.weight"
+    if k in state_dict and state_dict[k].shape[0] != config.type_vocab_size:
+        old = state_dict[k]
+        if config.type_vocab_size > old.shape[0]:
+            new = old.new_zeros(config.type_vocab_size, H)
+            new.normal_(mean=0.0, std=config.initializer_range)
+            new[:old.shape[0]] = old
+            if config.type_vocab_size >= 6:
+                new[2], new[3], new[4], new[5] = old[0], old[0], old[0], old[1]
+            state_dict[k] = new
+        else:
+            state_dict[k] = old[:config.type_vocab_size]
+    # position table: tile the learned rows when it grows (:685-702)
+    k = "bert.embeddings.position_embeddings.weight"
+    if k in state_dict and state_dict[k].shape[0] != config.max_position_embeddings:
+        old = state_dict[k]
+        n_old, n_new = old.shape[0], config.max_position_embeddings
+        if n_new > n_old:
+            reps = int(math.ceil(n_new / float(n_old)))
+            state_dict[k] = old.repeat(reps, 1)[:n_new].clone()
+        else:
+            state_dict[k] = old[:n_new]
+    k = "cls.predictions.transform.dense.weight"
+    if k in state_dict and state_dict[k].shape[0] != H:
+        raise NotImplementedError("checkpoint uses relax_projection; not supported by vlp_amd")
+    own = model.state_dict()
+    # a bare BertModel reads the 'bert.'-prefixed entries of a task checkpoint (:751)
+    strip = "" if hasattr(model, "bert") else "bert."
+    missing, unexpected, load = [], [], {}
+    for key, value in state_dict.items():
+        if strip and not key.startswith(strip):
+            unexpected.append(key)
+            continue
+        full = key[len(strip):]
+        if full in own:
+            if tuple(own[full].shape) != tuple(value.shape):
+                raise RuntimeError("size mismatch for %s: checkpoint %s vs model %s" % (full, tuple(value.shape), tuple(own[full].shape)))
+            load[full] = value
+        else:
+            unexpected.append(key)
+    for key in own:
+        if key not in load:
+            missing.append(key)
+    nn.Module.load_state_dict(model, load, strict=False)
+    model.missing_keys = missing
+    if missing:
+        logger.info("Weights of {} not initialized from pretrained model: {}".format(model.__class__.__name__, missing))
+    if unexpected:
+        logger.info("Weights from pretrained model not used in {}: {}".format(model.__class__.__name__, unexpected))
+    return model
+
+
 class PreTrainedBertModel(nn.Module):
     """Weight init and `from_pretrained` (:523-764)."""
 
@@ -318,63 +383,7 @@ class PreTrainedBertModel(nn.Module):
             if serialization_dir is None:
                 raise EnvironmentError("no weights: pass state_dict (or {} for random init)")
             state_dict = torch.load(os.path.join(serialization_dir, WEIGHTS_NAME), map_location="cpu")
-        state_dict = dict(state_dict)
-        # TF-era names (:651-663)
-        for key in list(state_dict.keys()):
-            new_key = key.replace("gamma", "weight").replace("beta", "bias")
-            if new_key != key:
-                state_dict[new_key] = state_dict.pop(key)
-        H = config.hidden_size
-        # segment table 2 -> 6 rows: rows 2,3,4 start from row 0 and row 5 from row 1 (:665-683)
-        k = "bert.embeddings.token_type_embeddings.weight"
-        if k in state_dict and state_dict[k].shape[0] != config.type_vocab_size:
-            old = state_dict[k]
-            if config.type_vocab_size > old.shape[0]:
-                new = old.new_zeros(config.type_vocab_size, H)
-                new.normal_(mean=0.0, std=config.initializer_range)
-                new[:old.shape[0]] = old
-                if config.type_vocab_size >= 6:
-                    new[2], new[3], new[4], new[5] = old[0], old[0], old[0], old[1]
-                state_dict[k] = new
-            else:
-                state_dict[k] = old[:config.type_vocab_size]
-        # position table: tile the learned rows when it grows (:685-702)
-        k = "bert.embeddings.position_embeddings.weight"
-        if k in state_dict and state_dict[k].shape[0] != config.max_position_embeddings:
-            old = state_dict[k]
-            n_old, n_new = old.shape[0], config.max_position_embeddings
-            if n_new > n_old:
-                reps = int(math.ceil(n_new / float(n_old)))
-                state_dict[k] = old.repeat(reps, 1)[:n_new].clone()
-            else:
-                state_dict[k] = old[:n_new]
-        k = "cls.predictions.transform.dense.weight"
-        if k in state_dict and state_dict[k].shape[0] != H:
-            raise NotImplementedError("checkpoint uses relax_projection; not supported by vlp_amd")
-        own = model.state_dict()
-        # a bare BertModel reads the 'bert.'-prefixed entries of a task checkpoint (:751)
-        strip = "" if hasattr(model, "bert") else "bert."
-        missing, unexpected, load = [], [], {}
-        for key, value in state_dict.items():
-            if strip and not key.startswith(strip):
-                unexpected.append(key)
-                continue
-            full = key[len(strip):]
-            if full in own:
-                if tuple(own[full].shape) != tuple(value.shape):
-                    raise RuntimeError("size mismatch for %s: checkpoint %s vs model %s" % (full, tuple(value.shape), tuple(own[full].shape)))
-                load[full] = value
-            else:
-                unexpected.append(key)
-        for key in own:
-            if key not in load:
-                missing.append(key)
-        nn.Module.load_state_dict(model, load, strict=False)
-        model.missing_keys = missing
-        if missing:
-            logger.info("Weights of {} not initialized from pretrained model: {}".format(model.__class__.__name__, missing))
-        if unexpected:
-            logger.info("Weights from pretrained model not used in {}: {}".format(model.__class__.__name__, unexpected))
+        load_checkpoint_state(model, state_dict)
         return model
 
 

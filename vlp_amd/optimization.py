@@ -105,6 +105,14 @@ class BertAdam(Optimizer):
         if eng is not None:
             eng.pack()
         self._flat = [_FlatGroup(list(g["params"])) for g in self.param_groups]
+        # per-parameter state exactly as the reference keeps it (optimization.py:131-137): `next_m` / `next_v` are views of the flat
+        # moment buffers, so `optimizer.state[p]` and the default state_dict() see the live values
+        for fg in self._flat:
+            for i, p in enumerate(fg.params):
+                st = self.state[p]
+                st["step"] = self._step
+                st["next_m"] = fg.m[fg.offs[i]:fg.offs[i + 1]].view(p.shape)
+                st["next_v"] = fg.v[fg.offs[i]:fg.offs[i + 1]].view(p.shape)
 
     def get_lr(self):   # optimization.py:96-110
         lr = []
@@ -117,6 +125,50 @@ class BertAdam(Optimizer):
                 else:
                     lr.append(group["lr"])
         return lr
+
+    def state_dict(self):
+        """torch.optim.Optimizer format with the reference's per-parameter entries (`step`, `next_m`, `next_v`; fp32 clones) plus
+        `vlp_master_fp32` (the fp32 master weights of fp16 parameters -- not in the reference, which only runs BertAdam on fp32
+        parameters, where the parameter IS the master)."""
+        if self._flat is None:
+            self._build()
+        sd = super(BertAdam, self).state_dict()
+        sd["state"] = {k: {kk: (vv.detach().clone() if torch.is_tensor(vv) else vv) for kk, vv in v.items()} for k, v in sd["state"].items()}
+        sd["vlp_master_fp32"] = [fg.p32.detach().clone() for fg in self._flat]
+        return sd
+
+    def load_state_dict(self, sd):
+        """Accepts this class's state_dict and a reference BertAdam checkpoint (per-parameter `next_m` / `next_v` / `step`, indexed in
+        param_groups order).  Moments are restored in fp32 into the flat buffers; never silently dropped: a shape mismatch raises."""
+        if self._flat is None:
+            self._build()
+        groups = sd["param_groups"]
+        if len(groups) != len(self.param_groups) or any(len(a["params"]) != len(b["params"]) for a, b in zip(groups, self.param_groups)):
+            raise ValueError("BertAdam.load_state_dict: parameter groups do not match the optimizer")
+        step = 0
+        for group, saved, fg in zip(self.param_groups, groups, self._flat):
+            group.update({k: v for k, v in saved.items() if k != "params"})
+            for i, pid in enumerate(saved["params"]):
+                st = sd["state"].get(pid)
+                if not st:
+                    continue
+                for key, buf in (("next_m", fg.m), ("next_v", fg.v)):
+                    t = st[key]
+                    if t.numel() != fg.offs[i + 1] - fg.offs[i]:
+                        raise ValueError("BertAdam.load_state_dict: %s of parameter %s has %d elements, expected %d"
+                                         % (key, pid, t.numel(), fg.offs[i + 1] - fg.offs[i]))
+                    buf[fg.offs[i]:fg.offs[i + 1]].copy_(t.detach().reshape(-1).float())
+                step = max(step, int(st.get("step", 0)))
+        masters = sd.get("vlp_master_fp32")
+        for j, fg in enumerate(self._flat):
+            if masters is not None:
+                fg.p32.copy_(masters[j])
+            else:
+                fg.p32.copy_(torch.cat([p.data.detach().float().reshape(-1) for p in fg.params]))
+        self._step = step
+        for fg in self._flat:
+            for p in fg.params:
+                self.state[p]["step"] = step
 
     def zero_grad(self, set_to_none=False):
         eng = self._engine()

@@ -108,7 +108,10 @@ class FP16_Optimizer_State(object):
         # {cur_scale, cur_iter, last_overflow_iter, scale_factor, scale_window, dynamic, skipped, -}
         self._scale_state = torch.tensor([init, 0, -1, factor, window, 1.0 if dynamic_loss_scale else 0.0, 0, 0], device=dev, dtype=torch.float32)
         self.verbose = verbose
-        self._nstep = 0
+        # Adam's step count = APPLIED steps only (apex increments state['step'] inside the update, which an overflow skips).  The
+        # skip decision lives on the device, so the count is derived from the device-side counters when it is needed:
+        #   applied = _applied0 + (cur_iter - _iter0) - (skipped - _skipped0)
+        self._applied0, self._iter0, self._skipped0 = 0, 0, 0
 
     # ---- lazily synchronised views of the device-side state -------------------------------------------
     @property
@@ -139,6 +142,12 @@ class FP16_Optimizer_State(object):
     def skipped_steps(self):
         return int(self._scale_state[6])
 
+    @property
+    def applied_steps(self):
+        """Number of optimizer updates that were really applied (overflow steps excluded); one host read-back."""
+        st = self._scale_state.tolist()
+        return int(self._applied0 + (st[1] - self._iter0) - (st[6] - self._skipped0))
+
     # ---- the train-loop contract -------------------------------------------------------------------------
     def backward(self, loss):
         """apex: scaled_loss = loss.float() * cur_scale; scaled_loss.backward()   (run_img2txt_dist.py:571)"""
@@ -157,7 +166,7 @@ class FP16_Optimizer_State(object):
             g = self.param_groups[i]
             b1, b2 = g["betas"]
             if g["bias_correction"]:
-                t = self._nstep + 1
+                t = self.applied_steps + 1          # not the reference's configuration (bias_correction=False): costs a host sync
                 step_size = g["lr"] * (1 - b2 ** t) ** 0.5 / (1 - b1 ** t)
             else:
                 step_size = g["lr"]
@@ -165,7 +174,6 @@ class FP16_Optimizer_State(object):
             K.fused_adam(self.fp32_groups_flat[i], self._m[i], self._v[i], eng.gflat[key], eng.flat[key], eng.sizes[key], self._hyper[i],
                          b1=b1, b2=b2, eps=g["eps"], decay=g["weight_decay"], eps_inside_sqrt=(self.optimizer.eps_mode == 0))
         K.loss_scale_update(self._scale_state, self._ovf)
-        self._nstep += 1
 
     # ---- checkpointing (optimization_fp16.py:17-80) ----------------------------------------------------------
     def state_dict(self):
@@ -175,7 +183,7 @@ class FP16_Optimizer_State(object):
         inner = self.optimizer.state_dict()
         inner["exp_avg"] = [t.clone() for t in self._m]
         inner["exp_avg_sq"] = [t.clone() for t in self._v]
-        inner["step"] = self._nstep
+        inner["step"] = self.applied_steps
         inner["group_keys"] = list(self._group_key)
         sd["optimizer_state_dict"] = inner
         sd["fp32_groups_flat"] = [t.clone() for t in self.fp32_groups_flat]
@@ -196,7 +204,8 @@ class FP16_Optimizer_State(object):
             cur.copy_(saved)
         for cur, saved in zip(self._v, inner["exp_avg_sq"]):
             cur.copy_(saved)
-        self._nstep = inner.get("step", 0)
+        st = self._scale_state.tolist()
+        self._applied0, self._iter0, self._skipped0 = int(inner.get("step", 0)), st[1], st[6]
         for cur, saved in zip(self.fp32_groups_flat, sd["fp32_groups_flat"]):
             cur.data.copy_(saved.data)
         for i, key in enumerate(self._group_key):       # refresh the fp16 model copy from the restored masters

@@ -30,7 +30,7 @@ import torch
 
 from . import synthetic
 from .distributed import DistributedDataParallel as DDP
-from .modeling import BertConfig, BertForPreTrainingLossMask
+from .modeling import BertConfig, BertForPreTrainingLossMask, load_checkpoint_state
 from .optimization import BertAdam, warmup_linear           # noqa: F401  (re-exported like the reference imports them)
 from .optimization_fp16 import FP16_Optimizer_State, FusedAdam
 
@@ -190,8 +190,9 @@ def build_model(args, device):
     model = BertForPreTrainingLossMask(config, num_labels=2, enable_butd=args.enable_butd, len_vis_input=args.len_vis_input,
                                        tasks=args.tasks, allow_random_fc7=bool(args.synthetic))
     if state is not None:
-        own = model.state_dict()
-        model.load_state_dict({k: v for k, v in state.items() if k in own and tuple(v.shape) == tuple(own[k].shape)}, strict=False)
+        # the reference always goes through from_pretrained(state_dict=...) (:324-336): gamma/beta renames, segment table 2 -> 6
+        # rows for --new_segment_ids, position-table tiling for --max_position_embeddings, and an ERROR on any other size mismatch
+        load_checkpoint_state(model, state)
     model.half()
     model.to(device)
     return model
@@ -209,9 +210,10 @@ def build_optimizer(args, model, t_total):
     return FP16_Optimizer_State(inner, static_loss_scale=args.loss_scale)
 
 
-def train_step(model, optimizer, batch, lr_this_step, mask_image_regions=False, drop_worst_ratio=0.0, accumulate=False):
-    """One iteration of the reference's inner loop (:479-585) on device-resident tensors.  Returns the loss tuple
-    (device tensors; nothing is read back)."""
+def train_step(model, optimizer, batch, lr_this_step, mask_image_regions=False, drop_worst_ratio=0.0, accumulate=False, accum_steps=1):
+    """One iteration of the reference's inner loop (:479-585) on device-resident tensors.  Returns the (un-normalised) loss
+    tuple (device tensors; nothing is read back).  With gradient accumulation the back-propagated loss is divided by
+    `accum_steps` exactly as the reference does before `optimizer.backward` (:567-571)."""
     (input_ids, segment_ids, input_mask, lm_label_ids, masked_pos, masked_weights, is_next, task_idx, img, vis_masked_pos, vis_pe,
      ans_labels) = batch
     loss_tuple = model(img, vis_pe, input_ids, segment_ids, input_mask, lm_label_ids, ans_labels, is_next, masked_pos=masked_pos,
@@ -219,6 +221,8 @@ def train_step(model, optimizer, batch, lr_this_step, mask_image_regions=False, 
                        mask_image_regions=mask_image_regions, drop_worst_ratio=drop_worst_ratio)
     masked_lm_loss, pretext_loss, ans_loss = loss_tuple
     loss = masked_lm_loss + pretext_loss + ans_loss          # :531
+    if accum_steps > 1:
+        loss = loss / accum_steps                            # :567-568
     optimizer.backward(loss)                                 # :571
     if not accumulate:
         for g in optimizer.param_groups:                     # :580-583
@@ -236,7 +240,14 @@ def build_packed_loader(args, device):
     with open(args.token_file) as f:
         examples = [(e[0], e[1]) for e in json.load(f)]
     if args.world_size > 1:
-        examples = examples[max(args.global_rank, 0)::args.world_size]
+        # DistributedSampler semantics (run_img2txt_dist.py:295): every rank gets the SAME number of samples, ceil(N / W), the
+        # list being padded by wrapping around -- unequal shards would give ranks different step counts (a hung all-reduce at the
+        # epoch end and disagreeing lr schedules)
+        W, r = args.world_size, max(args.global_rank, 0)
+        per_rank = -(-len(examples) // W)
+        padded = examples + examples[:per_rank * W - len(examples)]
+        examples = padded[r::W]
+        assert len(examples) == per_rank
     kw = dict(max_pred=args.max_pred, mask_prob=args.mask_prob, vocab_size=KNOWN_VOCABS.get(args.bert_model, 28996), cls_id=synthetic.CLS_ID,
               sep_id=synthetic.SEP_ID, mask_id=synthetic.MASK_ID, unk_id=synthetic.UNK_ID, max_len=args.max_seq_length, max_len_b=args.max_len_b,
               len_vis_input=args.len_vis_input, new_segment_ids=args.new_segment_ids, trunc_seg=args.trunc_seg,
@@ -316,8 +327,9 @@ def main(argv=None):
         for step, batch in enumerate(loader if loader is not None else synthetic_batches(args, device, steps_per_epoch, args.global_rank)):
             acc = (step + 1) % args.gradient_accumulation_steps != 0
             lr = args.learning_rate * warmup_linear(global_step / t_total, args.warmup_proportion)
-            lt = train_step(model, optimizer, batch, lr, drop_worst_ratio=args.max_drop_worst_ratio if i_epoch > args.drop_after else 0,
-                            accumulate=acc)
+            lt = train_step(model, optimizer, batch, lr, mask_image_regions=args.mask_image_regions,
+                            drop_worst_ratio=args.max_drop_worst_ratio if i_epoch > args.drop_after else 0,
+                            accumulate=acc, accum_steps=args.gradient_accumulation_steps)
             if not acc:
                 global_step += 1
             if step % args.log_every == 0:        # the only host read-back; the reference does 4 per step (:535-538)

@@ -1,0 +1,124 @@
+"""Kernel-variant selection for the GEMM entry points -- deterministic by default.
+
+Every variant of vlp_gemm_nt / vlp_gemm_tn computes the same contraction, but tile shape and split factor change the
+fp32 summation order, i.e. the low-order bits of the fp16 results.  Round 1 chose variants by timing candidates on first
+use, which made numerics (and HBM traffic) depend on the box and on timer noise.  Now the choice is a pure function of
+the problem shape:
+
+  1. `VLP_NT_VARIANT` / `VLP_TN_CHOICE` environment overrides (A/B runs);
+  2. the committed table `vlp_amd/tuned_gfx950.json` (measured once on an MI355X with `python -m vlp_amd.tuning --tune`,
+     i.e. `VLP_AUTOTUNE=1`; the file travels with the source, so every box runs the same kernels);
+  3. a shape heuristic for everything the table does not list.
+
+`VLP_AUTOTUNE=1` re-enables the timing search (engine.py); `dump()` writes what it found so it can be committed.
+"""
+import json
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+TABLE_PATH = os.environ.get("VLP_TUNE_TABLE") or os.path.join(_HERE, "tuned_gfx950.json")
+AUTOTUNE = os.environ.get("VLP_AUTOTUNE", "0") == "1"
+
+SKINNY_SPLITS = (2, 3, 4, 6, 8, 12, 16)
+TN_SPLIT_CANDIDATES = (0, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16)
+
+_table = None
+_found = {}          # what an autotune run measured in this process: key string -> choice
+
+
+def _load():
+    global _table
+    if _table is None:
+        _table = {}
+        if os.path.exists(TABLE_PATH):
+            with open(TABLE_PATH) as f:
+                _table = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+    return _table
+
+
+def _key(kind, M, N, K):
+    return "%s:%d,%d,%d" % (kind, M, N, K)
+
+
+def lookup(kind, M, N, K):
+    v = _load().get(_key(kind, M, N, K))
+    if isinstance(v, list):
+        v = tuple(v)
+    return v
+
+
+def remember(kind, M, N, K, choice):
+    _found[_key(kind, M, N, K)] = list(choice) if isinstance(choice, tuple) else choice
+
+
+def dump(path):
+    """Merge this process's autotune results into `path` (json)."""
+    cur = {}
+    if os.path.exists(path):
+        with open(path) as f:
+            cur = json.load(f)
+    cur.update(_found)
+    with open(path, "w") as f:
+        json.dump(cur, f, indent=0, sort_keys=True)
+    return cur
+
+
+# ---- heuristics ------------------------------------------------------------------------------------------------------
+def nt_heuristic(M, N, K):
+    """vlp_gemm_nt variant (include/vlp_hip.h): +8 = XCD-aware tile order."""
+    if M <= 1024:
+        return 1                      # few workgroups: 128x128 LDS-DMA double buffer
+    if N >= 2048 and K >= 2048:
+        return 13                     # 256x256 tiles
+    if N <= 1024 and K >= 2048:
+        return 11                     # 256x128 tiles: long contraction, narrow output
+    if N >= 2048:
+        return 10                     # 128x128 single buffer, up to 4 workgroups per CU (epilogue-heavy wide outputs)
+    return 9
+
+
+def tn_heuristic(M, N, K):
+    """(variant, split-M factor) of vlp_gemm_tn for C[N,K] = A[M,N]^T B[M,K]: tiles x splits should fill 256 CUs x 2."""
+    if M < 1024:
+        return (2, 0)
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    want = max(1, 512 // tiles)
+    best = 0
+    for s in TN_SPLIT_CANDIDATES:
+        if 1 < s <= want and M // s >= 128:
+            best = s
+    return (2, best)
+
+
+def skinny_heuristic(M, N, K):
+    """('v', variant) | ('s', splits) for the decoder's M <= 1024 GEMMs (engine._nt_skinny)."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    best = None
+    for s in SKINNY_SPLITS:
+        if s * 2 <= K // 64 and tiles * s <= 512:
+            best = s
+    if tiles >= 128 or best is None:
+        return ("v", 1)
+    return ("s", best)
+
+
+def nt_variant(M, N, K):
+    env = os.environ.get("VLP_NT_VARIANT")
+    if env:
+        return int(env)
+    v = lookup("nt", M, N, K)
+    return int(v) if v is not None else nt_heuristic(M, N, K)
+
+
+def tn_choice(M, N, K):
+    env = os.environ.get("VLP_TN_CHOICE")
+    if env:
+        a, b = env.split(",")
+        return (int(a), int(b))
+    v = lookup("tn", M, N, K)
+    return (int(v[0]), int(v[1])) if v is not None else tn_heuristic(M, N, K)
+
+
+def skinny_choice(M, N, K):
+    v = lookup("sk", M, N, K)
+    return (str(v[0]), int(v[1])) if v is not None else skinny_heuristic(M, N, K)
