@@ -122,3 +122,13 @@ def tn_choice(M, N, K):
 def skinny_choice(M, N, K):
     v = lookup("sk", M, N, K)
     return (str(v[0]), int(v[1])) if v is not None else skinny_heuristic(M, N, K)
+
+
+def _dump_at_exit():
+    path = os.environ.get("VLP_TUNE_DUMP")
+    if path and _found:
+        dump(path)
+
+
+import atexit      # noqa: E402
+atexit.register(_dump_at_exit)
