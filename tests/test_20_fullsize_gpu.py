@@ -85,7 +85,6 @@ import os        # noqa: E402
 from oracle import vlp_oracle as O      # noqa: E402  (checker only)
 
 FULL_REPORT = {}
-GSCALE = 4096.0
 
 
 def _relmax(a, b):
@@ -130,18 +129,19 @@ def _oracle(p, batch, tasks, dtype, scale=None):
 
 FULL_CASES = {
     # BASELINE.json configs[1]/[2]: COCO captions fine-tune, all seq2seq masks
-    "coco_s2s": dict(tasks="img2txt", s2s_prob=1.0, max_pred=3, seed=101),
+    "coco_s2s": dict(tasks="img2txt", s2s_prob=1.0, max_pred=3, seed=101, gscale=4096.0),
     # configs[3]: Conceptual Captions pre-training shape, per-sample Bernoulli(0.75) seq2seq / bidirectional masks
-    "cc_mixed": dict(tasks="img2txt", s2s_prob=0.75, max_pred=3, seed=102),
+    "cc_mixed": dict(tasks="img2txt", s2s_prob=0.75, max_pred=3, seed=102, gscale=4096.0),
     # configs[4]: VQA 2.0 fine-tune, bidirectional, P = 1, answer-classifier head + BCE
-    "vqa2": dict(tasks="vqa2", s2s_prob=0.0, max_pred=1, seed=103),
+    # (the BCE x 3129 loss of random labels is ~2 200: a x4 scale keeps loss x scale inside fp16 for the fp16 oracle)
+    "vqa2": dict(tasks="vqa2", s2s_prob=0.0, max_pred=1, seed=103, gscale=4.0),
 }
 
 
 @pytest.mark.parametrize("case", list(FULL_CASES))
 def test_full_size_parity_vs_device_oracle(case):
     c = FULL_CASES[case]
-    tasks = c["tasks"]
+    tasks, GSCALE = c["tasks"], c["gscale"]
     p = O.init_params(vocab_size=V, layers=12, tasks=tasks, seed=c["seed"])
     batch = S.make_batch(B, max_len_b=64, vocab_size=V, max_pred=c["max_pred"], s2s_prob=c["s2s_prob"], tasks=tasks, seed=c["seed"] + 7)
     assert batch.input_ids.shape == (B, 167)
@@ -163,7 +163,6 @@ def test_full_size_parity_vs_device_oracle(case):
     unused = m.engine.unused_parameter_names()
     worst, worst_name, worst_excess, n_checked = 0.0, "", -1.0, 0
     per_tensor = {}
-    gmax = max(float(v.norm()) for v in gt.values() if v is not None)
     for n, v in gt.items():
         if n == "cls.predictions.decoder.weight":
             continue
@@ -173,11 +172,14 @@ def test_full_size_parity_vs_device_oracle(case):
             continue
         assert n not in unused, n
         mine = params[n].grad.float() / GSCALE
-        floor = 1e-4 * gmax * (v.numel() ** 0.5) / (115.9e6 ** 0.5)        # tensors whose whole gradient is at the noise floor
         e_h = float((mine.double() - v.double()).norm())
         e_r = float((g16[n].double() - v.double()).norm())
         nv = float(v.double().norm())
-        rel_h, rel_r = e_h / (nv + floor), e_r / (nv + floor)
+        if n.endswith("attention.self.key.bias"):
+            # softmax is invariant to a shift of every key's score, so this gradient is EXACTLY zero in exact arithmetic: the fp32
+            # "truth" is round-off.  Scale = the query-bias gradient of the same layer (the same column sum, over dQ instead of dK).
+            nv = float(gt[n.replace("key.bias", "query.bias")].double().norm())
+        rel_h, rel_r = e_h / (nv + 1e-30), e_r / (nv + 1e-30)
         per_tensor[n] = (rel_h, rel_r)
         n_checked += 1
         if rel_h > worst:
