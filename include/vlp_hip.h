@@ -36,8 +36,9 @@ typedef enum {
     VLP_ERR_WORKSPACE = -3    /* workspace too small */
 } vlp_status;
 
-enum { VLP_ACT_NONE = 0, VLP_ACT_GELU = 1, VLP_ACT_RELU = 2, VLP_ACT_TANH = 3 };
-enum { VLP_MUL_NONE = 0, VLP_MUL_GELU_GRAD = 1, VLP_MUL_RELU_MASK = 2 };
+enum { VLP_ACT_NONE = 0, VLP_ACT_GELU = 1, VLP_ACT_RELU = 2, VLP_ACT_TANH = 3,
+       VLP_ACT_GELU_SAVE_GRAD = 4 /* y = gelu(z), and `preact` receives gelu'(z) instead of z (z = fp16-rounded pre-activation) */ };
+enum { VLP_MUL_NONE = 0, VLP_MUL_GELU_GRAD = 1, VLP_MUL_RELU_MASK = 2, VLP_MUL_PLAIN = 3 /* y *= mul_src (a stored derivative) */ };
 
 int vlp_version(void);
 const char* vlp_last_error_string(void);
@@ -62,7 +63,7 @@ typedef struct {
     const void* mul_src; int64_t ldm;    /* [M,N] operand of mul_mode or NULL */
     int32_t M, N, K;
     int32_t act;                         /* VLP_ACT_* */
-    int32_t mul_mode;                    /* VLP_MUL_*: GELU_GRAD multiplies by gelu'(mul_src), RELU_MASK by (mul_src > 0) */
+    int32_t mul_mode;                    /* VLP_MUL_*: GELU_GRAD multiplies by gelu'(mul_src), RELU_MASK by (mul_src > 0), PLAIN by mul_src */
     float alpha;
     float dropout_p; uint64_t seed; uint32_t rng_stream;
     int32_t variant;                     /* 0 = register-staged 128x128 tiles, 1 = LDS-DMA (global_load_lds) double-buffered,

@@ -15,8 +15,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VLP_HIP_LIB") or os.path.join(_HERE, "libvlp_hip.so")      # VLP_HIP_LIB: A/B runs against another build of the SAME ABI
 
-ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
-MUL_NONE, MUL_GELU_GRAD, MUL_RELU_MASK = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH, ACT_GELU_SAVE_GRAD = 0, 1, 2, 3, 4
+MUL_NONE, MUL_GELU_GRAD, MUL_RELU_MASK, MUL_PLAIN = 0, 1, 2, 3
 
 vp, i64, i32, f32, u64, u32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_uint64, C.c_uint32
 

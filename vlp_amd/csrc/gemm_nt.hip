@@ -19,6 +19,7 @@
 // to the per-lane SOURCE address because the LDS destination is lane-linear).
 #include "common.h"
 #include "gemm_nt.h"
+#include "gemm_nt_epilogue.h"
 
 #define BM 128
 #define BK 64
@@ -226,52 +227,8 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BM
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[tn * 4 + r] = acc[tm][tn][r] * p.alpha + bias_v[tn * 4 + r];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {            // two 8-wide vectors
-            const int nc = ncol0 + 8 * h;
-            if (nc >= p.N) continue;
-            float* vv = v + 8 * h;
-            if (p.preact) {
-                f16x8 z;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) z[j] = (nc + j < p.N) ? (f16)vv[j] : (f16)0.f;
-                st8(p.preact + (int64_t)m * p.ldp + nc, z);
-                // keep forward/backward consistent: the activation sees the fp16-rounded pre-activation
-#pragma unroll
-                for (int j = 0; j < 8; ++j) vv[j] = (float)z[j];
-            }
-            if (p.act == VLP_ACT_GELU) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) vv[j] = gelu_f(vv[j]);
-            } else if (p.act == VLP_ACT_RELU) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) vv[j] = fmaxf(vv[j], 0.f);
-            } else if (p.act == VLP_ACT_TANH) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) vv[j] = tanhf(vv[j]);
-            }
-            if (p.mulmode != VLP_MUL_NONE) {
-                f16x8 s = ld8(p.mulsrc + (int64_t)m * p.ldm + nc);
-                if (p.mulmode == VLP_MUL_GELU_GRAD) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) vv[j] *= gelu_grad_f((float)s[j]);
-                } else {   // VLP_MUL_RELU_MASK
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) vv[j] = ((float)s[j] > 0.f) ? vv[j] : 0.f;
-                }
-            }
-            if (p.drop.thresh) {
-                drop_mult8(p.drop, rkey, (uint32_t)nc, vv);
-            }
-            if (p.residual) {
-                f16x8 r = ld8(p.residual + (int64_t)m * p.ldr + nc);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) vv[j] += (float)r[j];
-            }
-            f16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (nc + j < p.N) ? (f16)vv[j] : (f16)0.f;
-            st8(p.Y + (int64_t)m * p.ldy + nc, o);
-        }
+        for (int h = 0; h < 2; ++h)              // two 8-wide vectors through the shared epilogue (bias already added)
+            nt_epilogue8(p, m, ncol0 + 8 * h, v + 8 * h, rkey, true);
     }
 }
 
@@ -290,7 +247,9 @@ int vlp_gemm_nt_fill_params(const vlp_gemm_nt_args* a, GemmNtParams& p) {
     if (a->mul_mode != VLP_MUL_NONE)
         VLP_CHECK_ARG(a->mul_src && a->ldm % 8 == 0 && a->ldm >= n8 && (uintptr_t)a->mul_src % 16 == 0, "vlp_gemm_nt: bad mul_src layout");
     if (a->bias) VLP_CHECK_ARG((uintptr_t)a->bias % 16 == 0, "vlp_gemm_nt: bias must be 16-byte aligned");
-    VLP_CHECK_ARG(a->act >= VLP_ACT_NONE && a->act <= VLP_ACT_TANH, "vlp_gemm_nt: bad act %d", a->act);
+    VLP_CHECK_ARG(a->act >= VLP_ACT_NONE && a->act <= VLP_ACT_GELU_SAVE_GRAD, "vlp_gemm_nt: bad act %d", a->act);
+    VLP_CHECK_ARG(a->act != VLP_ACT_GELU_SAVE_GRAD || a->preact, "vlp_gemm_nt: VLP_ACT_GELU_SAVE_GRAD needs `preact` (receives gelu'(z))");
+    VLP_CHECK_ARG(a->mul_mode >= VLP_MUL_NONE && a->mul_mode <= VLP_MUL_PLAIN, "vlp_gemm_nt: bad mul_mode %d", a->mul_mode);
     VLP_CHECK_ARG(a->dropout_p >= 0.f && a->dropout_p < 1.f, "vlp_gemm_nt: bad dropout p");
 
     p.X = (const f16*)a->X; p.ldx = a->ldx;

@@ -3,9 +3,9 @@
 #include "gemm_nt.h"
 
 // one 8-wide output vector of row m: bias, pre-activation store, activation, gelu'/relu-mask multiply, dropout, residual, store
-DEVFN void nt_epilogue8(const GemmNtParams& p, int m, int nc, float* vv, uint32_t rkey) {
+DEVFN void nt_epilogue8(const GemmNtParams& p, int m, int nc, float* vv, uint32_t rkey, bool bias_done = false) {
     if (nc >= p.N) return;
-    if (p.bias) {
+    if (p.bias && !bias_done) {
         if (nc + 8 <= p.N) {
             const f16x8 b = ld8(p.bias + nc);
 #pragma unroll
@@ -15,29 +15,45 @@ DEVFN void nt_epilogue8(const GemmNtParams& p, int m, int nc, float* vv, uint32_
             for (int j = 0; j < 8; ++j) if (nc + j < p.N) vv[j] += (float)p.bias[nc + j];
         }
     }
-    if (p.preact) {
-        f16x8 z;
+    if (p.act == VLP_ACT_GELU_SAVE_GRAD) {
+        // z = fp16-rounded pre-activation (what a stored z would hold); y = gelu(z); preact <- gelu'(z)
+        f16x8 d;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) z[j] = (nc + j < p.N) ? (f16)vv[j] : (f16)0.f;
-        st8(p.preact + (int64_t)m * p.ldp + nc, z);
+        for (int j = 0; j < 8; ++j) {
+            float gl, gp;
+            gelu_and_grad_f((float)(f16)vv[j], gl, gp);
+            vv[j] = gl;
+            d[j] = (nc + j < p.N) ? (f16)gp : (f16)0.f;
+        }
+        st8(p.preact + (int64_t)m * p.ldp + nc, d);
+    } else {
+        if (p.preact) {
+            f16x8 z;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) vv[j] = (float)z[j];      // the activation sees the fp16-rounded pre-activation (as backward will)
-    }
-    if (p.act == VLP_ACT_GELU) {
+            for (int j = 0; j < 8; ++j) z[j] = (nc + j < p.N) ? (f16)vv[j] : (f16)0.f;
+            st8(p.preact + (int64_t)m * p.ldp + nc, z);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) vv[j] = gelu_f(vv[j]);
-    } else if (p.act == VLP_ACT_RELU) {
+            for (int j = 0; j < 8; ++j) vv[j] = (float)z[j];      // the activation sees the fp16-rounded pre-activation (as backward will)
+        }
+        if (p.act == VLP_ACT_GELU) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) vv[j] = fmaxf(vv[j], 0.f);
-    } else if (p.act == VLP_ACT_TANH) {
+            for (int j = 0; j < 8; ++j) vv[j] = gelu_f(vv[j]);
+        } else if (p.act == VLP_ACT_RELU) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) vv[j] = tanhf(vv[j]);
+            for (int j = 0; j < 8; ++j) vv[j] = fmaxf(vv[j], 0.f);
+        } else if (p.act == VLP_ACT_TANH) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vv[j] = tanhf(vv[j]);
+        }
     }
     if (p.mulmode != VLP_MUL_NONE) {
         const f16x8 s = ld8(p.mulsrc + (int64_t)m * p.ldm + nc);
         if (p.mulmode == VLP_MUL_GELU_GRAD) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) vv[j] *= gelu_grad_f((float)s[j]);
+        } else if (p.mulmode == VLP_MUL_PLAIN) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vv[j] *= (float)s[j];
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) vv[j] = ((float)s[j] > 0.f) ? vv[j] : 0.f;
@@ -56,4 +72,3 @@ DEVFN void nt_epilogue8(const GemmNtParams& p, int m, int nc, float* vv, uint32_
     for (int j = 0; j < 8; ++j) o[j] = (nc + j < p.N) ? (f16)vv[j] : (f16)0.f;
     st8(p.Y + (int64_t)m * p.ldy + nc, o);
 }
-

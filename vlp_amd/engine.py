@@ -50,10 +50,12 @@ class Engine(object):
     NT_CANDIDATES = (1, 2, 4, 5, 9, 10, 11, 12, 13)   # LDS-DMA variants (+8 = XCD-aware tile order); see include/vlp_hip.h
     NT_CANDIDATES_SKINNY = (1, 2, 9, 10, 11, 17)      # M <= 1024 (decoding, LM head): few workgroups, latency-bound -> also the 4-stage ring
     GEMM_TN_VARIANT = 2      # ds_read_b64_tr_b16 fragment reads + LDS-DMA staging
-    # weight-gradient GEMMs of the encoder layers on a second HIP stream, concurrent with the dgrad chain: +1.5-2 % step
-    # throughput on one MI355X (4706 vs 4637 samples/s); off by default so that per-kernel timings (bench.py roofline,
-    # rocprofv3) are single-kernel measurements.  VLP_WGRAD_SIDE_STREAM=1 turns it on.
-    WGRAD_SIDE_STREAM = os.environ.get("VLP_WGRAD_SIDE_STREAM", "0") == "1"
+    # weight-gradient GEMMs of the encoder layers on a second HIP stream, concurrent with the dgrad chain (the wgrad grids are a single
+    # round of 430-580 workgroups whose tails leave CUs idle; so do LN / attention backward): +2.6 % step throughput on one MI355X.
+    # Results are bit-identical with and without (tests/test_10_model_gpu.py).  VLP_WGRAD_SIDE_STREAM=0 turns it off (clean
+    # single-kernel timings under rocprofv3).  bench.py's live roofline samples stay single-kernel measurements: a sampled launch
+    # first lets the side stream drain (see _nt).
+    WGRAD_SIDE_STREAM = os.environ.get("VLP_WGRAD_SIDE_STREAM", "1") == "1"
     TN_SPLITS = None         # None -> vlp_amd.tuning (variant flags, split-M factor) per (M, N, K)
     # split-M factor: the wgrad outputs are small (36..144 tiles of 128x128) and the contraction long (M = 10 688), so the
     # workgroup count tiles*splits has to land just under a multiple of the 256 CUs x 2 resident workgroups: 3 (432 workgroups)
@@ -79,6 +81,8 @@ class Engine(object):
         self._ws = {}
         self._shadow = None
         self.prof = None                  # list -> every PROF_EVERY-th NT-GEMM launch is bracketed by HIP events (bench.py roofline)
+        self._side = None                 # second HIP stream for the layer wgrads (created on first use)
+        self._side_busy = False           # True while backward may have work queued on it
         self._prof_ctr = 0
 
     # ------------------------------------------------------------------------------------------
@@ -353,11 +357,18 @@ class Engine(object):
         if self.prof is None or self._prof_ctr % self.PROF_EVERY:
             K.gemm_nt(x, w, y, M, N, Kd, variant=v, **kw)
             return
-        # events are recorded on torch's current stream == the stream handed to the C ABI
+        # events are recorded on torch's current stream == the stream handed to the C ABI.  While backward has weight-gradient GEMMs
+        # in flight on the side stream, a sampled launch waits for them (and they for it), so that the bracket times ONE kernel.
+        side = self._side if self._side_busy else None
+        main = torch.cuda.current_stream()
+        if side is not None:
+            main.wait_stream(side)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         K.gemm_nt(x, w, y, M, N, Kd, variant=v, **kw)
         e1.record()
+        if side is not None:
+            side.wait_stream(main)
         self.prof.append((e0, e1, 2.0 * M * N * Kd))
 
     SKINNY_SPLITS = (2, 3, 4, 6, 8, 12, 16)
@@ -485,8 +496,10 @@ class Engine(object):
                      residual=x, dropout_p=p, seed=seed, rng_stream=16 * i + 2)
             K.layernorm_fwd(a["pre1"], self.P(Ln + "attention.output.LayerNorm.weight"), self.P(Ln + "attention.output.LayerNorm.bias"),
                             a["x1"], M, H, a["st1"][0], a["st1"][1])
+            # a["z"] receives gelu'(z), not z: the only consumer is the FFN-down dgrad epilogue, which then multiplies by a stored
+            # number instead of re-evaluating erf + exp per element
             self._nt(a["x1"], self.P(Ln + "intermediate.dense.weight"), a["g"], M, I, H, bias=self.P(Ln + "intermediate.dense.bias"),
-                     preact=a["z"], act=K.ACT_GELU)
+                     preact=a["z"], act=K.ACT_GELU_SAVE_GRAD)
             self._nt(a["g"], self.P(Ln + "output.dense.weight"), a["pre2"], M, H, I, bias=self.P(Ln + "output.dense.bias"),
                      residual=a["x1"], dropout_p=p, seed=seed, rng_stream=16 * i + 3)
             K.layernorm_fwd(a["pre2"], self.P(Ln + "output.LayerNorm.weight"), self.P(Ln + "output.LayerNorm.bias"), a["x2"], M, H,
@@ -937,7 +950,7 @@ class Engine(object):
         scale = 1.0 / math.sqrt(H // A)
         main = torch.cuda.current_stream()
         use_side = self.WGRAD_SIDE_STREAM
-        if use_side and getattr(self, "_side", None) is None:
+        if use_side and self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
             self._side_done = [None, None]
         side = self._side if use_side else None
@@ -952,6 +965,7 @@ class Engine(object):
 
         if use_side:
             side.wait_stream(main)          # head wgrads above ran on main; order the side stream after them (tn_ws reuse)
+            self._side_busy = True
         for i in reversed(range(NL)):
             Ln = "bert.encoder.layer.%d." % i
             a = ws["layers"][i]
@@ -967,7 +981,7 @@ class Engine(object):
                             dx_drop=ds["dpre2_d"] if p > 0 else None, out_drop=(p, seed, 16 * i + 3))
             dy2 = ds["dpre2_d"] if p > 0 else dpre
             on_side(lambda: self._tn(dy2, a["g"], self.G(Ln + "output.dense.weight"), M, H, I, ws, beta, bias=self.G(Ln + "output.dense.bias")))
-            self._nt(dy2, s["w2T"], ds["dz"], M, I, H, mul_src=a["z"], mul_mode=K.MUL_GELU_GRAD)      # dG * gelu'(z)
+            self._nt(dy2, s["w2T"], ds["dz"], M, I, H, mul_src=a["z"], mul_mode=K.MUL_PLAIN)      # dG * gelu'(z) (stored by the forward)
             # BertIntermediate (modeling.py:340-343)
             on_side(lambda: self._tn(ds["dz"], a["x1"], self.G(Ln + "intermediate.dense.weight"), M, I, H, ws, beta,
                                      bias=self.G(Ln + "intermediate.dense.bias")))
@@ -997,6 +1011,7 @@ class Engine(object):
             self._nt(dqkv, s["qkvT"], dx, M, H, 3 * H, residual=dpre)
         if use_side:
             main.wait_stream(side)          # all layer wgrads (and their bucket hand-offs) precede the rest of backward
+            self._side_busy = False
         dpre = ws["dpre"]
 
         # ---- embeddings -------------------------------------------------------------------------------------
