@@ -202,11 +202,12 @@ def test_full_size_parity_vs_device_oracle(case):
     assert n_checked >= (208 if tasks == "img2txt" else 206), n_checked
     for n, (rel_h, rel_r) in per_tensor.items():
         if n.endswith("attention.self.key.bias"):          # true value 0: bounded against the sibling query-bias gradient
-            assert rel_h <= 5e-2, (n, rel_h, rel_r)
+            assert rel_h <= 5e-3, (n, rel_h, rel_r)         # measured <= 2.3e-3 of the query-bias gradient norm
             continue
-        # measured (profiles/r02_parity_report.json): worst tensor 1.45e-2 (vis_pe_embed.0.weight; the reference's own fp16
-        # arithmetic: 1.45e-2), median 1.7e-3, never more than 4.5e-4 above the reference-fp16 error of the same tensor
-        assert rel_h <= max(1.25 * rel_r, rel_r + 1e-3), (n, rel_h, rel_r)
+        # measured (profiles/r02_parity_report.json): worst tensor 1.45e-2 / 1.70e-2 (vis_pe_embed.0.weight, img2txt / vqa2; the
+        # reference's own fp16 arithmetic: 1.45e-2 / 1.69e-2), median 1.7e-3 / 3.5e-3, and never more than 4.5e-4 (img2txt) /
+        # 1.9e-3 (vqa2, back-propagated with a x4 scale only) above the reference-fp16 error of the same tensor
+        assert rel_h <= max(1.25 * rel_r, rel_r + (1e-3 if tasks == "img2txt" else 2.5e-3)), (n, rel_h, rel_r)
         assert rel_h <= 2e-2, (n, rel_h, rel_r)
 
 

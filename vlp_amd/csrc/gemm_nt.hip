@@ -36,7 +36,7 @@ DEVFN int swz_w(int r) { return (((r >> 4) & 3) << 1) | ((r >> 1) & 1); }
 //    bound by the DMA round trip.  On the decoder's skinny GEMMs (M = 128..640: a few dozen workgroups, each alone on its CU and
 //    paying one L2 round trip per k tile) the 128x128 ring (variant 17) is the latency-hiding kernel; the autotuner picks it there.
 // BM_T: rows of the block tile (128 -> 4 waves 2x2, 256 -> 8 waves 4x2); the wave tile is always 64x64.
-template <int VARIANT, int BM_T, int BN_T>
+template <int VARIANT, int BM_T, int BN_T, bool SG>
 __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BM_T / 128) : ((VARIANT == 2 || BN_T == 256) ? 4 : 2))) void gemm_nt_kernel(GemmNtParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     f16* smem = reinterpret_cast<f16*>(smem_raw);
@@ -228,7 +228,7 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BM
             for (int r = 0; r < 4; ++r) v[tn * 4 + r] = acc[tm][tn][r] * p.alpha + bias_v[tn * 4 + r];
 #pragma unroll
         for (int h = 0; h < 2; ++h)              // two 8-wide vectors through the shared epilogue (bias already added)
-            nt_epilogue8(p, m, ncol0 + 8 * h, v + 8 * h, rkey, true);
+            nt_epilogue8<SG>(p, m, ncol0 + 8 * h, v + 8 * h, rkey, true);
     }
 }
 
@@ -273,14 +273,22 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
     const int frc = vlp_gemm_nt_fill_params(a, p);
     if (frc != VLP_OK) return frc;
     hipStream_t s = (hipStream_t)stream;
-#define LAUNCH_NT(V, BMT, BNT, NBUF)                                                                                    \
+#define LAUNCH_NT_(V, BMT, BNT, NBUF, SGV)                                                                              \
     do {                                                                                                                \
         const size_t smem = (size_t)(NBUF) * ((BMT) + (BNT)) * BK * sizeof(f16);                                        \
-        static bool attr = false;                                                                                       \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<V, BMT, BNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; } \
+        static bool attr = false;   /* one process drives one GPU (one rank per device); see DESIGN.md */                \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<V, BMT, BNT, SGV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; } \
         p.tiles_n = cdiv(a->N, (BNT));                                                                                  \
-        hipLaunchKernelGGL((gemm_nt_kernel<V, BMT, BNT>), dim3(cdiv(a->M, (BMT)) * p.tiles_n), dim3(((BMT) / 64) * ((BNT) / 64) * 64), smem, s, p); \
+        hipLaunchKernelGGL((gemm_nt_kernel<V, BMT, BNT, SGV>), dim3(cdiv(a->M, (BMT)) * p.tiles_n), dim3(((BMT) / 64) * ((BNT) / 64) * 64), smem, s, p); \
     } while (0)
+#define LAUNCH_NT(V, BMT, BNT, NBUF) \
+    do { if (sg) LAUNCH_NT_(V, BMT, BNT, NBUF, true); else LAUNCH_NT_(V, BMT, BNT, NBUF, false); } while (0)
+    const bool sg = a->act == VLP_ACT_GELU_SAVE_GRAD;
+    if (sg) {
+        VLP_CHECK_ARG(!a->residual && a->mul_mode == VLP_MUL_NONE && a->dropout_p == 0.f,
+                      "vlp_gemm_nt: VLP_ACT_GELU_SAVE_GRAD fuses bias + gelu + derivative only (no residual / multiplier / dropout)");
+        VLP_CHECK_ARG((a->variant & 7) != 6 && (a->variant & 7) != 7, "vlp_gemm_nt: VLP_ACT_GELU_SAVE_GRAD is not provided by the phased variants (6, 7)");
+    }
     p.xcd_remap = (a->variant & 8) ? 1 : 0;
     switch (a->variant & 7) {
         case 6: case 7: {
@@ -297,6 +305,7 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
         default: LAUNCH_NT(1, 128, 128, 2); break;
     }
 #undef LAUNCH_NT
+#undef LAUNCH_NT_
     VLP_CHECK_LAUNCH("vlp_gemm_nt");
     return VLP_OK;
 }
@@ -306,5 +315,6 @@ extern "C" int vlp_gemm_nt_splitk(const vlp_gemm_nt_args* a, int32_t splits, voi
     GemmNtParams p;
     const int frc = vlp_gemm_nt_fill_params(a, p);
     if (frc != VLP_OK) return frc;
+    VLP_CHECK_ARG(a->act != VLP_ACT_GELU_SAVE_GRAD, "vlp_gemm_nt_splitk: VLP_ACT_GELU_SAVE_GRAD is not provided (training-shape kernels only)");
     return vlp_gemm_nt_splitk_launch(p, splits, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -3,6 +3,9 @@
 #include "gemm_nt.h"
 
 // one 8-wide output vector of row m: bias, pre-activation store, activation, gelu'/relu-mask multiply, dropout, residual, store
+// SG (compile time) = the VLP_ACT_GELU_SAVE_GRAD form; it lives in its own kernel instantiations so that the generic epilogue keeps
+// its register footprint (the erf/exp pair + derivative of 8 elements in flight costs ~25 VGPRs: the 128-VGPR variants spilled).
+template <bool SG = false>
 DEVFN void nt_epilogue8(const GemmNtParams& p, int m, int nc, float* vv, uint32_t rkey, bool bias_done = false) {
     if (nc >= p.N) return;
     if (p.bias && !bias_done) {
@@ -15,17 +18,20 @@ DEVFN void nt_epilogue8(const GemmNtParams& p, int m, int nc, float* vv, uint32_
             for (int j = 0; j < 8; ++j) if (nc + j < p.N) vv[j] += (float)p.bias[nc + j];
         }
     }
-    if (p.act == VLP_ACT_GELU_SAVE_GRAD) {
-        // z = fp16-rounded pre-activation (what a stored z would hold); y = gelu(z); preact <- gelu'(z)
-        f16x8 d;
+    if (SG) {
+        // z = fp16-rounded pre-activation (what a stored z would hold); y = gelu(z); preact <- gelu'(z); nothing else is fused
+        f16x8 d, o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float gl, gp;
             gelu_and_grad_f((float)(f16)vv[j], gl, gp);
-            vv[j] = gl;
-            d[j] = (nc + j < p.N) ? (f16)gp : (f16)0.f;
+            const bool in = nc + j < p.N;
+            o[j] = in ? (f16)gl : (f16)0.f;
+            d[j] = in ? (f16)gp : (f16)0.f;
         }
         st8(p.preact + (int64_t)m * p.ldp + nc, d);
+        st8(p.Y + (int64_t)m * p.ldy + nc, o);
+        return;
     } else {
         if (p.preact) {
             f16x8 z;
