@@ -73,7 +73,9 @@ typedef struct {
                                             counted vmcnt, 128x64 / 64x64 wave tiles, two staggered wave groups; need K >= 128;
                                             +16 = one barrier per phase, compiler-scheduled, +48 = no stagger);
                                             17 / 19 = variants 1 / 3 with a 4- / 3-stage LDS-DMA ring and counted vmcnt (17: latency hiding for skinny M);
-                                            +8 = XCD-aware tile order.  Every variant computes the same result. */
+                                            +8 = XCD-aware tile order;
+                                            21 = variant 5 (256x256) as a 2-stage ring: one raw s_barrier per k tile, DMA issued right behind it, counted vmcnt.
+                                            Every variant computes the same result. */
 } vlp_gemm_nt_args;
 int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream);
 /* Split-K form for skinny problems (incremental decoding, M = 128..640 rows: only N/128 output tiles): the k range is cut into `splits`
@@ -98,8 +100,8 @@ typedef struct {
     int32_t beta;                        /* 0 or 1 */
     void* workspace; int64_t workspace_bytes;
     int32_t variant;                     /* 0 = ds_read_u16 fragment gathers, 1 = ds_read_b64_tr_b16 (register-staged), 2 = ds_read_b64_tr_b16 +
-                                            LDS-DMA staging with a transpose-read swizzle, 128x128 tile; 3 / 4 / 5 = the same with
-                                            256x128 / 128x256 / 256x256 (n x k) tiles; +8 = XCD-aware tile order,
+                                            LDS-DMA staging with a transpose-read swizzle, 128x128 tile; 3 / 4 = the same with
+                                            256x128 / 128x256 (n x k) tiles (5 = 256x256 was removed in round 2: rejected); +8 = XCD-aware tile order,
                                             +16 = split-major tile order (with +8: one XCD per row range) */
     int32_t splits;                      /* 0 = choose automatically */
     void* bias_out;                      /* optional [N] fp16: (+)= column sums of A, i.e. the bias gradient of the same

@@ -56,22 +56,37 @@ def main():
         cases = []
     cases.append(("ffn_up     N=3072 K=768  bias+gelu+savegrad", I, H, lambda n: dict(bias=r(n), preact=torch.empty(M, n, device=DEV, dtype=torch.half), act=K.ACT_GELU_SAVE_GRAD)))
     cases.append(("d_ffn_down N=3072 K=768  plain mul", I, H, lambda n: dict(mul_src=r(M, n, scale=1.0), mul_mode=K.MUL_PLAIN)))
+    rot = 1
+    for a in sys.argv:
+        if a.startswith("--rotate="):
+            rot = int(a.split("=")[1])       # cycle through `rot` independent operand sets (as the 12 layers of a step do): cold caches
     for name, n, k, mk in cases:
-        x, w = r(M, k), r(n, k, scale=0.05)
-        y = torch.empty(M, n, device=DEV, dtype=torch.half)
-        kw = mk(n)
+        sets = []
+        for _ in range(rot):
+            sets.append((r(M, k), r(n, k, scale=0.05), torch.empty(M, n, device=DEV, dtype=torch.half), mk(n)))
         row = {}
         for v in variants:
             if v & 7 == 5 and n < 1024:
                 continue
+            ctr = [0]
+
+            def call(v=v):
+                x, w, y, kw = sets[ctr[0] % rot]
+                ctr[0] += 1
+                K.gemm_nt(x, w, y, M, n, k, variant=v, **kw)
             try:
-                us = timeit(lambda: K.gemm_nt(x, w, y, M, n, k, variant=v, **kw))
-            except RuntimeError as e:
+                us = timeit(call, iters=max(20, 2 * rot))
+            except RuntimeError:
                 row[v] = None
                 continue
             row[v] = us
-        a = x
-        us_t = timeit(lambda: torch.matmul(a, w.t()))
+        ctr = [0]
+
+        def tcall():
+            x, w, y, kw = sets[ctr[0] % rot]
+            ctr[0] += 1
+            torch.matmul(x, w.t())
+        us_t = timeit(tcall, iters=max(20, 2 * rot))
         res[name] = {"variants": row, "torch_matmul_plain": us_t, "gflop": 2.0 * M * n * k / 1e9}
         best = min((u, v) for v, u in row.items() if u)
         print("%-42s best v%-2d %6.1f us %6.0f TF | torch plain %6.1f us | %s" % (

@@ -231,8 +231,10 @@ __global__ __launch_bounds__(ATT_THREADS8, NT <= 12 ? 4 : 2) void attn_fwd_kerne
 // =================================================================================================
 // backward, part 1: dQ (and delta = rowsum(dO * O)).  Transposed orientation, query column per lane.
 // =================================================================================================
+// NT = 16 (192 < L <= 256) needs ~300 registers per lane (16 score tiles + 8 dS fragments live): one workgroup per CU there (512-entry
+// unified VGPR/AGPR file, no spills) instead of two with 43 spilled VGPRs
 template <int NT>
-__global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(ATT_THREADS, NT <= 12 ? 2 : 1) void attn_bwd_dq_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int LP = NT * 16;
     f16* Ks = reinterpret_cast<f16*>(smem_raw);     // [LP][64] swizzled
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams 
 // loads of a key tile are issued before its query loop.
 // =================================================================================================
 template <int NT>
-__global__ __launch_bounds__(ATT_THREADS8, 4) void attn_bwd_dkv_kernel(AttnParams p) {
+__global__ __launch_bounds__(ATT_THREADS8, NT >= 8 ? 4 : 2) void attn_bwd_dkv_kernel(AttnParams p) {   // NT = 4: the fully unrolled pair loop needs 130 VGPRs
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int LP = NT * 16;
     f16* Qs = reinterpret_cast<f16*>(smem_raw);     // [LP][64] swizzled

@@ -36,8 +36,9 @@ DEVFN int swz_w(int r) { return (((r >> 4) & 3) << 1) | ((r >> 1) & 1); }
 //    bound by the DMA round trip.  On the decoder's skinny GEMMs (M = 128..640: a few dozen workgroups, each alone on its CU and
 //    paying one L2 round trip per k tile) the 128x128 ring (variant 17) is the latency-hiding kernel; the autotuner picks it there.
 // BM_T: rows of the block tile (128 -> 4 waves 2x2, 256 -> 8 waves 4x2); the wave tile is always 64x64.
-template <int VARIANT, int BM_T, int BN_T, bool SG>
-__global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BM_T / 128) : ((VARIANT == 2 || BN_T == 256) ? 4 : 2))) void gemm_nt_kernel(GemmNtParams p) {
+// NSR: stages of the VARIANT 3 ring (0 = default: 3 for 256-row tiles, 4 for 128x128).
+template <int VARIANT, int BM_T, int BN_T, bool SG, int NSR = 0>
+__global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BN_T == 256 ? 4 : BM_T / 128) : ((VARIANT == 2 || BN_T == 256) ? 4 : 2))) void gemm_nt_kernel(GemmNtParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     f16* smem = reinterpret_cast<f16*>(smem_raw);
     constexpr int WN_ = BN_T / 64;        // waves along n
@@ -184,8 +185,11 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BM
         // stay in flight; (2) barrier: every wave's pieces have landed AND every wave has finished the MFMAs (hence the ds_reads) of
         // stage kt-1, whose buffer is therefore free; (3) refill that buffer with stage kt+NS-1; (4) compute stage kt.
         // k tiles past the end are clamped to the last one (dummy reloads into buffers nobody reads again) so the count stays constant.
-        constexpr int NS = (BM_T == 256) ? 3 : 4;
+        constexpr int NS = NSR ? NSR : ((BM_T == 256) ? 3 : 4);
         constexpr int LPS = XP + WP;                 // DMA instructions per thread per stage
+        // (An L2 prefetch of later stages by dummy dword loads -- one 128-byte row per thread, counted into the vmcnt budget -- was measured
+        // and removed: every byte then crosses the L2 -> CU path twice, and that path, not HBM latency alone, is what bounds these loops:
+        // 78 vs 63 us on 10688x768x3072 with cold operands, tools/nt_lab.py --rotate=12.)
 #pragma unroll
         for (int st = 0; st < NS - 1; ++st) glds(min(st, nk - 1), st);
         int buf = 0, nbuf = NS - 1;
@@ -273,16 +277,19 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
     const int frc = vlp_gemm_nt_fill_params(a, p);
     if (frc != VLP_OK) return frc;
     hipStream_t s = (hipStream_t)stream;
-#define LAUNCH_NT_(V, BMT, BNT, NBUF, SGV)                                                                              \
+#define LAUNCH_NT_(V, BMT, BNT, NBUF, SGV, NSRV)                                                                  \
     do {                                                                                                                \
         const size_t smem = (size_t)(NBUF) * ((BMT) + (BNT)) * BK * sizeof(f16);                                        \
         static bool attr = false;   /* one process drives one GPU (one rank per device); see DESIGN.md */                \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<V, BMT, BNT, SGV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; } \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<V, BMT, BNT, SGV, NSRV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; } \
         p.tiles_n = cdiv(a->N, (BNT));                                                                                  \
-        hipLaunchKernelGGL((gemm_nt_kernel<V, BMT, BNT, SGV>), dim3(cdiv(a->M, (BMT)) * p.tiles_n), dim3(((BMT) / 64) * ((BNT) / 64) * 64), smem, s, p); \
+        hipLaunchKernelGGL((gemm_nt_kernel<V, BMT, BNT, SGV, NSRV>), dim3(cdiv(a->M, (BMT)) * p.tiles_n), dim3(((BMT) / 64) * ((BNT) / 64) * 64), smem, s, p); \
     } while (0)
 #define LAUNCH_NT(V, BMT, BNT, NBUF) \
-    do { if (sg) LAUNCH_NT_(V, BMT, BNT, NBUF, true); else LAUNCH_NT_(V, BMT, BNT, NBUF, false); } while (0)
+    do { if (sg) LAUNCH_NT_(V, BMT, BNT, NBUF, true, 0); else LAUNCH_NT_(V, BMT, BNT, NBUF, false, 0); } while (0)
+    /* ring kernels with an explicit stage count (NBUF = stages) */
+#define LAUNCH_RING(BMT, BNT, NSV) \
+    do { if (sg) LAUNCH_NT_(3, BMT, BNT, NSV, true, NSV); else LAUNCH_NT_(3, BMT, BNT, NSV, false, NSV); } while (0)
     const bool sg = a->act == VLP_ACT_GELU_SAVE_GRAD;
     if (sg) {
         VLP_CHECK_ARG(!a->residual && a->mul_mode == VLP_MUL_NONE && a->dropout_p == 0.f,
@@ -298,12 +305,19 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
         }
         case 0: LAUNCH_NT(0, 128, 128, 2); break;
         case 1: if (a->variant & 16) LAUNCH_NT(3, 128, 128, 4); else LAUNCH_NT(1, 128, 128, 2); break;
-        case 3: if (a->variant & 16) LAUNCH_NT(3, 256, 128, 3); else LAUNCH_NT(1, 256, 128, 2); break;
+        case 3:
+            if (a->variant & 16) LAUNCH_NT(3, 256, 128, 3);
+            else LAUNCH_NT(1, 256, 128, 2);
+            break;
         case 2: LAUNCH_NT(2, 128, 128, 1); break;
         case 4: LAUNCH_NT(2, 256, 128, 1); break;
-        case 5: LAUNCH_NT(1, 256, 256, 2); break;
+        case 5:
+            if (a->variant & 16) LAUNCH_RING(256, 256, 2);
+            else LAUNCH_NT(1, 256, 256, 2);
+            break;
         default: LAUNCH_NT(1, 128, 128, 2); break;
     }
+#undef LAUNCH_RING
 #undef LAUNCH_NT
 #undef LAUNCH_NT_
     VLP_CHECK_LAUNCH("vlp_gemm_nt");

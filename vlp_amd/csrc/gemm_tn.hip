@@ -470,7 +470,8 @@ extern "C" int vlp_gemm_tn(const vlp_gemm_tn_args* a, void* stream) {
     if (base == 2) LAUNCH_TN_GLDS(128, 128);
     else if (base == 3) LAUNCH_TN_GLDS(256, 128);
     else if (base == 4) LAUNCH_TN_GLDS(128, 256);
-    else if (base == 5) LAUNCH_TN_GLDS(256, 256);
+    else if (base == 5) return vlp_set_error(VLP_ERR_BAD_ARG, "vlp_gemm_tn: variant 5 (256x256 tiles, 16 waves) was removed: it needed 139 VGPRs under a "
+                                             "128-register cap (spills) and lost to the 128x128 kernel on every training shape");
     else {
         dim3 grid(p.tiles_k * p.tiles_n * splits), block(TN_THREADS);
         const size_t smem = 2 * 2 * TN_BM * TN_PITCH * sizeof(f16);   // 68 KiB

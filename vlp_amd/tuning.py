@@ -65,16 +65,13 @@ def dump(path):
 
 # ---- heuristics ------------------------------------------------------------------------------------------------------
 def nt_heuristic(M, N, K):
-    """vlp_gemm_nt variant (include/vlp_hip.h): +8 = XCD-aware tile order."""
+    """vlp_gemm_nt variant (include/vlp_hip.h): +8 = XCD-aware tile order, +16 = LDS-DMA ring (raw barrier, counted vmcnt).
+    Measured with cold operands (tools/nt_lab.py --rotate=12), which is what a training step sees: the rings win every shape."""
     if M <= 1024:
         return 1                      # few workgroups: 128x128 LDS-DMA double buffer
-    if N >= 2048 and K >= 2048:
-        return 13                     # 256x256 tiles
-    if N <= 1024 and K >= 2048:
-        return 11                     # 256x128 tiles: long contraction, narrow output
-    if N >= 2048:
-        return 10                     # 128x128 single buffer, up to 4 workgroups per CU (epilogue-heavy wide outputs)
-    return 9
+    if N <= 1024:
+        return 27                     # 256x128 tiles, 3-stage ring: narrow outputs (252 workgroups at M = 10 688, N = 768)
+    return 29                         # 256x256 tiles, 2-stage ring
 
 
 def tn_heuristic(M, N, K):
