@@ -109,6 +109,10 @@ typedef struct {
 } vlp_gemm_tn_args;
 int64_t vlp_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K);
 int vlp_gemm_tn(const vlp_gemm_tn_args* a, void* stream);
+/* Several weight gradients in ONE launch (1..8 problems; the four Linears of a BertLayer: modeling.py:270-272, 314, 341, 354).
+ * Every 128x128 output tile of every problem is one workgroup that walks that problem's WHOLE contraction: no split-M slabs, no
+ * reduce launches (`workspace`, `splits`, `variant` of the entries are ignored); `beta` and `bias_out` as in vlp_gemm_tn. */
+int vlp_gemm_tn_grouped(const vlp_gemm_tn_args* list, int32_t count, void* stream);
 
 /* out[n] (+)= sum_m A[m,n]  -- bias gradients (autograd SumBackward of the broadcast bias add). */
 typedef struct {

@@ -242,7 +242,48 @@ def K_ws(M, N, Kd):
     return K.gemm_tn_workspace_bytes(M, N, Kd)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+def test_gemm_tn_grouped(gen):
+    """vlp_gemm_tn_grouped: several wgrads in one grid, every workgroup walking its problem's whole contraction (no split-M slabs).
+    Shapes: ragged N / K / M (tile tails, zero-filled last stage), beta = 0 and 1, fused bias gradients, a problem without bias;
+    repeated launches are bit-identical and equal to the single-problem kernel with splits = 1 (same accumulation order)."""
+    shapes = [(1000, 256, 384), (1000, 768, 768), (777, 72, 64), (1000, 1000, 128), (2048 + 37, 2304, 768)]
+    probs, refs, cs = [], [], []
+    for i, (M, N, Kd) in enumerate(shapes):
+        a, b = h16(M, (N + 7) // 8 * 8, scale=0.3, gen=gen), h16(M, Kd, scale=0.3, gen=gen)
+        c = h16(N, Kd, gen=gen)
+        bias = h16(N, gen=gen) if i != 2 else None
+        probs.append([a, b, c, M, N, Kd, 0, bias])
+        refs.append(a[:, :N].float().t() @ b.float())
+        cs.append(a[:, :N].float().sum(0))
+    K.gemm_tn_grouped([tuple(q) for q in probs])
+    first = [q[2].clone() for q in probs]
+    for q, ref, col in zip(probs, refs, cs):
+        assert rel(q[2].float(), ref) < 1.5e-3
+        if q[7] is not None:
+            assert float((q[7].float() - col).abs().max()) < 2e-3 * float(col.abs().max()) + 1e-2
+    # single-problem kernel, no split: identical bits
+    for q, f in zip(probs, first):
+        a, b, c, M, N, Kd, _, _ = q
+        c1 = torch.empty_like(c)
+        ws = torch.empty(K_ws(M, N, Kd), device=DEV, dtype=torch.uint8)
+        K.gemm_tn(a, b, c1, M, N, Kd, beta=0, workspace=ws, variant=2, splits=1)
+        assert torch.equal(c1, f)
+    # beta = 1 accumulates (weights and biases); run twice from the same start -> same bits
+    outs = []
+    for rep in range(2):
+        for q, f in zip(probs, first):
+            q[2].copy_(f)
+            q[6] = 1
+        K.gemm_tn_grouped([tuple(q) for q in probs])
+        outs.append([q[2].clone() for q in probs])
+    for x, y, ref in zip(outs[0], outs[1], refs):
+        assert torch.equal(x, y)
+        assert rel(x.float(), 2 * ref) < 2.5e-3
+    with pytest.raises(RuntimeError, match="1..8"):
+        K.gemm_tn_grouped([tuple(probs[0])] * 9)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_gemm_tn_asymmetric(variant):
     """dY = I-like selector against an asymmetric X: dW[n,k] must equal X[n,k] for n < M."""
     M, N, Kd = 128, 128, 128

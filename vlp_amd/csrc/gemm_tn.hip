@@ -213,11 +213,10 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(GemmTnParams p) 
 // =================================================================================================
 DEVFN int tn_swz(int r) { return ((r & 3) | (((r >> 3) & 1) << 2)) << 1; }
 
-// BN_T x BK_T output tile (each 128 or 256); one wave per 64x64 sub-tile -> 4, 8 or 16 waves.
+// BN_T x BK_T output tile (each 128 or 256); one wave per 64x64 sub-tile -> 4 or 8 waves.  `bid` = linear tile index of this workgroup
+// inside the problem p (after any XCD remap): shared by the single-problem kernel and the grouped launch below.
 template <int BN_T, int BK_T>
-__global__ __launch_bounds__((BN_T / 64) * (BK_T / 64) * 64, ((BN_T / 64) * (BK_T / 64) >= 16 ? 4 : 2)) void gemm_tn_glds_kernel(GemmTnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    f16* smem = reinterpret_cast<f16*>(smem_raw);
+DEVFN void tn_glds_tile(const GemmTnParams& p, int bid, f16* smem) {
     constexpr int WK_ = BK_T / 64;
     constexpr int T = (BN_T / 64) * WK_ * 64;            // threads
     constexpr int ATILE = TN_BM * BN_T, BTILE = TN_BM * BK_T;   // halfs
@@ -230,11 +229,6 @@ __global__ __launch_bounds__((BN_T / 64) * (BK_T / 64) * 64, ((BN_T / 64) * (BK_
     const int wn = wid / WK_, wk = wid % WK_;
     const int g = lane >> 4, li = lane & 15;
 
-    int bid = blockIdx.x;
-    if (p.xcd_remap) {
-        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
     int split, ktile, ntile;
     if (p.split_major) {
         ktile = bid % p.tiles_k;
@@ -371,6 +365,55 @@ __global__ __launch_bounds__((BN_T / 64) * (BK_T / 64) * 64, ((BN_T / 64) * (BK_
     }
 }
 
+DEVFN int tn_xcd_remap(int bid, int nb) {      // bijective for any grid size: XCD x owns (q+1) tiles if x < r else q
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+template <int BN_T, int BK_T>
+__global__ __launch_bounds__((BN_T / 64) * (BK_T / 64) * 64, 2) void gemm_tn_glds_kernel(GemmTnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    int bid = blockIdx.x;
+    if (p.xcd_remap) bid = tn_xcd_remap(bid, gridDim.x);
+    tn_glds_tile<BN_T, BK_T>(p, bid, reinterpret_cast<f16*>(smem_raw));
+}
+
+// -------------------------------------------------------------------------------------------------
+// Grouped launch: the weight gradients of several Linears in ONE grid (the four of a BertLayer: 36 + 108 + 144 + 144 = 432
+// tiles of 128x128).  A single wgrad has too few output tiles for 256 CUs, which is what forced the split-M form above (fp32 slabs:
+// 28 MB written + read per FFN wgrad, plus a reduce launch each); together they fill the chip with every workgroup walking the
+// WHOLE contraction (M = 10 688 rows): no slabs, no reduce kernels, one fp32 accumulation chain per output element.
+// -------------------------------------------------------------------------------------------------
+#define TN_GROUP_MAX 8
+struct TnGroupEntry {
+    const f16* A; int64_t lda;
+    const f16* B; int64_t ldb;
+    f16* C; int64_t ldc;
+    f16* bias_out;
+    int M, N, K, beta, tiles_k, tile_begin;
+};
+struct TnGroupParams {
+    TnGroupEntry e[TN_GROUP_MAX];
+    int count, total_tiles, xcd_remap;
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(TnGroupParams gp) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    int bid = blockIdx.x;
+    if (gp.xcd_remap) bid = tn_xcd_remap(bid, gridDim.x);
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < TN_GROUP_MAX; ++i)
+        if (i < gp.count && bid >= gp.e[i].tile_begin) j = i;
+    const TnGroupEntry& e = gp.e[j];
+    GemmTnParams p;
+    p.A = e.A; p.lda = e.lda; p.B = e.B; p.ldb = e.ldb; p.C = e.C; p.ldc = e.ldc;
+    p.slab = nullptr; p.bias_slab = nullptr; p.bias_out = e.bias_out;
+    p.M = e.M; p.N = e.N; p.K = e.K; p.beta = e.beta; p.splits = 1; p.rows_per_split = (e.M + TN_BM - 1) / TN_BM * TN_BM;
+    p.tiles_k = e.tiles_k; p.tiles_n = 0; p.xcd_remap = 0; p.split_major = 0;
+    tn_glds_tile<128, 128>(p, bid - e.tile_begin, reinterpret_cast<f16*>(smem_raw));
+}
+
 // out[n,k] = (beta ? out : 0) + sum_s slab[s][n][k]; the tail of the grid reduces the fused bias partials [s][N]
 __global__ void gemm_tn_reduce_kernel(const float* slab, f16* C, int64_t ldc, int N, int K, int splits, int beta,
                                       const float* bias_slab, f16* bias_out, int main_blocks) {
@@ -496,5 +539,42 @@ extern "C" int vlp_gemm_tn(const vlp_gemm_tn_args* a, void* stream) {
                            p.bias_slab, p.bias_out, blocks);
         VLP_CHECK_LAUNCH("vlp_gemm_tn_reduce");
     }
+    return VLP_OK;
+}
+
+static int tn_check_one(const vlp_gemm_tn_args* a) {
+    VLP_CHECK_ARG(a->A && a->B && a->C, "vlp_gemm_tn: null operand");
+    VLP_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "vlp_gemm_tn: bad shape");
+    VLP_CHECK_ARG(a->K % 8 == 0, "vlp_gemm_tn: K=%d must be a multiple of 8", a->K);
+    VLP_CHECK_ARG(a->lda % 8 == 0 && a->ldb % 8 == 0 && a->ldc % 8 == 0, "vlp_gemm_tn: leading dims must be multiples of 8");
+    VLP_CHECK_ARG(a->lda >= (a->N + 7) / 8 * 8 && a->ldb >= a->K && a->ldc >= a->K, "vlp_gemm_tn: leading dim too small");
+    VLP_CHECK_ARG(((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) % 16 == 0, "vlp_gemm_tn: operands must be 16-byte aligned");
+    VLP_CHECK_ARG(a->beta == 0 || a->beta == 1, "vlp_gemm_tn: beta must be 0 or 1");
+    return VLP_OK;
+}
+
+extern "C" int vlp_gemm_tn_grouped(const vlp_gemm_tn_args* list, int32_t count, void* stream) {
+    VLP_CHECK_ARG(list != nullptr && count >= 1 && count <= TN_GROUP_MAX, "vlp_gemm_tn_grouped: 1..%d problems", TN_GROUP_MAX);
+    TnGroupParams gp;
+    int tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        const vlp_gemm_tn_args* a = list + i;
+        const int rc = tn_check_one(a);
+        if (rc != VLP_OK) return rc;
+        TnGroupEntry& e = gp.e[i];
+        e.A = (const f16*)a->A; e.lda = a->lda; e.B = (const f16*)a->B; e.ldb = a->ldb; e.C = (f16*)a->C; e.ldc = a->ldc;
+        e.bias_out = (f16*)a->bias_out;
+        e.M = a->M; e.N = a->N; e.K = a->K; e.beta = a->beta;
+        e.tiles_k = cdiv(a->K, 128);
+        e.tile_begin = tiles;
+        tiles += e.tiles_k * cdiv(a->N, 128);
+    }
+    for (int i = count; i < TN_GROUP_MAX; ++i) { gp.e[i] = gp.e[0]; gp.e[i].tile_begin = 0x7fffffff; }
+    gp.count = count; gp.total_tiles = tiles; gp.xcd_remap = 1;
+    const size_t smem = (size_t)2 * TN_BM * (128 + 128) * sizeof(f16);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(tiles), dim3(256), smem, (hipStream_t)stream, gp);
+    VLP_CHECK_LAUNCH("vlp_gemm_tn_grouped");
     return VLP_OK;
 }

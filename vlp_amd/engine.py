@@ -56,6 +56,7 @@ class Engine(object):
     # single-kernel timings under rocprofv3).  bench.py's live roofline samples stay single-kernel measurements: a sampled launch
     # first lets the side stream drain (see _nt).
     WGRAD_SIDE_STREAM = os.environ.get("VLP_WGRAD_SIDE_STREAM", "1") == "1"
+    GROUPED_WGRAD = os.environ.get("VLP_GROUPED_WGRAD", "1") == "1"     # one vlp_gemm_tn_grouped launch per layer instead of 4 split-M wgrads + 4 reduces
     TN_SPLITS = None         # None -> vlp_amd.tuning (variant flags, split-M factor) per (M, N, K)
     # split-M factor: the wgrad outputs are small (36..144 tiles of 128x128) and the contraction long (M = 10 688), so the
     # workgroup count tiles*splits has to land just under a multiple of the 256 CUs x 2 resident workgroups: 3 (432 workgroups)
@@ -966,6 +967,7 @@ class Engine(object):
         if use_side:
             side.wait_stream(main)          # head wgrads above ran on main; order the side stream after them (tn_ws reuse)
             self._side_busy = True
+        grouped = self.GROUPED_WGRAD and M >= 2048       # enough rows for a long contraction per workgroup; tiny batches keep split-M
         for i in reversed(range(NL)):
             Ln = "bert.encoder.layer.%d." % i
             a = ws["layers"][i]
@@ -980,11 +982,13 @@ class Engine(object):
                             self.G(Ln + "output.LayerNorm.weight"), self.G(Ln + "output.LayerNorm.bias"), M, H, ws["ln_ws"], beta=beta,
                             dx_drop=ds["dpre2_d"] if p > 0 else None, out_drop=(p, seed, 16 * i + 3))
             dy2 = ds["dpre2_d"] if p > 0 else dpre
-            on_side(lambda: self._tn(dy2, a["g"], self.G(Ln + "output.dense.weight"), M, H, I, ws, beta, bias=self.G(Ln + "output.dense.bias")))
+            if not grouped:
+                on_side(lambda: self._tn(dy2, a["g"], self.G(Ln + "output.dense.weight"), M, H, I, ws, beta, bias=self.G(Ln + "output.dense.bias")))
             self._nt(dy2, s["w2T"], ds["dz"], M, I, H, mul_src=a["z"], mul_mode=K.MUL_PLAIN)      # dG * gelu'(z) (stored by the forward)
             # BertIntermediate (modeling.py:340-343)
-            on_side(lambda: self._tn(ds["dz"], a["x1"], self.G(Ln + "intermediate.dense.weight"), M, I, H, ws, beta,
-                                     bias=self.G(Ln + "intermediate.dense.bias")))
+            if not grouped:
+                on_side(lambda: self._tn(ds["dz"], a["x1"], self.G(Ln + "intermediate.dense.weight"), M, I, H, ws, beta,
+                                         bias=self.G(Ln + "intermediate.dense.bias")))
             self._nt(ds["dz"], s["w1T"], dx, M, H, I, residual=dpre)                            # + residual path of LN2's input
             # BertSelfOutput: LN(dropout(dense(ctx)) + x)   (modeling.py:313-317)
             dpre = ds["dpre1"]
@@ -992,16 +996,26 @@ class Engine(object):
                             self.G(Ln + "attention.output.LayerNorm.weight"), self.G(Ln + "attention.output.LayerNorm.bias"), M, H, ws["ln_ws"],
                             beta=beta, dx_drop=ds["dpre1_d"] if p > 0 else None, out_drop=(p, seed, 16 * i + 2))
             dy1 = ds["dpre1_d"] if p > 0 else dpre
-            on_side(lambda: self._tn(dy1, a["ctx"], self.G(Ln + "attention.output.dense.weight"), M, H, H, ws, beta,
-                                     bias=self.G(Ln + "attention.output.dense.bias")))
+            if not grouped:
+                on_side(lambda: self._tn(dy1, a["ctx"], self.G(Ln + "attention.output.dense.weight"), M, H, H, ws, beta,
+                                         bias=self.G(Ln + "attention.output.dense.bias")))
             self._nt(dy1, s["oT"], dctx, M, H, H)
             # BertSelfAttention (modeling.py:268-303)
             dqkv = ds["dqkv"]
             K.attn_bwd(a["qkv"], ws["maskb"], ws["maskt"], a["ctx"], dctx, a["lse"], dqkv, ws["delta"], B, L, A, scale, dropout_p=pa, seed=seed, rng_stream=16 * i + 1)
 
             def last_wgrad():
-                self._tn(dqkv, x_in, self.G(Ln + "attention.self.query.weight"), M, 3 * H, H, ws, beta,
-                         bias=self.G(Ln + "attention.self.query.bias"))     # packed [3H, H] gradient
+                if grouped:
+                    # the layer's four weight gradients (+ bias gradients) as ONE grid of 36 + 108 + 144 + 144 output tiles, every
+                    # workgroup walking the whole contraction: no split-M slabs, no reduce launches (csrc/gemm_tn.hip)
+                    K.gemm_tn_grouped([
+                        (dy2, a["g"], self.G(Ln + "output.dense.weight"), M, H, I, beta, self.G(Ln + "output.dense.bias")),
+                        (ds["dz"], a["x1"], self.G(Ln + "intermediate.dense.weight"), M, I, H, beta, self.G(Ln + "intermediate.dense.bias")),
+                        (dqkv, x_in, self.G(Ln + "attention.self.query.weight"), M, 3 * H, H, beta, self.G(Ln + "attention.self.query.bias")),
+                        (dy1, a["ctx"], self.G(Ln + "attention.output.dense.weight"), M, H, H, beta, self.G(Ln + "attention.output.dense.bias"))])
+                else:
+                    self._tn(dqkv, x_in, self.G(Ln + "attention.self.query.weight"), M, 3 * H, H, ws, beta,
+                             bias=self.G(Ln + "attention.self.query.bias"))     # packed [3H, H] gradient
                 self._bucket_done(NL - i)          # the layer's gradient slice is complete in this stream's order
                 if use_side:
                     ev = torch.cuda.Event()

@@ -99,10 +99,23 @@ def skinny_heuristic(M, N, K):
     return ("s", best)
 
 
+def _nt_overrides():
+    """VLP_NT_OVERRIDE="M,N,K=variant;M,N,K=variant" -- per-shape A/B runs inside the real step (same box, same process layout)."""
+    out = {}
+    for item in os.environ.get("VLP_NT_OVERRIDE", "").split(";"):
+        if "=" in item:
+            k, v = item.split("=")
+            out[tuple(int(x) for x in k.split(","))] = int(v)
+    return out
+
+
 def nt_variant(M, N, K):
     env = os.environ.get("VLP_NT_VARIANT")
     if env:
         return int(env)
+    ov = _nt_overrides().get((M, N, K))
+    if ov is not None:
+        return ov
     v = lookup("nt", M, N, K)
     return int(v) if v is not None else nt_heuristic(M, N, K)
 
