@@ -97,19 +97,19 @@ DEVFN void drop_mult8(const DropCtx& d, uint32_t rowkey, uint32_t col0, float* v
 // one v_rcp + one v_exp instead of the ~40-instruction libm erff in the GEMM epilogues.
 DEVFN float fast_erf(float x) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));     // v_rcp_f32 (1 ulp); __frcp_rn expands to the 10-instruction IEEE division
     float poly = fmaf(1.061405429f, t, -1.453152027f);
     poly = fmaf(poly, t, 1.421413741f);
     poly = fmaf(poly, t, -0.284496736f);
     poly = fmaf(poly, t, 0.254829592f);
-    const float r = 1.0f - poly * t * __expf(-ax * ax);
+    const float r = 1.0f - poly * t * __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);      // one v_exp_f32 (argument <= 0: no range fix-ups)
     return copysignf(r, x);
 }
 DEVFN float gelu_f(float x) { return x * 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f)); }   // modeling.py:62-67
 DEVFN float gelu_grad_f(float x) {
     // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
     float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f));
-    float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.5f * 1.4426950408889634f * x * x);
     return cdf + x * pdf;
 }
 
@@ -118,12 +118,12 @@ DEVFN float gelu_grad_f(float x) {
 // stored number instead of re-evaluating erf + exp per element (the backward epilogue was VALU-bound: +22 us per launch).
 DEVFN void gelu_and_grad_f(float x, float& gl, float& gp) {
     const float ax = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
     float poly = fmaf(1.061405429f, t, -1.453152027f);
     poly = fmaf(poly, t, 1.421413741f);
     poly = fmaf(poly, t, -0.284496736f);
     poly = fmaf(poly, t, 0.254829592f);
-    const float e = __expf(-ax * ax);                       // exp(-x^2 / 2)
+    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);      // exp(-x^2 / 2): one v_exp_f32, no range fix-ups (argument <= 0)
     const float cdf = 0.5f * (1.0f + copysignf(1.0f - poly * t * e, x));
     gl = x * cdf;
     gp = fmaf(x * 0.39894228040143267794f, e, cdf);

@@ -25,9 +25,13 @@ DEVFN void nt_epilogue8(const GemmNtParams& p, int m, int nc, float* vv, uint32_
         for (int j = 0; j < 8; ++j) {
             float gl, gp;
             gelu_and_grad_f((float)(f16)vv[j], gl, gp);
-            const bool in = nc + j < p.N;
-            o[j] = in ? (f16)gl : (f16)0.f;
-            d[j] = in ? (f16)gp : (f16)0.f;
+            o[j] = (f16)gl;
+            d[j] = (f16)gp;
+        }
+        if ((p.N & 7) && nc + 8 > p.N) {        // ragged last vector of a row (scalar test first: N % 8 == 0 skips it): zero the pad columns
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (nc + j >= p.N) { o[j] = (f16)0.f; d[j] = (f16)0.f; }
         }
         st8(p.preact + (int64_t)m * p.ldp + nc, d);
         st8(p.Y + (int64_t)m * p.ldy + nc, o);

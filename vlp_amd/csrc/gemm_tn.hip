@@ -326,15 +326,16 @@ DEVFN void tn_glds_tile(const GemmTnParams& p, int bid, f16* smem) {
     };
 
     if (nstages > 0) {
+        // two LDS stages as a ring: wait for stage st (DMA: vmcnt; the ragged tail's ds_writes: lgkmcnt), ONE raw barrier -- every wave's
+        // pieces have landed and every wave is done with the fragment reads of stage st-1 -- then refill that buffer with stage st+1
+        // right behind the barrier and compute stage st while it streams in (the form that won on the NT side: gemm_nt.hip ring)
         stage(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
         for (int st = 0; st < nstages; ++st) {
             const int buf = st & 1;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             if (st + 1 < nstages) stage(st + 1, buf ^ 1);
             compute(buf);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
         }
     }
 
