@@ -217,9 +217,15 @@ typedef struct {
     float dy_drop_p; uint64_t dy_seed; uint32_t dy_stream;
     float out_drop_p; uint64_t out_seed; uint32_t out_stream;
     void* workspace; int64_t workspace_bytes;   /* vlp_layernorm_bwd_workspace_bytes(H) */
+    int32_t defer_reduce;                /* 1: leave the per-block dgamma/dbeta partials in `workspace` and do NOT touch dgamma/dbeta;
+                                            the caller reduces many LayerNorms at once with vlp_layernorm_bwd_reduce_batched */
 } vlp_layernorm_bwd_args;
 int64_t vlp_layernorm_bwd_workspace_bytes(int32_t H);
 int vlp_layernorm_bwd(const vlp_layernorm_bwd_args* a, void* stream);
+/* Second stage of `count` deferred vlp_layernorm_bwd calls in ONE launch (the 25 LayerNorms of a 12-layer step otherwise cost 25
+ * tiny reduce launches): slot i of `parts` (stride = vlp_layernorm_bwd_workspace_bytes(H) / 4 floats) holds the partials of
+ * LayerNorm i (all with the same M, H); dst[2*i] / dst[2*i+1] (device array of pointers) are its dgamma / dbeta ([H] fp16). */
+int vlp_layernorm_bwd_reduce_batched(const float* parts, const void* const* dst, int32_t count, int32_t M, int32_t H, int32_t beta, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Embedding splice (modeling.py:217-236): pre[b,l,:] = word(l) + pos(l) + type[seg[b,l]] where for

@@ -415,6 +415,38 @@ def test_layernorm_fwd_bwd(M, H, gen):
     assert rel(dg.float(), 2 * g64.grad) < 4e-3
 
 
+@pytest.mark.parametrize("M,H", [(1000, 768), (37, 768), (4000, 1024)])
+def test_layernorm_bwd_deferred_batched_reduce(M, H, gen):
+    """defer_reduce leaves dgamma / dbeta untouched and the per-block partials in the caller's slot; ONE batched launch then writes
+    every LayerNorm's dgamma / dbeta -- bit-identical to the immediate second stage (same summation order), beta = 0 and 1."""
+    n = 3
+    slot = K.layernorm_bwd_workspace_bytes(H)
+    slots = torch.empty(n * slot, device=DEV, dtype=torch.uint8)
+    ws = torch.empty(slot, device=DEV, dtype=torch.uint8)
+    want, dst, keep = [], [], []
+    for i in range(n):
+        x, gamma = h16(M, H, scale=2.0, gen=gen), (1 + 0.1 * torch.randn(H, device=DEV, generator=gen)).half()
+        y = torch.empty_like(x)
+        mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+        K.layernorm_fwd(x, gamma, torch.zeros(H, device=DEV).half(), y, M, H, mean, rstd)
+        dy = h16(M, H, gen=gen)
+        dx0, dx1 = torch.empty_like(x), torch.empty_like(x)
+        g0, b0 = h16(H, gen=gen), h16(H, gen=gen)                 # pre-existing gradient content (beta = 1 accumulates onto it)
+        g1, b1 = g0.clone(), b0.clone()
+        for beta, gg, bb in ((1, g0, b0),):
+            K.layernorm_bwd(dy, x, gamma, mean, rstd, dx0, gg, bb, M, H, ws, beta=beta)
+        K.layernorm_bwd(dy, x, gamma, mean, rstd, dx1, g1, b1, M, H, slots[i * slot:(i + 1) * slot], beta=1, defer_reduce=True)
+        assert torch.equal(dx0, dx1)
+        assert not torch.equal(g1, g0)                            # untouched so far
+        want.append((g0, b0))
+        dst.append([g1.data_ptr(), b1.data_ptr()])
+        keep.append((g1, b1))
+    table = torch.tensor(dst, dtype=torch.int64, device=DEV)
+    K.layernorm_bwd_reduce_batched(slots, table, n, M, H, beta=1)
+    for (g0, b0), (g1, b1) in zip(want, keep):
+        assert torch.equal(g0, g1) and torch.equal(b0, b1)
+
+
 def test_layernorm_dropout_paths(gen):
     M, H, p = 257, 768, 0.2
     x, gamma, beta = h16(M, H, gen=gen), torch.ones(H, device=DEV).half(), torch.zeros(H, device=DEV).half()

@@ -63,7 +63,7 @@ class LayerNormBwdArgs(C.Structure):
                 ("M", i32), ("H", i32), ("beta", i32),
                 ("dy_drop_p", f32), ("dy_seed", u64), ("dy_stream", u32),
                 ("out_drop_p", f32), ("out_seed", u64), ("out_stream", u32),
-                ("workspace", vp), ("workspace_bytes", i64)]
+                ("workspace", vp), ("workspace_bytes", i64), ("defer_reduce", i32)]
 
 
 class EmbedFwdArgs(C.Structure):
@@ -152,6 +152,7 @@ SYMBOLS = {
     "vlp_layernorm_fwd": (C.c_int, [C.POINTER(LayerNormFwdArgs), vp]),
     "vlp_layernorm_bwd_workspace_bytes": (i64, [i32]),
     "vlp_layernorm_bwd": (C.c_int, [C.POINTER(LayerNormBwdArgs), vp]),
+    "vlp_layernorm_bwd_reduce_batched": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "vlp_embed_fwd": (C.c_int, [C.POINTER(EmbedFwdArgs), vp]),
     "vlp_embed_bwd": (C.c_int, [C.POINTER(EmbedBwdArgs), vp]),
     "vlp_copy2d": (C.c_int, [vp, i64, i32, vp, i64, i32, i32, i32, i32, vp]),
@@ -427,13 +428,21 @@ def layernorm_bwd_workspace_bytes(H):
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M, H, workspace, beta=0, dx_drop=None,
-                  dy_drop=(0.0, 0, 0), out_drop=(0.0, 0, 0)):
+                  dy_drop=(0.0, 0, 0), out_drop=(0.0, 0, 0), defer_reduce=False):
+    """defer_reduce: leave the dgamma / dbeta partials in `workspace` (one private slot per LayerNorm) for layernorm_bwd_reduce_batched."""
     _req_cuda(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace)
     a = LayerNormBwdArgs(ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), dx.stride(0),
                          ptr(dx_drop), dx_drop.stride(0) if dx_drop is not None else 0, ptr(dgamma), ptr(dbeta), M, H, beta,
                          dy_drop[0], dy_drop[1], dy_drop[2], out_drop[0], out_drop[1], out_drop[2],
-                         ptr(workspace), workspace.numel() * workspace.element_size())
+                         ptr(workspace), workspace.numel() * workspace.element_size(), 1 if defer_reduce else 0)
     _check(load().vlp_layernorm_bwd(C.byref(a), stream_ptr()))
+
+
+def layernorm_bwd_reduce_batched(parts, dst_table, count, M, H, beta=0):
+    """parts: uint8/float32 buffer of `count` slots of layernorm_bwd_workspace_bytes(H); dst_table: int64 device tensor [count, 2] of
+    dgamma / dbeta addresses."""
+    _req_cuda(parts, dst_table)
+    _check(load().vlp_layernorm_bwd_reduce_batched(ptr(parts), ptr(dst_table), count, M, H, beta, stream_ptr()))
 
 
 def embed_fwd(input_ids, segment_ids, word_emb, pos_emb, type_emb, vis_h, vispe_h, pre, B, L, Nv, H, position_ids=None):

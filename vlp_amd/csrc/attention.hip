@@ -19,6 +19,7 @@
 // With the (r & 7) chunk swizzle both access patterns are bank-conflict free: ds_read_b128 row fragments
 // (16 rows x one chunk) and transpose reads (8 rows x 32 contiguous bytes per half-wave).
 #include "common.h"
+#include <stdlib.h>
 
 #define HD 64            // head dim
 #define ATT_THREADS 256         // dQ kernel (240 VGPRs: 2 workgroups of 4 waves per CU)
@@ -108,8 +109,11 @@ DEVFN void mask4w(uint32_t w, bool full, float c0, float out[4]) {
 // =================================================================================================
 // forward
 // =================================================================================================
-template <int NT>   // NT = LP / 16 key tiles (4, 8, 12 or 16)
-__global__ __launch_bounds__(ATT_THREADS8, NT <= 12 ? 4 : 2) void attn_fwd_kernel(AttnParams p) {   // (threads, min waves per SIMD)
+// NW = waves per workgroup.  8 for most shapes; 4 at NT = 12 (129 <= L <= 192, the training shape L = 167): B x heads = 768 workgroups
+// on 256 CUs is 1.5 rounds of the 2 x 8-wave workgroups a CU holds -- with 4-wave workgroups three fit (3 x 48 KB LDS, 12 waves), all 768
+// are resident at once, and the 11 query tiles of L = 167 spread over 4 waves (3 passes, 92 % busy) instead of 8 (2 passes, 69 %).
+template <int NT, int NW>   // NT = LP / 16 key tiles (4, 8, 12 or 16)
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void attn_fwd_kernel(AttnParams p) {   // (threads, min waves per SIMD)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int LP = NT * 16;
     f16* Ks = reinterpret_cast<f16*>(smem_raw);            // [LP][64] swizzled
@@ -126,12 +130,12 @@ __global__ __launch_bounds__(ATT_THREADS8, NT <= 12 ? 4 : 2) void attn_fwd_kerne
 
     const f16* kpre = p.n_prefix ? p.k2 + (int64_t)(b / p.beams) * p.bs_kv2 * p.ld_kv + h * HD : nullptr;
     const f16* vpre = p.n_prefix ? p.v2 + (int64_t)(b / p.beams) * p.bs_kv2 * p.ld_kv + h * HD : nullptr;
-    stage_rowmajor(Ks, kbase, p.ld_kv, L, LP, tid, ATT_THREADS8, kpre, p.n_prefix);
-    stage_rowmajor(Vs, vbase, p.ld_kv, L, LP, tid, ATT_THREADS8, vpre, p.n_prefix);
+    stage_rowmajor(Ks, kbase, p.ld_kv, L, LP, tid, NW * 64, kpre, p.n_prefix);
+    stage_rowmajor(Vs, vbase, p.ld_kv, L, LP, tid, NW * 64, vpre, p.n_prefix);
     __syncthreads();
 
     const int nqt = (Lq + 15) / 16;
-    for (int qt = wid; qt < nqt; qt += ATT_WAVES8) {
+    for (int qt = wid; qt < nqt; qt += NW) {
         const int q = qt * 16 + li;             // this lane's query (column of every transposed tile)
         const int qc = min(q, Lq - 1);
         int gq = g;                             // opaque copy: keeps per-key index math inside the loop (no LICM + spills)
@@ -336,8 +340,8 @@ __global__ __launch_bounds__(ATT_THREADS, NT <= 12 ? 2 : 1) void attn_bwd_dq_ker
 // The byte mask is read from its key-major copy so that a lane fetches 4 queries of its key with one dword load; all
 // loads of a key tile are issued before its query loop.
 // =================================================================================================
-template <int NT>
-__global__ __launch_bounds__(ATT_THREADS8, NT >= 8 ? 4 : 2) void attn_bwd_dkv_kernel(AttnParams p) {   // NT = 4: the fully unrolled pair loop needs 130 VGPRs
+template <int NT, int NW>     // NW: as in the forward (4 waves at NT = 12: three workgroups per CU, 11 key tiles over 4 waves)
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT >= 8 ? 4 : 2)) void attn_bwd_dkv_kernel(AttnParams p) {   // NT = 4: the fully unrolled pair loop needs 130 VGPRs
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int LP = NT * 16;
     f16* Qs = reinterpret_cast<f16*>(smem_raw);     // [LP][64] swizzled
@@ -355,9 +359,9 @@ __global__ __launch_bounds__(ATT_THREADS8, NT >= 8 ? 4 : 2) void attn_bwd_dkv_ke
     const f16* vbase = qbase + 2 * p.H;
     const f16* dobase = p.dctx + (int64_t)b * L * p.ld_dctx + h * HD;
 
-    stage_rowmajor(Qs, qbase, p.ld_qkv, L, LP, tid, ATT_THREADS8);
-    stage_rowmajor(dOs, dobase, p.ld_dctx, L, LP, tid, ATT_THREADS8);
-    for (int i = tid; i < LP; i += ATT_THREADS8) {
+    stage_rowmajor(Qs, qbase, p.ld_qkv, L, LP, tid, NW * 64);
+    stage_rowmajor(dOs, dobase, p.ld_dctx, L, LP, tid, NW * 64);
+    for (int i = tid; i < LP; i += NW * 64) {
         const int64_t stat = ((int64_t)b * p.heads + h) * L + min(i, L - 1);
         lse_s[i] = p.lse[stat] * LOG2E_F;
         dl_s[i] = p.delta[stat];
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(ATT_THREADS8, NT >= 8 ? 4 : 2) void attn_bwd_dkv_ke
     __syncthreads();
 
     const int nkt = (L + 15) / 16;
-    for (int kt = wid; kt < nkt; kt += ATT_WAVES8) {
+    for (int kt = wid; kt < nkt; kt += NW) {
         const int key = kt * 16 + li;            // this lane's key (column)
         const int kc = min(key, L - 1);
         f16x8 kf[2], vf[2];
@@ -457,17 +461,26 @@ static int attn_common_check(const char* who, const void* qkv, int64_t ld_qkv, c
 
 static inline int lp_of(int L) { return L <= 64 ? 64 : (L <= 128 ? 128 : (L <= 192 ? 192 : 256)); }
 
+// waves per workgroup of the forward / dK-dV kernels at NT = 12 (VLP_ATTN_WAVES=8 restores the round-1 geometry for A/B runs)
+static int attn_waves_nt12() {
+    const char* e = getenv("VLP_ATTN_WAVES");
+    return (e && atoi(e) == 8) ? 8 : 4;
+}
+
 static int launch_attn_fwd(AttnParams& p, hipStream_t s) {
     const int LP = lp_of(p.Lk);
     const size_t smem = (size_t)2 * LP * HD * 2;
-    dim3 grid(p.B * p.heads), block(ATT_THREADS8);
-#define LAUNCH_FWD(NT_)                                                                                              \
+    dim3 grid(p.B * p.heads);
+    static const int nw12 = attn_waves_nt12();
+#define LAUNCH_FWD(NT_, NW_)                                                                                         \
     do {                                                                                                             \
         static bool attr = false;                                                                                    \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; } \
-        hipLaunchKernelGGL(attn_fwd_kernel<NT_>, grid, block, smem, s, p);                                           \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NT_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; } \
+        hipLaunchKernelGGL((attn_fwd_kernel<NT_, NW_>), grid, dim3((NW_) * 64), smem, s, p);                           \
     } while (0)
-    if (LP == 64) LAUNCH_FWD(4); else if (LP == 128) LAUNCH_FWD(8); else if (LP == 192) LAUNCH_FWD(12); else LAUNCH_FWD(16);
+    if (LP == 64) LAUNCH_FWD(4, 8); else if (LP == 128) LAUNCH_FWD(8, 8);
+    else if (LP == 192) { if (nw12 == 4) LAUNCH_FWD(12, 4); else LAUNCH_FWD(12, 8); }
+    else LAUNCH_FWD(16, 8);
 #undef LAUNCH_FWD
     VLP_CHECK_LAUNCH("vlp_attn_fwd");
     return VLP_OK;
@@ -539,18 +552,21 @@ extern "C" int vlp_attn_bwd(const vlp_attn_bwd_args* a, void* stream) {
     const size_t smem_dkv = (size_t)2 * LP * HD * 2 + (size_t)3 * LP * 4;
     dim3 grid(a->B * a->heads), block(ATT_THREADS);
     hipStream_t s = (hipStream_t)stream;
-#define LAUNCH_BWD(NT_)                                                                                              \
+    static const int nw12 = attn_waves_nt12();
+#define LAUNCH_BWD(NT_, NW_)                                                                                         \
     do {                                                                                                             \
         static bool attr = false;                                                                                    \
         if (!attr) {                                                                                                 \
             hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dq);   \
-            hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dkv); \
+            hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<NT_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dkv); \
             attr = true;                                                                                             \
         }                                                                                                            \
         hipLaunchKernelGGL(attn_bwd_dq_kernel<NT_>, grid, block, smem_dq, s, p);                                     \
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<NT_>, grid, dim3(ATT_THREADS8), smem_dkv, s, p);                                   \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<NT_, NW_>), grid, dim3((NW_) * 64), smem_dkv, s, p);                   \
     } while (0)
-    if (LP == 64) LAUNCH_BWD(4); else if (LP == 128) LAUNCH_BWD(8); else if (LP == 192) LAUNCH_BWD(12); else LAUNCH_BWD(16);
+    if (LP == 64) LAUNCH_BWD(4, 8); else if (LP == 128) LAUNCH_BWD(8, 8);
+    else if (LP == 192) { if (nw12 == 4) LAUNCH_BWD(12, 4); else LAUNCH_BWD(12, 8); }
+    else LAUNCH_BWD(16, 8);
 #undef LAUNCH_BWD
     VLP_CHECK_LAUNCH("vlp_attn_bwd");
     return VLP_OK;

@@ -256,9 +256,42 @@ extern "C" int vlp_layernorm_bwd(const vlp_layernorm_bwd_args* a, void* stream) 
         hipLaunchKernelGGL(layernorm_bwd_kernel<8>, dim3(blocks), dim3(LNB_THREADS), lnb_smem, s, (const f16*)a->dy, a->lddy, (const f16*)a->x, a->ldx,
                            (const f16*)a->gamma, a->mean, a->rstd, (f16*)a->dx, a->lddx, (f16*)a->dx_drop, a->lddxd, part, a->M, a->H, dyd, outd);
     VLP_CHECK_LAUNCH("vlp_layernorm_bwd");
+    if (a->defer_reduce) return VLP_OK;
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * a->H, 64)), dim3(1024), 0, s, part, blocks, a->H, (f16*)a->dgamma,
                        (f16*)a->dbeta, a->beta);
     VLP_CHECK_LAUNCH("vlp_layernorm_bwd_reduce");
+    return VLP_OK;
+}
+
+// blockIdx.y = LayerNorm index: same arithmetic (and summation order) as ln_bwd_reduce_kernel on slot y
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_batched_kernel(const float* __restrict__ parts, int64_t slot_stride, f16* const* __restrict__ dst,
+                                                                     int nparts, int H, int beta) {
+    __shared__ float sh[16][64];
+    const float* part = parts + (int64_t)blockIdx.y * slot_stride;
+    const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + cl;
+    float s = 0.f;
+    if (i < 2 * H)
+        for (int p = pg; p < nparts; p += 16) s += part[(int64_t)p * 2 * H + i];
+    sh[pg][cl] = s;
+    __syncthreads();
+    if (pg == 0 && i < 2 * H) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k][cl];
+        f16* d = i < H ? dst[2 * blockIdx.y] + i : dst[2 * blockIdx.y + 1] + (i - H);
+        *d = (f16)(beta ? (float)*d + t : t);
+    }
+}
+
+extern "C" int vlp_layernorm_bwd_reduce_batched(const float* parts, const void* const* dst, int32_t count, int32_t M, int32_t H, int32_t beta, void* stream) {
+    VLP_CHECK_ARG(parts && dst && count > 0 && count <= 65535 && M > 0 && H > 0 && H % 8 == 0 && H <= 2048, "vlp_layernorm_bwd_reduce_batched: bad args");
+    VLP_CHECK_ARG(beta == 0 || beta == 1, "vlp_layernorm_bwd_reduce_batched: beta must be 0 or 1");
+    int blocks = cdiv(M, LNB_WAVES);
+    if (blocks > LNB_BLOCKS) blocks = LNB_BLOCKS;
+    hipLaunchKernelGGL(ln_bwd_reduce_batched_kernel, dim3(cdiv(2 * H, 64), count), dim3(1024), 0, (hipStream_t)stream, parts,
+                       (int64_t)LNB_BLOCKS * 2 * H, (f16* const*)dst, blocks, H, beta);
+    VLP_CHECK_LAUNCH("vlp_layernorm_bwd_reduce_batched");
     return VLP_OK;
 }
 

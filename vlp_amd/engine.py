@@ -56,6 +56,8 @@ class Engine(object):
     # single-kernel timings under rocprofv3).  bench.py's live roofline samples stay single-kernel measurements: a sampled launch
     # first lets the side stream drain (see _nt).
     WGRAD_SIDE_STREAM = os.environ.get("VLP_WGRAD_SIDE_STREAM", "1") == "1"
+    LN_DEFER = os.environ.get("VLP_LN_DEFER", "1") == "1"               # LayerNorm dgamma / dbeta second stages batched into one launch per backward
+    SHADOW_ON_SIDE = os.environ.get("VLP_SHADOW_SIDE", "1") == "1"      # W^T shadows transposed on the side stream during the forward
     GROUPED_WGRAD = os.environ.get("VLP_GROUPED_WGRAD", "1") == "1"     # one vlp_gemm_tn_grouped launch per layer instead of 4 split-M wgrads + 4 reduces
     TN_SPLITS = None         # None -> vlp_amd.tuning (variant flags, split-M factor) per (M, N, K)
     # split-M factor: the wgrad outputs are small (36..144 tiles of 128x128) and the contraction long (M = 10 688), so the
@@ -193,6 +195,7 @@ class Engine(object):
         self.packed = False
         self._ws = {}
         self._shadow = None
+        self._ln_tab = None
 
     def P(self, name):
         return self._params[name].data
@@ -264,6 +267,10 @@ class Engine(object):
         ws["tn_ws"] = torch.empty(tn_bytes, device=dev, dtype=torch.uint8)
         ws["cs_ws"] = torch.empty(max(K.colsum_workspace_bytes(M, I), K.colsum_workspace_bytes(B * max(P, 1), Vp)), device=dev, dtype=torch.uint8)
         ws["ln_ws"] = torch.empty(K.layernorm_bwd_workspace_bytes(max(H, 8)), device=dev, dtype=torch.uint8)
+        # one private partials slot per encoder / embedding LayerNorm: their dgamma / dbeta second stages run as ONE launch at the
+        # end of backward (vlp_layernorm_bwd_reduce_batched) instead of 2 * layers + 1 tiny reduce kernels
+        ws["ln_slot_bytes"] = K.layernorm_bwd_workspace_bytes(max(H, 8))
+        ws["ln_slots"] = torch.empty((2 * NL + 1) * ws["ln_slot_bytes"], device=dev, dtype=torch.uint8)
         self._ws[key] = ws
         return ws
 
@@ -288,6 +295,20 @@ class Engine(object):
             sh.update(tT=h(H, H))
         self._shadow = sh
         return sh
+
+    def _ln_table(self):
+        """Device table [2 * layers + 1, 2] of (dgamma, dbeta) addresses: slot 2i = attention.output.LayerNorm of layer i, 2i + 1 =
+        output.LayerNorm of layer i, last = embeddings.LayerNorm (addresses of the flat gradient buffer are stable)."""
+        if getattr(self, "_ln_tab", None) is None:
+            NL = self._model().config.num_hidden_layers
+            rows = []
+            for i in range(NL):
+                L = "bert.encoder.layer.%d." % i
+                for n in ("attention.output.LayerNorm", "output.LayerNorm"):
+                    rows.append([self.G(L + n + ".weight").data_ptr(), self.G(L + n + ".bias").data_ptr()])
+            rows.append([self.G("bert.embeddings.LayerNorm.weight").data_ptr(), self.G("bert.embeddings.LayerNorm.bias").data_ptr()])
+            self._ln_tab = torch.tensor(rows, dtype=torch.int64, device=self.device)
+        return self._ln_tab
 
     def _refresh_shadows(self):
         """All W^T shadows of the step in one batched launch (descriptor table cached: buffer addresses are stable)."""
@@ -446,6 +467,19 @@ class Engine(object):
         seed = st.seed = self.base_seed + self.step_seed
         M, Mv = B * L, B * Nv
 
+        # ---- W^T shadows of this step's dgrad GEMMs: the weights are final once the optimizer has stepped, so the batched transpose
+        # (78 us) runs on the side stream underneath the forward instead of at the head of backward
+        self._shadow_ev = None
+        if (train or torch.is_grad_enabled()) and self.WGRAD_SIDE_STREAM and self.SHADOW_ON_SIDE:
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+                self._side_done = [None, None]
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                self._refresh_shadows()
+                self._shadow_ev = torch.cuda.Event()
+                self._shadow_ev.record(self._side)
         # ---- inputs -----------------------------------------------------------------------------
         want_t = ws["maskt"] if train or torch.is_grad_enabled() else None
         if mask_spec:                       # per-sample lengths -> packed masks on the device (seq2seq_loader.py:292-301)
@@ -900,7 +934,11 @@ class Engine(object):
         M, Mv = B * L, B * Nv
         beta = 1 if self.grads_dirty else 0
         img, input_ids, token_type_ids, masked_pos = st.batch
-        self._refresh_shadows()
+        if getattr(self, "_shadow_ev", None) is not None:
+            torch.cuda.current_stream().wait_event(self._shadow_ev)     # transposed during the forward (side stream)
+            self._shadow_ev = None
+        else:
+            self._refresh_shadows()
         sh = self._shadows()
         x_last = ws["layers"][NL - 1]["x2"]
         dx = ws["dx"]
@@ -954,6 +992,8 @@ class Engine(object):
         if use_side and self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
             self._side_done = [None, None]
+        if use_side and getattr(self, "_side_done", None) is None:
+            self._side_done = [None, None]
         side = self._side if use_side else None
 
         def on_side(fn):
@@ -967,6 +1007,12 @@ class Engine(object):
         if use_side:
             side.wait_stream(main)          # head wgrads above ran on main; order the side stream after them (tn_ws reuse)
             self._side_busy = True
+        slot_bytes = ws["ln_slot_bytes"]
+        defer = self.LN_DEFER
+
+        def ln_slot(k):
+            return ws["ln_slots"][k * slot_bytes:(k + 1) * slot_bytes]
+
         grouped = self.GROUPED_WGRAD and M >= 2048       # enough rows for a long contraction per workgroup; tiny batches keep split-M
         for i in reversed(range(NL)):
             Ln = "bert.encoder.layer.%d." % i
@@ -979,8 +1025,8 @@ class Engine(object):
             # BertOutput: LN(dropout(dense(g)) + x1)   (modeling.py:353-357)
             dpre = ds["dpre2"]
             K.layernorm_bwd(dx, a["pre2"], self.P(Ln + "output.LayerNorm.weight"), a["st2"][0], a["st2"][1], dpre,
-                            self.G(Ln + "output.LayerNorm.weight"), self.G(Ln + "output.LayerNorm.bias"), M, H, ws["ln_ws"], beta=beta,
-                            dx_drop=ds["dpre2_d"] if p > 0 else None, out_drop=(p, seed, 16 * i + 3))
+                            self.G(Ln + "output.LayerNorm.weight"), self.G(Ln + "output.LayerNorm.bias"), M, H, ln_slot(2 * i + 1), beta=beta,
+                            dx_drop=ds["dpre2_d"] if p > 0 else None, out_drop=(p, seed, 16 * i + 3), defer_reduce=defer)
             dy2 = ds["dpre2_d"] if p > 0 else dpre
             if not grouped:
                 on_side(lambda: self._tn(dy2, a["g"], self.G(Ln + "output.dense.weight"), M, H, I, ws, beta, bias=self.G(Ln + "output.dense.bias")))
@@ -993,8 +1039,8 @@ class Engine(object):
             # BertSelfOutput: LN(dropout(dense(ctx)) + x)   (modeling.py:313-317)
             dpre = ds["dpre1"]
             K.layernorm_bwd(dx, a["pre1"], self.P(Ln + "attention.output.LayerNorm.weight"), a["st1"][0], a["st1"][1], dpre,
-                            self.G(Ln + "attention.output.LayerNorm.weight"), self.G(Ln + "attention.output.LayerNorm.bias"), M, H, ws["ln_ws"],
-                            beta=beta, dx_drop=ds["dpre1_d"] if p > 0 else None, out_drop=(p, seed, 16 * i + 2))
+                            self.G(Ln + "attention.output.LayerNorm.weight"), self.G(Ln + "attention.output.LayerNorm.bias"), M, H, ln_slot(2 * i),
+                            beta=beta, dx_drop=ds["dpre1_d"] if p > 0 else None, out_drop=(p, seed, 16 * i + 2), defer_reduce=defer)
             dy1 = ds["dpre1_d"] if p > 0 else dpre
             if not grouped:
                 on_side(lambda: self._tn(dy1, a["ctx"], self.G(Ln + "attention.output.dense.weight"), M, H, H, ws, beta,
@@ -1030,7 +1076,10 @@ class Engine(object):
 
         # ---- embeddings -------------------------------------------------------------------------------------
         K.layernorm_bwd(dx, ws["emb_pre"], self.P(E + "LayerNorm.weight"), ws["stat0"][0], ws["stat0"][1], dpre,
-                        self.G(E + "LayerNorm.weight"), self.G(E + "LayerNorm.bias"), M, H, ws["ln_ws"], beta=beta, dy_drop=(p, seed, 1000))
+                        self.G(E + "LayerNorm.weight"), self.G(E + "LayerNorm.bias"), M, H, ln_slot(2 * NL), beta=beta, dy_drop=(p, seed, 1000),
+                        defer_reduce=defer)
+        if defer:      # dgamma / dbeta of the 2 * layers + 1 LayerNorms above: one launch (slot order = table order)
+            K.layernorm_bwd_reduce_batched(ws["ln_slots"], self._ln_table(), 2 * NL + 1, M, H, beta=beta)
         K.embed_bwd(dpre, input_ids, token_type_ids, ws["vis_h"], ws["vispe_h"], self.G(E + "word_embeddings.weight"),
                     self.G(E + "position_embeddings.weight"), self.G(E + "token_type_embeddings.weight"), ws["d_vis_h"], ws["d_vispe_h"],
                     ws["acc32"], B, L, Nv, H, V, cfg.type_vocab_size, drop_p=p, seed=seed, vis_stream=1001, vispe_stream=1002)
