@@ -130,24 +130,25 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BN
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (int64_t)kt * BK),
                                              (__attribute__((address_space(3))) void*)(ws + (RPP * i + 8 * wid) * BK), 16, 0, 0);
     };
-    auto compute = [&](int buf) {
+    auto compute_ks = [&](int buf, int ks) {
         const f16* xs = smem + buf * (XT + WT);
         const f16* ws = xs + XT;
+        const int c = ks * 4 + g;
+        f16x8 xf[4], wf[4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int c = ks * 4 + g;
-            f16x8 xf[4], wf[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                xf[t] = ld8(xs + xrow[t] * BK + ((c ^ swz_x(xrow[t])) << 3));
-                wf[t] = ld8(ws + wrow[t] * BK + ((c ^ swz_w(wrow[t])) << 3));
-            }
-#pragma unroll
-            for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], acc[tm][tn], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) {
+            xf[t] = ld8(xs + xrow[t] * BK + ((c ^ swz_x(xrow[t])) << 3));
+            wf[t] = ld8(ws + wrow[t] * BK + ((c ^ swz_w(wrow[t])) << 3));
         }
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], acc[tm][tn], 0, 0, 0);
+    };
+    auto compute = [&](int buf) {
+        compute_ks(buf, 0);
+        compute_ks(buf, 1);
     };
 
     if (VARIANT == 0) {
@@ -196,6 +197,8 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BN
         for (int kt = 0; kt < nk; ++kt) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS * (NS - 2)) : "memory");
             __builtin_amdgcn_s_barrier();
+            // (issuing the refill later in the iteration -- staggered between the waves that share a SIMD so that one streams DMA addresses
+            // while the other runs MFMAs -- was measured and lost 0.2 ms per step: the refill has to start as early as possible)
             glds(min(kt + NS - 1, nk - 1), nbuf);
             compute(buf);
             buf = (buf + 1 == NS) ? 0 : buf + 1;
