@@ -363,6 +363,23 @@ def test_attention_fwd_bwd(B, L, Nv, heads, gen):
         a = dqkv.view(B * L, 3, H)[:, i].float()
         r = g.view(B * L, 3, H)[:, i]
         assert rel(a, r) < 4e-3, name
+    # dead-block skipping (blocks whose probabilities are exactly zero under the mask) must not change a single bit, with and
+    # without dropout: the same calls with VLP_ATTN_SKIP=0 (read at every launch)
+    import os
+    for pdrop in (0.0, 0.2):
+        outs = []
+        for flag in ("1", "0"):
+            os.environ["VLP_ATTN_SKIP"] = flag
+            try:
+                c2, l2 = torch.zeros_like(ctx), torch.zeros_like(lse)
+                d2, dl2 = torch.zeros_like(dqkv), torch.zeros_like(delta)
+                K.attn_fwd(qkv, mb, c2, l2, B, L, heads, 0.125, dropout_p=pdrop, seed=11, rng_stream=3)
+                K.attn_bwd(qkv, mb, mt, c2, dctx, l2, d2, dl2, B, L, heads, 0.125, dropout_p=pdrop, seed=11, rng_stream=3)
+                outs.append((c2, l2, d2, dl2))
+            finally:
+                os.environ.pop("VLP_ATTN_SKIP", None)
+        for x, y in zip(*outs):
+            assert torch.equal(x, y)
 
 
 def test_attention_dropout_exact_mask(gen):

@@ -50,7 +50,13 @@ struct AttnParams {
     int Lq, Lk;
     // decode with beams: rows [0, n_prefix) of sequence b come from the per-SAMPLE cache k2 / v2 (row b / beams), the rest from k / v
     const f16* k2; const f16* v2; int64_t bs_kv2; int n_prefix, beams;
+    // 1: (query tile, key tile) blocks whose probabilities are EXACTLY zero (every key masked or padding for every query of the tile,
+    // and every query of the tile has at least one attended key, so exp2(-10000 log2 e - max) underflows to 0) are skipped: bit-identical
+    // results, ~1/3 fewer tiles under seq2seq masks (regions never attend caption tokens; tokens attend causally)
+    int skip;
 };
+
+#define ANY_ATTEND(w) (((w) & 0x01010101u) != 0u)        /* some byte of the mask word is 1 (bytes are 0, 1 or 2) */
 
 // ---- LDS staging helpers ---------------------------------------------------------------------
 // row-major, 128-B rows, chunk-swizzled: dst[key][64]; rows >= L are zero.
@@ -153,11 +159,28 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
 #pragma unroll
             for (int t = 0; t < NT; ++t) mw[t] = mask_word(mrow, t * 16 + 4 * gq, p.Lp);
         }
+        // key tiles that are dead for ALL 16 queries of this wave's tile (bit t clear); only when every query row has an attended key
+        uint32_t live = 0xffffffffu;
+        if (PRELOAD && p.skip) {
+            uint32_t any1 = 0u;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) any1 |= mw[PRELOAD ? t : 0] & 0x01010101u;
+            int rowlive = any1 != 0u;
+            rowlive |= __shfl_xor(rowlive, 16, 64);
+            rowlive |= __shfl_xor(rowlive, 32, 64);
+            if (__all(rowlive)) {
+                live = 0u;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) live |= (__any(ANY_ATTEND(mw[PRELOAD ? t : 0])) ? 1u : 0u) << t;
+            }
+            live = __builtin_amdgcn_readfirstlane(live);
+        }
         // S^T tiles: rows = keys 16t + 4g + reg, col = query
         f32x4 s[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (!((live >> t) & 1u)) continue;
             const int kr = t * 16 + li;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -170,6 +193,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
         float mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+            if (!((live >> t) & 1u)) continue;
             float ma[4];
             mask4w(PRELOAD ? mw[PRELOAD ? t : 0] : mask_word(mrow, t * 16 + 4 * gq, p.Lp), t * 16 + 16 <= L, -MASK_C1, ma);
 #pragma unroll
@@ -182,12 +206,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float sum = 0.f;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) {
+            if (!((live >> t) & 1u)) continue;            // dead tile: s[t] stays 0 = the exact value of its probabilities
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - mx);
                 sum += s[t][r];
             }
+        }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         // the normalisation and the dropout scale 1/(1-p) are applied to the 16 outputs of the lane instead of its 4*NT probabilities
@@ -205,7 +231,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int t = 2 * u + hh;
-                if (p.drop.thresh) {
+                if (!((live >> t) & 1u)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pf[u][hh * 4 + r] = (f16)0.f;
+                } else if (p.drop.thresh) {
                     const uint32_t h0 = mix32(pk0 + (uint32_t)(8 * t) * VLP_PHI), h1 = mix32(pk0 + (uint32_t)(8 * t + 1) * VLP_PHI);
                     pf[u][hh * 4 + 0] = (f16)(((h0 & 0xffffu) < p.drop.thresh) ? 0.f : s[t][0]);
                     pf[u][hh * 4 + 1] = (f16)(((h0 >> 16) < p.drop.thresh) ? 0.f : s[t][1]);
@@ -222,8 +251,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
         for (int n = 0; n < 4; ++n) {
             f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < NT / 2; ++u)
+            for (int u = 0; u < NT / 2; ++u) {
+                if (!((live >> (2 * u)) & 3u)) continue;       // both key tiles of the pair dead: P = 0 exactly
                 o = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(Vs, 32 * u, 32 * u + 16, 16 * n, g, li), pf[u], o, 0, 0, 0);
+            }
             if (q < Lq) {
                 f16x4 ov = (f16x4){(f16)(o[0] * inv), (f16)(o[1] * inv), (f16)(o[2] * inv), (f16)(o[3] * inv)};
                 st4(p.ctx + ((int64_t)b * Lq + q) * p.ld_ctx + h * HD + n * 16 + 4 * g, ov);
@@ -292,8 +323,18 @@ __global__ __launch_bounds__(ATT_THREADS, NT <= 12 ? 2 : 1) void attn_bwd_dq_ker
         const uint32_t pk0 = drop_pairkey(rk, (uint32_t)(4 * gq));
         const float sc2 = p.scale * LOG2E_F, c0 = -MASK_C1 - lse * LOG2E_F;      // P = exp2(s * sc2 + mask term - lse * log2(e))
         f16x8 dsf[NT / 2];
+        // dead (query tile, key tile) blocks: P = 0 exactly (see AttnParams::skip); a query row without any attended key has
+        // lse ~ -10000 (every score carries the -10000 mask term) -- such rows need every key tile
+        const bool rows_live = PRELOAD && p.skip && __all(lse > -5000.f);
+        uint32_t live = 0u;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+            if (rows_live && !__any(ANY_ATTEND(mw[PRELOAD ? t : 0]))) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dsf[t >> 1][(t & 1) * 4 + r] = (f16)0.f;
+                continue;
+            }
+            live |= 1u << t;
             f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int kr = t * 16 + li;
 #pragma unroll
@@ -323,8 +364,10 @@ __global__ __launch_bounds__(ATT_THREADS, NT <= 12 ? 2 : 1) void attn_bwd_dq_ker
         for (int n = 0; n < 4; ++n) {
             f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < NT / 2; ++u)
+            for (int u = 0; u < NT / 2; ++u) {
+                if (!((live >> (2 * u)) & 3u)) continue;
                 o = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(Ks, 32 * u, 32 * u + 16, 16 * n, g, li), dsf[u], o, 0, 0, 0);
+            }
             if (q < L) {
                 f16x4 ov = (f16x4){(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
                 st4(p.dqkv + ((int64_t)b * L + q) * p.ld_dqkv + h * HD + n * 16 + 4 * g, ov);
@@ -400,9 +443,22 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT >= 8 ? 4 : 2)) void attn
             uint32_t mnext[2] = {0x02020202u, 0x02020202u};
             if (u + 1 < NT / 2) { mnext[0] = mload(2 * u + 2); mnext[1] = mload(2 * u + 3); }
             f16x8 pdf, dsf;                      // B operands: rows = queries (pair slots), col = key
+            bool pair_live = false;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int qt = 2 * u + half;
+                // dead block: no (query, key) pair of it is attended AND all its queries have an attended key somewhere (lse_s holds
+                // lse * log2 e; rows whose every key is masked sit at ~ -14 400) -> P = 0 exactly for the whole block
+                if (p.skip) {
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 16 + 4 * gq);
+                    const bool need = ANY_ATTEND(mcur[half]) || fminf(fminf(l4[0], l4[1]), fminf(l4[2], l4[3])) < -7000.f;
+                    if (!__any(need)) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { pdf[half * 4 + r] = (f16)0.f; dsf[half * 4 + r] = (f16)0.f; }
+                        continue;
+                    }
+                }
+                pair_live = true;
                 // S tile: rows = queries 16qt + 4g + reg, col = key.  A = Q rows (LDS), B = K rows (registers)
                 const int qa = qt * 16 + li;
                 f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -428,6 +484,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT >= 8 ? 4 : 2)) void attn
                 }
             }
             // dV^T += dO^T . Pd ; dK^T += Q^T . dS   (rows = head-dim, col = key); transposed operands by ds_read_b64_tr_b16
+            if (pair_live)
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 dv[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(dOs, 32 * u, 32 * u + 16, 16 * n, gq, li), pdf, dv[n], 0, 0, 0);
@@ -467,7 +524,14 @@ static int attn_waves_nt12() {
     return (e && atoi(e) == 8) ? 8 : 4;
 }
 
+// VLP_ATTN_SKIP=0 disables the dead-block skipping (bit-identical either way; read at every launch so tests can toggle it)
+static int attn_skip_enabled() {
+    const char* e = getenv("VLP_ATTN_SKIP");
+    return (e && e[0] == '0') ? 0 : 1;
+}
+
 static int launch_attn_fwd(AttnParams& p, hipStream_t s) {
+    p.skip = attn_skip_enabled();
     const int LP = lp_of(p.Lk);
     const size_t smem = (size_t)2 * LP * HD * 2;
     dim3 grid(p.B * p.heads);
@@ -547,6 +611,7 @@ extern "C" int vlp_attn_bwd(const vlp_attn_bwd_args* a, void* stream) {
     p.Lp = (a->L + 31) / 32 * 32;
     p.scale = a->scale;
     p.drop = make_drop(a->dropout_p, a->seed, a->rng_stream);
+    p.skip = attn_skip_enabled();
     const int LP = lp_of(a->L);
     const size_t smem_dq = (size_t)2 * LP * HD * 2;
     const size_t smem_dkv = (size_t)2 * LP * HD * 2 + (size_t)3 * LP * 4;
