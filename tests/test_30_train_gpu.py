@@ -120,6 +120,36 @@ def test_training_reduces_loss_and_checkpoint_round_trip(tmp_path):
     opt.load_state_dict(osd)
 
 
+def test_pipelined_optimizer_step_is_bit_identical():
+    """FP16_Optimizer_State.pipeline_with_forward: the update runs on the optimizer stream, chunked in the order the next forward reads
+    the parameters, and the forward waits per chunk.  Same kernels, same arithmetic: losses of every step, parameters, Adam moments
+    and the loss-scale state must equal the plain step() bit for bit -- including an overflow (skipped) step."""
+    runs = []
+    for pipelined in (False, True):
+        model, _ = small_model(drop=0.1, layers=3)
+        model.train()
+        opt = FP16_Optimizer_State(FusedAdam(groups_of(model), lr=3e-4, bias_correction=False, max_grad_norm=1.0), dynamic_loss_scale=True,
+                                   dynamic_loss_args={"init_scale": 2.0 ** 24})          # the first steps overflow and are skipped
+        opt.pipeline_with_forward = pipelined
+        batches = [S.batch_to(S.make_batch(6, max_len_b=20, vocab_size=1024, max_pred=3, seed=40 + i), DEV, half=True) for i in range(3)]
+        losses = []
+        for it in range(12):
+            lt = train_step(model, opt, batches[it % 3], 3e-4)
+            losses.append(lt[0].detach().clone())
+        torch.cuda.synchronize()
+        runs.append((losses, {k: v.clone() for k, v in model.engine.flat.items()}, [t.clone() for t in opt.fp32_groups_flat],
+                     [t.clone() for t in opt._m], [t.clone() for t in opt._v], opt.cur_scale, opt.skipped_steps, opt.applied_steps))
+    a, b = runs
+    assert b[6] >= 1 and a[5:] == b[5:], (a[5:], b[5:])
+    for x, y in zip(a[0], b[0]):
+        assert torch.equal(x, y)
+    for k in a[1]:
+        assert torch.equal(a[1][k], b[1][k]), k
+    for i in (2, 3, 4):
+        for x, y in zip(a[i], b[i]):
+            assert torch.equal(x, y)
+
+
 def test_exact_resume_from_model_and_optimizer_checkpoint(tmp_path):
     """N4: the optimizer checkpoint the reference left disabled (run_img2txt_dist.py:599) and the resume path (:310,:428-437):
     2 epochs in one go == 1 epoch, process "restart", resume for epoch 2 -- bit for bit, with dropout on (the engine's mask-stream

@@ -84,6 +84,9 @@ class Engine(object):
         self._ws = {}
         self._shadow = None
         self.prof = None                  # list -> every PROF_EVERY-th NT-GEMM launch is bracketed by HIP events (bench.py roofline)
+        self._opt_stream = None           # optimizer stream of the pipelined FusedAdam step (optimization_fp16._step_pipelined)
+        self._param_events = None         # {"nodecay" | bucket index: event} of the last pipelined optimizer step, consumed by forward
+        self._params_done = None          # event behind its last chunk
         self._side = None                 # second HIP stream for the layer wgrads (created on first use)
         self._side_busy = False           # True while backward may have work queued on it
         self._prof_ctr = 0
@@ -205,6 +208,34 @@ class Engine(object):
 
     def unused_parameter_names(self):
         return set(self._unused)
+
+    # ------------------------------------------------------------------------------------------
+    # pipelined optimizer step: parameter chunks become valid one by one (events on the optimizer stream)
+    # ------------------------------------------------------------------------------------------
+    def optimizer_stream(self):
+        if self._opt_stream is None:
+            self._opt_stream = torch.cuda.Stream(device=self.device)
+        return self._opt_stream
+
+    def set_param_events(self, events, done):
+        self._param_events, self._params_done = events, done
+
+    def wait_params(self, key=None, host=False):
+        """Make the current stream (host=True: the calling thread) wait until the optimizer stream has written parameter chunk `key`
+        ("nodecay" or a bucket index); key=None: all of them (also orders the optimizer's reads of the gradient buffers before later work)."""
+        if self._params_done is None:
+            return
+        if key is None:
+            if host:
+                self._params_done.synchronize()
+            else:
+                torch.cuda.current_stream().wait_event(self._params_done)
+            if host:
+                self._param_events, self._params_done = None, None
+            return
+        ev = self._param_events.get(key) if self._param_events else None
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     def zero_grad(self):
         """optimizer.zero_grad() of the train loop (run_img2txt_dist.py:585): no memset -- the next
@@ -476,6 +507,8 @@ class Engine(object):
                 self._side = torch.cuda.Stream(device=self.device)
                 self._side_done = [None, None]
             self._side.wait_stream(main)
+            if self._params_done is not None:
+                self._side.wait_event(self._params_done)        # the transposes read every weight matrix
             with torch.cuda.stream(self._side):
                 self._refresh_shadows()
                 self._shadow_ev = torch.cuda.Event()
@@ -507,6 +540,9 @@ class Engine(object):
         K.copy2d(self.P("vis_pe_embed.0.weight"), PE_DIM, False, ws["wpe_pad"], PE_PAD, H, PE_DIM, PE_PAD)
         st.batch = (img, input_ids.contiguous(), token_type_ids.contiguous(), masked_pos)
 
+        # parameters written by a pipelined optimizer step become readable chunk by chunk (wait_params is a no-op otherwise)
+        self.wait_params("nodecay")
+        self.wait_params(len(self.buckets) - 1)             # embeddings + region projections
         # ---- region projections (modeling.py:1003-1018,1035-1036) ---------------------------------
         self._nt(img, self.P("vis_embed.0.weight"), ws["h1"], Mv, 2048, 2048, bias=self.P("vis_embed.0.bias"), act=K.ACT_RELU)
         self._nt(ws["h1"], self.P("vis_embed.2.weight"), ws["vis_h"], Mv, H, 2048, bias=self.P("vis_embed.2.bias"), act=K.ACT_RELU,
@@ -525,6 +561,7 @@ class Engine(object):
         for i in range(NL):
             Ln = "bert.encoder.layer.%d." % i
             a = ws["layers"][i]
+            self.wait_params(NL - i)                            # bucket of layer i
             self._nt(x, self.P(Ln + "attention.self.query.weight"), a["qkv"], M, 3 * H, H, bias=self.P(Ln + "attention.self.query.bias"))
             K.attn_fwd(a["qkv"], ws["maskb"], a["ctx"], a["lse"], B, L, A, scale, dropout_p=pa, seed=seed, rng_stream=16 * i + 1)
             self._nt(a["ctx"], self.P(Ln + "attention.output.dense.weight"), a["pre1"], M, H, H, bias=self.P(Ln + "attention.output.dense.bias"),
@@ -541,6 +578,7 @@ class Engine(object):
                             a["st2"][0], a["st2"][1])
             x = a["x2"]
         # ---- heads ------------------------------------------------------------------------------------
+        self.wait_params(0)
         st.has_mlm = P > 0
         if P > 0:
             C = "cls.predictions."
@@ -767,6 +805,7 @@ class Engine(object):
         row, :1236-1247) and attends over the cache.  Returns (ids [B, n] int64, max logits [B, n] f32); with sample=True the
         ids are drawn from softmax(logits) (:1229-1235) and the second output holds their log-probabilities."""
         self.pack()
+        self.wait_params()
         V = self._model().config.vocab_size
         B, in_len, out_len = self._decode_check(vis_feats, vis_pe, input_ids, token_type_ids, attention_mask)
         n_steps, T0 = out_len - in_len, in_len + 1
@@ -817,6 +856,7 @@ class Engine(object):
         n-gram blocking (:1367-1430); when given, ids / pointers are copied to the host every step exactly as the reference does.
         Returns (total_scores, step_ids, back_ptrs) as [frames, B, K] tensors on the device."""
         self.pack()
+        self.wait_params()
         model = self._model()
         cfg = model.config
         H, NL, V = cfg.hidden_size, cfg.num_hidden_layers, cfg.vocab_size
@@ -934,6 +974,7 @@ class Engine(object):
         M, Mv = B * L, B * Nv
         beta = 1 if self.grads_dirty else 0
         img, input_ids, token_type_ids, masked_pos = st.batch
+        self.wait_params()           # the optimizer stream has read the previous gradients and written every parameter
         if getattr(self, "_shadow_ev", None) is not None:
             torch.cuda.current_stream().wait_event(self._shadow_ev)     # transposed during the forward (side stream)
             self._shadow_ev = None

@@ -336,6 +336,9 @@ class PreTrainedBertModel(nn.Module):
     def state_dict(self, *args, **kwargs):
         """Same keys as the reference; tensors are detached clones so a checkpoint never drags the flat
         parameter buffer along."""
+        eng = self.__dict__.get("engine") or getattr(self, "engine", None)
+        if eng is not None and getattr(eng, "packed", False):
+            eng.wait_params()            # a pipelined optimizer step may still be writing the flat parameter buffers
         sd = super(PreTrainedBertModel, self).state_dict(*args, **kwargs)
         if args or kwargs.get("destination") is not None:
             return sd            # nested call from a parent module: the top-level call clones once

@@ -14,6 +14,8 @@ absent here; this module restates that contract on the flat buffers of vlp_amd.e
 Every scalar decision stays on the device: a training step issues no host synchronisation
 (`cur_scale`, `overflow` are read back lazily, only when inspected).
 """
+import os
+
 import torch
 
 from . import _lib as K
@@ -108,43 +110,58 @@ class FP16_Optimizer_State(object):
         # {cur_scale, cur_iter, last_overflow_iter, scale_factor, scale_window, dynamic, skipped, -}
         self._scale_state = torch.tensor([init, 0, -1, factor, window, 1.0 if dynamic_loss_scale else 0.0, 0, 0], device=dev, dtype=torch.float32)
         self.verbose = verbose
+        # True: step() runs on a second stream, chunked in the order the next forward reads the parameters (see _step_pipelined).  Set by
+        # the train loops that only touch parameters through the engine (vlp_amd.run_img2txt_dist, bench.py); default off because code
+        # that reads parameter storage directly right after step() would have to call engine.wait_params() first.
+        self.pipeline_with_forward = os.environ.get("VLP_ADAM_PIPELINE", "0") == "1"
         # Adam's step count = APPLIED steps only (apex increments state['step'] inside the update, which an overflow skips).  The
         # skip decision lives on the device, so the count is derived from the device-side counters when it is needed:
         #   applied = _applied0 + (cur_iter - _iter0) - (skipped - _skipped0)
         self._applied0, self._iter0, self._skipped0 = 0, 0, 0
 
     # ---- lazily synchronised views of the device-side state -------------------------------------------
+    def _sync(self):
+        self.engine.wait_params(host=True)
+
     @property
     def cur_scale(self):
+        self._sync()
         return float(self._scale_state[0])
 
     @property
     def cur_iter(self):
+        self._sync()
         return int(self._scale_state[1])
 
     @property
     def last_overflow_iter(self):
+        self._sync()
         return int(self._scale_state[2])
 
     @property
     def scale_factor(self):
+        self._sync()
         return float(self._scale_state[3])
 
     @property
     def scale_window(self):
+        self._sync()
         return int(self._scale_state[4])
 
     @property
     def overflow(self):
+        self._sync()
         return bool(self._ovf[0] != 0)
 
     @property
     def skipped_steps(self):
+        self._sync()
         return int(self._scale_state[6])
 
     @property
     def applied_steps(self):
         """Number of optimizer updates that were really applied (overflow steps excluded); one host read-back."""
+        self._sync()
         st = self._scale_state.tolist()
         return int(self._applied0 + (st[1] - self._iter0) - (st[6] - self._skipped0))
 
@@ -158,25 +175,71 @@ class FP16_Optimizer_State(object):
 
     def step(self, closure=None):
         eng = self.engine
+        if self.pipeline_with_forward:
+            return self._step_pipelined()
+        eng.wait_params()                        # a previous pipelined step may still be writing
         for i, key in enumerate(self._group_key):
             K.sumsq(eng.gflat[key], eng.sizes[key], self._sumsq[i], self._partial)
         # apex skips the whole step when ANY group overflowed
         torch.maximum(self._sumsq[0][1:2], self._sumsq[1][1:2], out=self._ovf)
         for i, key in enumerate(self._group_key):
             g = self.param_groups[i]
-            b1, b2 = g["betas"]
-            if g["bias_correction"]:
-                t = self.applied_steps + 1          # not the reference's configuration (bias_correction=False): costs a host sync
-                step_size = g["lr"] * (1 - b2 ** t) ** 0.5 / (1 - b1 ** t)
-            else:
-                step_size = g["lr"]
-            K.adam_hyper(self._sumsq[i], self._ovf, self._scale_state, g["max_grad_norm"], step_size, self._hyper[i])
-            K.fused_adam(self.fp32_groups_flat[i], self._m[i], self._v[i], eng.gflat[key], eng.flat[key], eng.sizes[key], self._hyper[i],
-                         b1=b1, b2=b2, eps=g["eps"], decay=g["weight_decay"], eps_inside_sqrt=(self.optimizer.eps_mode == 0))
+            K.adam_hyper(self._sumsq[i], self._ovf, self._scale_state, g["max_grad_norm"], self._step_size(g), self._hyper[i])
+            self._adam_range(i, key, 0, eng.sizes[key])
         K.loss_scale_update(self._scale_state, self._ovf)
+
+    def _step_size(self, g):
+        if g["bias_correction"]:
+            b1, b2 = g["betas"]
+            t = self.applied_steps + 1              # not the reference's configuration (bias_correction=False): costs a host sync
+            return g["lr"] * (1 - b2 ** t) ** 0.5 / (1 - b1 ** t)
+        return g["lr"]
+
+    def _adam_range(self, i, key, lo, hi):
+        g = self.param_groups[i]
+        b1, b2 = g["betas"]
+        eng = self.engine
+        K.fused_adam(self.fp32_groups_flat[i][lo:hi], self._m[i][lo:hi], self._v[i][lo:hi], eng.gflat[key][lo:hi], eng.flat[key][lo:hi], hi - lo,
+                     self._hyper[i], b1=b1, b2=b2, eps=g["eps"], decay=g["weight_decay"], eps_inside_sqrt=(self.optimizer.eps_mode == 0))
+
+    def _step_pipelined(self):
+        """The same update, issued on the engine's optimizer stream in the order the NEXT forward consumes the parameters (no-decay
+        group, embeddings + region projections, layer 0 ... layer N-1, task head), one event per chunk: the next forward waits for
+        the chunk it is about to read instead of for the whole 3.25 GB pass, so the HBM-bound update runs underneath the (MFMA /
+        latency-bound) GEMMs of the first layers.  Same kernels, same per-element arithmetic: results are bit-identical to step().
+        The gradient norm (hence the clip factor and the overflow decision) still needs ALL gradients first."""
+        eng = self.engine
+        main = torch.cuda.current_stream()
+        st = eng.optimizer_stream()
+        eng.wait_params()                        # chunks of the previous step (normally long done)
+        st.wait_stream(main)                     # backward (and the gradient all-reduce) is complete in main's order
+        events = {}
+        with torch.cuda.stream(st):
+            for i, key in enumerate(self._group_key):
+                K.sumsq(eng.gflat[key], eng.sizes[key], self._sumsq[i], self._partial)
+            torch.maximum(self._sumsq[0][1:2], self._sumsq[1][1:2], out=self._ovf)
+            for i, key in enumerate(self._group_key):
+                g = self.param_groups[i]
+                K.adam_hyper(self._sumsq[i], self._ovf, self._scale_state, g["max_grad_norm"], self._step_size(g), self._hyper[i])
+            i_nd, i_d = self._group_key.index("nodecay"), self._group_key.index("decay")
+            self._adam_range(i_nd, "nodecay", 0, eng.sizes["nodecay"])
+            ev = torch.cuda.Event()
+            ev.record(st)
+            events["nodecay"] = ev
+            for b in reversed(range(len(eng.buckets))):          # slice len-1 = embeddings + region projections, ..., slice 0 = head
+                lo, hi = eng.buckets[b]
+                self._adam_range(i_d, "decay", lo, hi)
+                ev = torch.cuda.Event()
+                ev.record(st)
+                events[b] = ev
+            K.loss_scale_update(self._scale_state, self._ovf)
+            done = torch.cuda.Event()
+            done.record(st)
+        eng.set_param_events(events, done)
 
     # ---- checkpointing (optimization_fp16.py:17-80) ----------------------------------------------------------
     def state_dict(self):
+        self._sync()
         sd = {"dynamic_loss_scale": self.dynamic_loss_scale, "cur_scale": self.cur_scale, "cur_iter": self.cur_iter}
         if self.dynamic_loss_scale:
             sd.update(last_overflow_iter=self.last_overflow_iter, scale_factor=self.scale_factor, scale_window=self.scale_window)
@@ -192,6 +255,7 @@ class FP16_Optimizer_State(object):
         return sd
 
     def load_state_dict(self, sd):
+        self._sync()
         self.dynamic_loss_scale = sd["dynamic_loss_scale"]
         st = self._scale_state.cpu()
         st[0], st[1] = sd["cur_scale"], sd["cur_iter"]

@@ -309,6 +309,10 @@ def main(argv=None):
     if distributed:
         model = DDP(model, device_ids=[args.local_rank], output_device=args.local_rank, find_unused_parameters=True)
     optimizer = build_optimizer(args, model, t_total)
+    if hasattr(optimizer, "pipeline_with_forward"):
+        # this loop touches parameters only through the engine, so the optimizer step MAY stream underneath the next forward
+        # (VLP_ADAM_PIPELINE=1; bit-identical).  On one MI355X it is a wash (the HBM-bound update slows the concurrent GEMMs), so off.
+        optimizer.pipeline_with_forward = os.environ.get("VLP_ADAM_PIPELINE", "0") == "1"
     global_step = 0
     if recover_step:                                         # :428-437
         logger.info("***** Recover optimizer: %d *****", recover_step)
