@@ -87,8 +87,10 @@ def test_forward_backward_vs_reference_fixture(name):
     mine = relmax(ours, truth)
     direct = relmax(ours, ref16[key].float().cpu().reshape(truth.shape))
     REPORT.setdefault(name, {}).update({"logits_err_vs_fp32_truth": mine, "reference_fp16_err_vs_fp32_truth": yard, "hip_vs_reference_fp16": direct})
-    assert mine <= yard + 1e-3, REPORT[name]
-    assert direct <= 4e-3, REPORT[name]
+    assert mine <= yard + 1e-3, REPORT[name]              # criterion (ii)
+    # criterion (i), direct distance to the reference's fp16 arithmetic: measured 1.4e-3 - 1.6e-3 (2 layers), 2.4e-3 (12 layers), while
+    # two evaluations of the reference's OWN fp16 arithmetic differ by 0.9e-3 - 1.2e-3 / 1.8e-3 (test_reference_fp16_self_spread)
+    assert direct <= 3e-3, REPORT[name]
     # losses: fp32 CE over fp16 logits
     lt = float(g["losses"].sum())
     assert abs(float(total.sum()) - lt) <= 2e-3 * abs(lt), (float(total.sum()), lt)
