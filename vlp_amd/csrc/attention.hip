@@ -56,6 +56,14 @@ struct AttnParams {
     int skip;
 };
 
+#ifdef VLP_ATTN_TRACE
+// investigation build only (tools/attn_trace.sh): wave 0 of every workgroup of attn_fwd records s_memtime at phase boundaries
+__device__ unsigned long long g_attn_trace[4096 * 8];
+#define TRACE(slot) do { if (wid == 0 && lane == 0 && blockIdx.x < 4096) g_attn_trace[blockIdx.x * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int vlp_debug_read_attn_trace(void* dst, int64_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_trace), bytes); }
+#else
+#define TRACE(slot) do { } while (0)
+#endif
 #define ANY_ATTEND(w) (((w) & 0x01010101u) != 0u)        /* some byte of the mask word is 1 (bytes are 0, 1 or 2) */
 
 // ---- LDS staging helpers ---------------------------------------------------------------------
@@ -68,6 +76,32 @@ DEVFN void stage_rowmajor(f16* dst, const f16* src, int64_t ld, int L, int Lp, i
         u32x4 v = (u32x4){0, 0, 0, 0};
         if (r < L) v = *reinterpret_cast<const u32x4*>((r < n_first ? src_first : src) + (int64_t)r * ld + c * 8);
         *reinterpret_cast<u32x4*>(dst + r * HD + ((c ^ swzk(r)) << 3)) = v;
+    }
+}
+// Two tiles at once with ALL global loads in flight before the first LDS store: the loop above compiles to one HBM round trip per
+// 16-byte piece (load, wait, store; 12 in a row at L = 167 with 256 threads) -- measured 27 % of the forward kernel's time per workgroup
+// (tools/attn_trace.py) -- this form pays one.
+template <int LP_, int NTHR>
+DEVFN void stage_two_rowmajor(f16* dst0, const f16* src0, int64_t ld0, f16* dst1, const f16* src1, int64_t ld1, int L, int tid) {
+    constexpr int IT = (LP_ * 8 + NTHR - 1) / NTHR;
+    u32x4 v0[IT], v1[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int idx = tid + i * NTHR, r = idx >> 3, c = idx & 7;
+        v0[i] = (u32x4){0, 0, 0, 0};
+        v1[i] = (u32x4){0, 0, 0, 0};
+        if (r < L) {
+            v0[i] = *reinterpret_cast<const u32x4*>(src0 + (int64_t)r * ld0 + c * 8);
+            v1[i] = *reinterpret_cast<const u32x4*>(src1 + (int64_t)r * ld1 + c * 8);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int idx = tid + i * NTHR, r = idx >> 3, c = idx & 7;
+        if (idx < LP_ * 8) {
+            *reinterpret_cast<u32x4*>(dst0 + r * HD + ((c ^ swzk(r)) << 3)) = v0[i];
+            *reinterpret_cast<u32x4*>(dst1 + r * HD + ((c ^ swzk(r)) << 3)) = v1[i];
+        }
     }
 }
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -136,9 +170,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
 
     const f16* kpre = p.n_prefix ? p.k2 + (int64_t)(b / p.beams) * p.bs_kv2 * p.ld_kv + h * HD : nullptr;
     const f16* vpre = p.n_prefix ? p.v2 + (int64_t)(b / p.beams) * p.bs_kv2 * p.ld_kv + h * HD : nullptr;
-    stage_rowmajor(Ks, kbase, p.ld_kv, L, LP, tid, NW * 64, kpre, p.n_prefix);
-    stage_rowmajor(Vs, vbase, p.ld_kv, L, LP, tid, NW * 64, vpre, p.n_prefix);
+    TRACE(0);
+    if (p.n_prefix) {       // beam decode: rows < n_prefix come from the per-sample prefix cache
+        stage_rowmajor(Ks, kbase, p.ld_kv, L, LP, tid, NW * 64, kpre, p.n_prefix);
+        stage_rowmajor(Vs, vbase, p.ld_kv, L, LP, tid, NW * 64, vpre, p.n_prefix);
+    } else {
+        stage_two_rowmajor<LP, NW * 64>(Ks, kbase, p.ld_kv, Vs, vbase, p.ld_kv, L, tid);
+    }
+    TRACE(1);
     __syncthreads();
+    TRACE(2);
 
     const int nqt = (Lq + 15) / 16;
     for (int qt = wid; qt < nqt; qt += NW) {
@@ -159,6 +200,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
 #pragma unroll
             for (int t = 0; t < NT; ++t) mw[t] = mask_word(mrow, t * 16 + 4 * gq, p.Lp);
         }
+        if (qt == wid) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TRACE(3); }      // first tile: Q + mask words have arrived
         // key tiles that are dead for ALL 16 queries of this wave's tile (bit t clear); only when every query row has an attended key
         uint32_t live = 0xffffffffu;
         if (PRELOAD && p.skip) {
@@ -188,6 +230,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
                 s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], s[t], 0, 0, 0);
             }
         }
+        if (qt == wid) TRACE(4);       // S MFMAs issued
         // scores in the log2 domain: s2 = s * scale * log2(e) + mask term; softmax = exp2(s2 - max) / sum
         const float sc2 = p.scale * LOG2E_F;
         float mx = -INFINITY;
@@ -246,6 +289,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
                 }
             }
 
+        if (qt == wid) TRACE(5);       // softmax + P fragments done
         // O^T tiles: rows = head-dim 16n + 4g + reg, col = query
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -260,7 +304,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
                 st4(p.ctx + ((int64_t)b * Lq + q) * p.ld_ctx + h * HD + n * 16 + 4 * g, ov);
             }
         }
+        if (qt == wid) TRACE(6);       // first tile stored
     }
+    TRACE(7);
 }
 
 // =================================================================================================
@@ -283,8 +329,7 @@ __global__ __launch_bounds__(ATT_THREADS, NT <= 12 ? 2 : 1) void attn_bwd_dq_ker
     const f16* kbase = qbase + p.H;
     const f16* vbase = qbase + 2 * p.H;
 
-    stage_rowmajor(Ks, kbase, p.ld_qkv, L, LP, tid);
-    stage_rowmajor(Vs, vbase, p.ld_qkv, L, LP, tid);
+    stage_two_rowmajor<LP, ATT_THREADS>(Ks, kbase, p.ld_qkv, Vs, vbase, p.ld_qkv, L, tid);
     __syncthreads();
 
     const int nqt = (L + 15) / 16;
@@ -402,8 +447,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT >= 8 ? 4 : 2)) void attn
     const f16* vbase = qbase + 2 * p.H;
     const f16* dobase = p.dctx + (int64_t)b * L * p.ld_dctx + h * HD;
 
-    stage_rowmajor(Qs, qbase, p.ld_qkv, L, LP, tid, NW * 64);
-    stage_rowmajor(dOs, dobase, p.ld_dctx, L, LP, tid, NW * 64);
+    stage_two_rowmajor<LP, NW * 64>(Qs, qbase, p.ld_qkv, dOs, dobase, p.ld_dctx, L, tid);
     for (int i = tid; i < LP; i += NW * 64) {
         const int64_t stat = ((int64_t)b * p.heads + h) * L + min(i, L - 1);
         lse_s[i] = p.lse[stat] * LOG2E_F;
