@@ -217,18 +217,26 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
             }
             live = __builtin_amdgcn_readfirstlane(live);
         }
-        // S^T tiles: rows = keys 16t + 4g + reg, col = query
+        // S^T tiles: rows = keys 16t + 4g + reg, col = query.  Groups of 4 key tiles: one scalar branch per group (a branch per tile
+        // makes every tile its own basic block: two LDS reads, a full lgkmcnt wait, two dependent MFMAs -- ~500 cycles per tile in the
+        // trace); inside a group the 8 fragment reads are issued together and the 8 MFMAs follow.
         f32x4 s[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (!((live >> t) & 1u)) continue;
-            const int kr = t * 16 + li;
+        for (int t = 0; t < NT; ++t) s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                f16x8 kf = ld8(Ks + kr * HD + (((ks * 4 + g) ^ swzk(kr)) << 3));
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], s[t], 0, 0, 0);
+        for (int t0 = 0; t0 < NT; t0 += 4) {
+            if (!((live >> t0) & 15u)) continue;
+            f16x8 kf[4][2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kr = (t0 + j) * 16 + li;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) kf[j][ks] = ld8(Ks + kr * HD + (((ks * 4 + g) ^ swzk(kr)) << 3));
             }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[t0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[j][ks], qf[ks], s[t0 + j], 0, 0, 0);
         }
         if (qt == wid) TRACE(4);       // S MFMAs issued
         // scores in the log2 domain: s2 = s * scale * log2(e) + mask term; softmax = exp2(s2 - max) / sum
@@ -290,17 +298,24 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
             }
 
         if (qt == wid) TRACE(5);       // softmax + P fragments done
-        // O^T tiles: rows = head-dim 16n + 4g + reg, col = query
+        // O^T tiles: rows = head-dim 16n + 4g + reg, col = query.  Key-tile pair outermost (one scalar branch per pair, four independent
+        // accumulators inside) instead of a branch in front of every MFMA.
+        f32x4 o[4];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < 4; ++n) o[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < NT / 2; ++u) {
-                if (!((live >> (2 * u)) & 3u)) continue;       // both key tiles of the pair dead: P = 0 exactly
-                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(Vs, 32 * u, 32 * u + 16, 16 * n, g, li), pf[u], o, 0, 0, 0);
-            }
-            if (q < Lq) {
-                f16x4 ov = (f16x4){(f16)(o[0] * inv), (f16)(o[1] * inv), (f16)(o[2] * inv), (f16)(o[3] * inv)};
+        for (int u = 0; u < NT / 2; ++u) {
+            if (!((live >> (2 * u)) & 3u)) continue;       // both key tiles of the pair dead: P = 0 exactly
+            f16x8 vfr[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) vfr[n] = tr_frag(Vs, 32 * u, 32 * u + 16, 16 * n, g, li);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) o[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfr[n], pf[u], o[n], 0, 0, 0);
+        }
+        if (q < Lq) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                f16x4 ov = (f16x4){(f16)(o[n][0] * inv), (f16)(o[n][1] * inv), (f16)(o[n][2] * inv), (f16)(o[n][3] * inv)};
                 st4(p.ctx + ((int64_t)b * Lq + q) * p.ld_ctx + h * HD + n * 16 + 4 * g, ov);
             }
         }
