@@ -111,14 +111,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU.  VLP_BENCH_SHARE_GPU=1 (test only: world-2 run of the real engine + DDP hooks on a 1-GPU box, backend gloo)
+    # lets several ranks share the visible devices
+    dev_index = local_rank % torch.cuda.device_count() if os.environ.get("VLP_BENCH_SHARE_GPU") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+        # RCCL ("nccl" on ROCm).  VLP_DIST_BACKEND=gloo only exists for the shared-GPU path check above
+        dist.init_process_group(backend=os.environ.get("VLP_DIST_BACKEND", "nccl"), init_method="env://", world_size=world, rank=rank)
 
     from vlp_amd import synthetic as S
     from vlp_amd.distributed import DistributedDataParallel as DDP
@@ -133,7 +137,7 @@ def main():
     model.half().to(dev)
     eng = model.engine
     if use_dist:
-        model = DDP(model, device_ids=[local_rank], output_device=local_rank, find_unused_parameters=True)
+        model = DDP(model, device_ids=[dev_index], output_device=dev_index, find_unused_parameters=True)
     named = list(model.named_parameters())
     no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
     groups = [{"params": [p for n, p in named if not any(nd in n for nd in no_decay)], "weight_decay": 0.01},
@@ -171,6 +175,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     loss = float((lt[0] + lt[1] + lt[2]).sum().detach())
+    if use_dist and os.environ.get("VLP_BENCH_CHECK_RANKS") == "1":
+        # data-parallel invariant: after any number of steps every rank holds bit-identical parameters
+        eng.wait_params()
+        mine = torch.stack([eng.flat[k].float().sum() for k in ("decay", "nodecay")] + [eng.flat["decay"].float().abs().sum()])
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        if not all(torch.equal(allv[0], v) for v in allv):
+            raise SystemExit("rank parameter checksums differ: %s" % [v.tolist() for v in allv])
     prof, eng.prof = eng.prof, None
 
     if args.tasks == "vqa2":

@@ -230,3 +230,25 @@ def test_bench_through_torchrun_and_rccl_world1():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["final_loss"] == out["config"]["final_loss"]
+
+
+@pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])
+def test_bench_world2_on_one_gpu_real_engine_ddp_hooks(mode):
+    """The N > 1 path of bench.py / run_img2txt_dist.py with the REAL engine: two ranks (sharing this box's single GPU, backend gloo
+    because RCCL refuses two ranks on one device) drive DistributedDataParallel -- parameter broadcast, grouped wgrads announcing
+    their gradient bucket from the side stream, asynchronous bucket reductions, finish() before the optimizer -- on different data,
+    and must hold bit-identical parameters afterwards (checked inside bench.py with VLP_BENCH_CHECK_RANKS=1)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29519" if mode == "allreduce" else "29521", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--layers", "3",
+           "--batch", "16", "--no-cpu-baseline"]
+    env = dict(os.environ, VLP_BENCH_SHARE_GPU="1", VLP_DIST_BACKEND="gloo", VLP_BENCH_CHECK_RANKS="1", VLP_DDP_MODE=mode)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2 and out["config"]["global_batch"] == 32
+    assert out["value"] > 0 and out["config"]["final_loss"] == out["config"]["final_loss"]
