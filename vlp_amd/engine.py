@@ -1125,13 +1125,20 @@ class Engine(object):
                     self.G(E + "position_embeddings.weight"), self.G(E + "token_type_embeddings.weight"), ws["d_vis_h"], ws["d_vispe_h"],
                     ws["acc32"], B, L, Nv, H, V, cfg.type_vocab_size, drop_p=p, seed=seed, vis_stream=1001, vispe_stream=1002)
         # vis_pe_embed: Linear(1607, H) -- wgrad into the padded shadow, then crop-accumulate
-        self._tn(ws["d_vispe_h"], ws["vpe_in"], ws["dwpe_pad"], Mv, H, PE_PAD, ws, 0)
+        # vis_embed: Linear(2048,2048)+ReLU -> Linear(2048,H)+ReLU+Dropout
+        self._nt(ws["d_vis_h"], sh["v2T"], ws["dz1v"], Mv, 2048, H, mul_src=ws["h1"], mul_mode=K.MUL_RELU_MASK)
+        if grouped and Mv >= 2048:
+            # the three region-projection wgrads (78 + 96 + 256 output tiles, contraction over B x 100 region rows) as one grouped launch
+            K.gemm_tn_grouped([
+                (ws["dz1v"], img, self.G("vis_embed.0.weight"), Mv, 2048, 2048, beta, self.G("vis_embed.0.bias")),
+                (ws["d_vis_h"], ws["h1"], self.G("vis_embed.2.weight"), Mv, H, 2048, beta, self.G("vis_embed.2.bias")),
+                (ws["d_vispe_h"], ws["vpe_in"], ws["dwpe_pad"], Mv, H, PE_PAD, 0, None)])
+        else:
+            self._tn(ws["d_vispe_h"], ws["vpe_in"], ws["dwpe_pad"], Mv, H, PE_PAD, ws, 0)
+            self._tn(ws["d_vis_h"], ws["h1"], self.G("vis_embed.2.weight"), Mv, H, 2048, ws, beta, bias=self.G("vis_embed.2.bias"))
+            self._tn(ws["dz1v"], img, self.G("vis_embed.0.weight"), Mv, 2048, 2048, ws, beta, bias=self.G("vis_embed.0.bias"))
         K.copy2d(ws["dwpe_pad"], PE_PAD, False, self.G("vis_pe_embed.0.weight"), PE_DIM, H, PE_DIM, PE_DIM, beta=beta)
         K.colsum(ws["d_vispe_h"], self.G("vis_pe_embed.0.bias"), Mv, H, beta=beta, workspace=ws["cs_ws"])
-        # vis_embed: Linear(2048,2048)+ReLU -> Linear(2048,H)+ReLU+Dropout
-        self._tn(ws["d_vis_h"], ws["h1"], self.G("vis_embed.2.weight"), Mv, H, 2048, ws, beta, bias=self.G("vis_embed.2.bias"))
-        self._nt(ws["d_vis_h"], sh["v2T"], ws["dz1v"], Mv, 2048, H, mul_src=ws["h1"], mul_mode=K.MUL_RELU_MASK)
-        self._tn(ws["dz1v"], img, self.G("vis_embed.0.weight"), Mv, 2048, 2048, ws, beta, bias=self.G("vis_embed.0.bias"))
         self._bucket_done(NL + 1)
         self.grads_dirty = True
         if self.post_backward_hook is not None:
