@@ -112,12 +112,23 @@ DEVFN f16x4 lds_tr_read(const f16* p) {
 // MFMA A-operand fragment of the TRANSPOSE of a row-major swizzled tile: the lane receives column col0 + (lane&15) for the
 // 8 k-slots {r_first + 4g + e, r_second + 4g + e} (e = 0..3): two ds_read_b64_tr_b16; lane s of a 16-lane group supplies
 // the 8-byte piece (row + (s>>2), cols col0 + 4*(s&3) .. +3).
+// MFMA fragments are assembled as four 32-bit words (two fp16 each) and bit-cast: writing fp16 ELEMENTS of an f16x8 from different
+// branches makes the compiler extract / re-insert 16-bit halves (v_lshrrev + v_perm + v_mov: ~1 000 of the 3 500 instructions of a
+// forward query tile), and a wave issues one instruction per 4-5 cycles whatever else is resident (tools/attn_trace.py).
+DEVFN uint32_t pack_f16x2(float a, float b) {
+    const f16x2 v = (f16x2){(f16)a, (f16)b};
+    return __builtin_bit_cast(uint32_t, v);
+}
+DEVFN f16x8 words_f16x8(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    const u32x4 w = (u32x4){a, b, c, d};
+    return __builtin_bit_cast(f16x8, w);
+}
 DEVFN f16x8 tr_frag(const f16* tile, int r_first, int r_second, int col0, int g, int li) {
     const int ra = r_first + 4 * g + (li >> 2), rb = r_second + 4 * g + (li >> 2);
     const int c = col0 + 4 * (li & 3);
-    const f16x4 a = lds_tr_read(tile + ra * HD + (((c >> 3) ^ (ra & 7)) << 3) + (c & 4));
-    const f16x4 b = lds_tr_read(tile + rb * HD + (((c >> 3) ^ (rb & 7)) << 3) + (c & 4));
-    return (f16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    const u32x2 a = __builtin_bit_cast(u32x2, lds_tr_read(tile + ra * HD + (((c >> 3) ^ (ra & 7)) << 3) + (c & 4)));
+    const u32x2 b = __builtin_bit_cast(u32x2, lds_tr_read(tile + rb * HD + (((c >> 3) ^ (rb & 7)) << 3) + (c & 4)));
+    return words_f16x8(a[0], a[1], b[0], b[1]);
 }
 
 // Mask bytes (vlp_mask_pack): 1 = attend (+0), 0 = masked (-10000, modeling.py:832), 2 = padding column past L (excluded: -inf).
@@ -272,7 +283,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
         if (p.lse && g == 0 && q < Lq) p.lse[((int64_t)b * p.heads + h) * Lq + q] = (mx + __builtin_amdgcn_logf(sum)) * LN2_F;
 
         // P^T (UNnormalised exp2 values in (0, 1], dropped entries zeroed) as fp16 B-operand fragments: pair u = tiles (2u, 2u+1)
-        f16x8 pf[NT / 2];
+        uint32_t pfw[NT / 2][4];                 // pair u = tiles (2u, 2u+1); words 2hh, 2hh+1 = the four probabilities of tile 2u+hh
         // dropout element = (row (b, h, q), col key)
         const uint32_t rk = p.drop.thresh ? drop_rowkey(p.drop, ((uint64_t)b * p.heads + h) * (uint64_t)Lq + (uint64_t)qc) : 0u;
         // columns (keys) of tile t held by this lane: 16t + 4g + {0..3} = two hash pairs; pair key advances by 8*PHI per tile
@@ -283,18 +294,20 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
             for (int hh = 0; hh < 2; ++hh) {
                 const int t = 2 * u + hh;
                 if (!((live >> t) & 1u)) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pf[u][hh * 4 + r] = (f16)0.f;
-                } else if (p.drop.thresh) {
-                    const uint32_t h0 = mix32(pk0 + (uint32_t)(8 * t) * VLP_PHI), h1 = mix32(pk0 + (uint32_t)(8 * t + 1) * VLP_PHI);
-                    pf[u][hh * 4 + 0] = (f16)(((h0 & 0xffffu) < p.drop.thresh) ? 0.f : s[t][0]);
-                    pf[u][hh * 4 + 1] = (f16)(((h0 >> 16) < p.drop.thresh) ? 0.f : s[t][1]);
-                    pf[u][hh * 4 + 2] = (f16)(((h1 & 0xffffu) < p.drop.thresh) ? 0.f : s[t][2]);
-                    pf[u][hh * 4 + 3] = (f16)(((h1 >> 16) < p.drop.thresh) ? 0.f : s[t][3]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pf[u][hh * 4 + r] = (f16)s[t][r];
+                    pfw[u][2 * hh] = 0u;
+                    pfw[u][2 * hh + 1] = 0u;
+                    continue;
                 }
+                float p0 = s[t][0], p1 = s[t][1], p2 = s[t][2], p3 = s[t][3];
+                if (p.drop.thresh) {
+                    const uint32_t h0 = mix32(pk0 + (uint32_t)(8 * t) * VLP_PHI), h1 = mix32(pk0 + (uint32_t)(8 * t + 1) * VLP_PHI);
+                    p0 = ((h0 & 0xffffu) < p.drop.thresh) ? 0.f : p0;
+                    p1 = ((h0 >> 16) < p.drop.thresh) ? 0.f : p1;
+                    p2 = ((h1 & 0xffffu) < p.drop.thresh) ? 0.f : p2;
+                    p3 = ((h1 >> 16) < p.drop.thresh) ? 0.f : p3;
+                }
+                pfw[u][2 * hh] = pack_f16x2(p0, p1);
+                pfw[u][2 * hh + 1] = pack_f16x2(p2, p3);
             }
 
         if (qt == wid) TRACE(5);       // softmax + P fragments done
@@ -309,8 +322,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
             f16x8 vfr[4];
 #pragma unroll
             for (int n = 0; n < 4; ++n) vfr[n] = tr_frag(Vs, 32 * u, 32 * u + 16, 16 * n, g, li);
+            const f16x8 pfu = words_f16x8(pfw[u][0], pfw[u][1], pfw[u][2], pfw[u][3]);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) o[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfr[n], pf[u], o[n], 0, 0, 0);
+            for (int n = 0; n < 4; ++n) o[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfr[n], pfu, o[n], 0, 0, 0);
         }
         if (q < Lq) {
 #pragma unroll
@@ -382,7 +396,7 @@ __global__ __launch_bounds__(ATT_THREADS, NT <= 12 ? 2 : 1) void attn_bwd_dq_ker
         const uint32_t rk = p.drop.thresh ? drop_rowkey(p.drop, ((uint64_t)b * p.heads + h) * (uint64_t)L + (uint64_t)qc) : 0u;
         const uint32_t pk0 = drop_pairkey(rk, (uint32_t)(4 * gq));
         const float sc2 = p.scale * LOG2E_F, c0 = -MASK_C1 - lse * LOG2E_F;      // P = exp2(s * sc2 + mask term - lse * log2(e))
-        f16x8 dsf[NT / 2];
+        uint32_t dsw[NT / 2][4];                 // dS^T fragments as packed words (see pack_f16x2)
         // dead (query tile, key tile) blocks: P = 0 exactly (see AttnParams::skip); a query row without any attended key has
         // lse ~ -10000 (every score carries the -10000 mask term) -- such rows need every key tile
         const bool rows_live = PRELOAD && p.skip && __all(lse > -5000.f);
@@ -390,8 +404,8 @@ __global__ __launch_bounds__(ATT_THREADS, NT <= 12 ? 2 : 1) void attn_bwd_dq_ker
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             if (rows_live && !__any(ANY_ATTEND(mw[PRELOAD ? t : 0]))) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dsf[t >> 1][(t & 1) * 4 + r] = (f16)0.f;
+                dsw[t >> 1][2 * (t & 1)] = 0u;
+                dsw[t >> 1][2 * (t & 1) + 1] = 0u;
                 continue;
             }
             live |= 1u << t;
@@ -411,13 +425,15 @@ __global__ __launch_bounds__(ATT_THREADS, NT <= 12 ? 2 : 1) void attn_bwd_dq_ker
                 m4[0] = drop_mult_h(p.drop, h0, 0u); m4[1] = drop_mult_h(p.drop, h0, 1u);
                 m4[2] = drop_mult_h(p.drop, h1, 0u); m4[3] = drop_mult_h(p.drop, h1, 1u);
             }
+            float ds4[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, ma[r]));     // 0 for keys >= L (-inf)
                 const float dpr = dp[r] * m4[r];
-                const float ds = pr * (dpr - dl) * p.scale;
-                dsf[t >> 1][(t & 1) * 4 + r] = (f16)ds;
+                ds4[r] = pr * (dpr - dl) * p.scale;
             }
+            dsw[t >> 1][2 * (t & 1)] = pack_f16x2(ds4[0], ds4[1]);
+            dsw[t >> 1][2 * (t & 1) + 1] = pack_f16x2(ds4[2], ds4[3]);
         }
         // dQ^T tiles: rows = head-dim, col = query;  dQ^T = K^T . dS^T
 #pragma unroll
@@ -426,7 +442,8 @@ __global__ __launch_bounds__(ATT_THREADS, NT <= 12 ? 2 : 1) void attn_bwd_dq_ker
 #pragma unroll
             for (int u = 0; u < NT / 2; ++u) {
                 if (!((live >> (2 * u)) & 3u)) continue;
-                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(Ks, 32 * u, 32 * u + 16, 16 * n, g, li), dsf[u], o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(Ks, 32 * u, 32 * u + 16, 16 * n, g, li),
+                                                           words_f16x8(dsw[u][0], dsw[u][1], dsw[u][2], dsw[u][3]), o, 0, 0, 0);
             }
             if (q < L) {
                 f16x4 ov = (f16x4){(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
@@ -501,7 +518,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT >= 8 ? 4 : 2)) void attn
             asm volatile("" : "+v"(gq));
             uint32_t mnext[2] = {0x02020202u, 0x02020202u};
             if (u + 1 < NT / 2) { mnext[0] = mload(2 * u + 2); mnext[1] = mload(2 * u + 3); }
-            f16x8 pdf, dsf;                      // B operands: rows = queries (pair slots), col = key
+            uint32_t pdw[4], dsw[4];             // B operands (rows = queries (pair slots), col = key) as packed words
             bool pair_live = false;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -512,8 +529,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT >= 8 ? 4 : 2)) void attn
                     const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 16 + 4 * gq);
                     const bool need = ANY_ATTEND(mcur[half]) || fminf(fminf(l4[0], l4[1]), fminf(l4[2], l4[3])) < -7000.f;
                     if (!__any(need)) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { pdf[half * 4 + r] = (f16)0.f; dsf[half * 4 + r] = (f16)0.f; }
+                        pdw[2 * half] = pdw[2 * half + 1] = 0u;
+                        dsw[2 * half] = dsw[2 * half + 1] = 0u;
                         continue;
                     }
                 }
@@ -533,19 +550,25 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT >= 8 ? 4 : 2)) void attn
                 const u32x4 rk4 = *reinterpret_cast<const u32x4*>(rk_s + q0);
                 float ma[4];
                 mask4w(mcur[half], qt * 16 + 16 <= L && kt * 16 + 16 <= L, -MASK_C1, ma);
+                float pd4[4], ds4[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, ma[r] - lse4[r]));     // lse_s holds lse * log2(e); excluded (padding) -> exp2(-inf) = 0
                     float mult = 1.f;
                     if (p.drop.thresh) mult = drop_mult_h(p.drop, mix32(rk4[r] + keyphi), kodd);
-                    pdf[half * 4 + r] = (f16)(pr * mult);
-                    dsf[half * 4 + r] = (f16)(pr * (dp[r] * mult - dl4[r]) * p.scale);
+                    pd4[r] = pr * mult;
+                    ds4[r] = pr * (dp[r] * mult - dl4[r]) * p.scale;
                 }
+                pdw[2 * half] = pack_f16x2(pd4[0], pd4[1]);
+                pdw[2 * half + 1] = pack_f16x2(pd4[2], pd4[3]);
+                dsw[2 * half] = pack_f16x2(ds4[0], ds4[1]);
+                dsw[2 * half + 1] = pack_f16x2(ds4[2], ds4[3]);
             }
             // dV^T += dO^T . Pd ; dK^T += Q^T . dS   (rows = head-dim, col = key); transposed operands by ds_read_b64_tr_b16
             if (pair_live)
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
+                const f16x8 pdf = words_f16x8(pdw[0], pdw[1], pdw[2], pdw[3]), dsf = words_f16x8(dsw[0], dsw[1], dsw[2], dsw[3]);
                 dv[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(dOs, 32 * u, 32 * u + 16, 16 * n, gq, li), pdf, dv[n], 0, 0, 0);
                 dk[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(Qs, 32 * u, 32 * u + 16, 16 * n, gq, li), dsf, dk[n], 0, 0, 0);
             }
