@@ -80,20 +80,22 @@ DEVFN void stage_rowmajor(f16* dst, const f16* src, int64_t ld, int L, int Lp, i
 }
 // Two tiles at once with ALL global loads in flight before the first LDS store: the loop above compiles to one HBM round trip per
 // 16-byte piece (load, wait, store; 12 in a row at L = 167 with 256 threads) -- measured 27 % of the forward kernel's time per workgroup
-// (tools/attn_trace.py) -- this form pays one.
+// (tools/attn_trace.py) -- this form pays one.  The loads go through buffer descriptors whose extent ends with row L - 1, so rows
+// >= L read as zero in hardware: a guarded global load per piece made the compiler carry both tiles as one select-merged register
+// block (~400 v_mov of the 3 000 instructions of a dq workgroup).
+DEVFN __amdgpu_buffer_rsrc_t rows_rsrc(const f16* src, int64_t ld, int L) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)(((int64_t)(L - 1) * ld + HD) * 2), 0x00020000);
+}
 template <int LP_, int NTHR>
 DEVFN void stage_two_rowmajor(f16* dst0, const f16* src0, int64_t ld0, f16* dst1, const f16* src1, int64_t ld1, int L, int tid) {
     constexpr int IT = (LP_ * 8 + NTHR - 1) / NTHR;
+    const __amdgpu_buffer_rsrc_t r0 = rows_rsrc(src0, ld0, L), r1 = rows_rsrc(src1, ld1, L);
     u32x4 v0[IT], v1[IT];
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
         const int idx = tid + i * NTHR, r = idx >> 3, c = idx & 7;
-        v0[i] = (u32x4){0, 0, 0, 0};
-        v1[i] = (u32x4){0, 0, 0, 0};
-        if (r < L) {
-            v0[i] = *reinterpret_cast<const u32x4*>(src0 + (int64_t)r * ld0 + c * 8);
-            v1[i] = *reinterpret_cast<const u32x4*>(src1 + (int64_t)r * ld1 + c * 8);
-        }
+        v0[i] = __builtin_amdgcn_raw_buffer_load_b128(r0, (r * (int)ld0 + c * 8) * 2, 0, 0);
+        v1[i] = __builtin_amdgcn_raw_buffer_load_b128(r1, (r * (int)ld1 + c * 8) * 2, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < IT; ++i) {

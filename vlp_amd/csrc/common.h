@@ -89,6 +89,16 @@ DEVFN void drop_mult8(const DropCtx& d, uint32_t rowkey, uint32_t col0, float* v
         vv[2 * j + 1] *= drop_mult_h(d, h, 1u);
     }
 }
+// 4 consecutive columns starting at col0 (a multiple of 4): 2 hashes
+DEVFN void drop_mult4(const DropCtx& d, uint32_t rowkey, uint32_t col0, float* vv) {
+    const uint32_t base = drop_pairkey(rowkey, col0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t h = mix32(base + (uint32_t)j * VLP_PHI);
+        vv[2 * j] *= drop_mult_h(d, h, 0u);
+        vv[2 * j + 1] *= drop_mult_h(d, h, 1u);
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // math

@@ -6,6 +6,7 @@
 // the dropout that follows the embedding LayerNorm (:240); backward replaces their autograd plus the
 // SumBackward of every broadcast bias add.
 #include "common.h"
+#include <cstdlib>
 
 #define LN_THREADS 256
 #define LN_WAVES 4
@@ -87,42 +88,44 @@ extern "C" int vlp_layernorm_fwd(const vlp_layernorm_fwd_args* a, void* stream) 
 
 // ---------------------------------------------------------------------------------------------
 // backward.  Each wave walks rows (grid-stride) keeping per-column partial sums of dgamma / dbeta in
-// registers; partials [nwaves][2][H] go to the workspace and a second kernel reduces them.
+// registers; partials [nblocks][2][H] go to the workspace and a second kernel reduces them.
+// A lane owns NP pieces of 4 columns (piece k = columns 256k + 4*lane .. +3, 8-byte loads): at H = 768 every lane is busy with 12
+// columns and the kernel needs ~100 VGPRs, so two 8-wave blocks fit a CU.  (The earlier 8-column chunks left half the lanes idle
+// in the second chunk at H = 768 and took 142 VGPRs -- one block per CU, 2 waves per SIMD, one row of prefetch each: 3.4 TB/s.)
 // ---------------------------------------------------------------------------------------------
-#define LNB_BLOCKS 256
+#define LNB_BLOCKS 512
 #define LNB_THREADS 512
 #define LNB_WAVES 8
 
-template <int MAXJ>
-__global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(
+template <int NP>
+__global__ __launch_bounds__(LNB_THREADS, NP <= 3 ? 4 : (NP == 4 ? 3 : 2)) void layernorm_bwd_kernel(
     const f16* __restrict__ dy, int64_t lddy, const f16* __restrict__ x, int64_t ldx, const f16* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, f16* __restrict__ dx, int64_t lddx,
     f16* __restrict__ dxd, int64_t lddxd, float* __restrict__ part, int M, int H, DropCtx dyd, DropCtx outd) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * LNB_WAVES + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * LNB_WAVES;
-    const int nch = H >> 3;
     const float invH = 1.f / (float)H;
-    float g[MAXJ][8], dg[MAXJ][8], db[MAXJ][8];
+    float g[NP][4], dg[NP][4], db[NP][4];
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-        const int c = lane + 64 * j;
-        f16x8 gv = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        if (c < nch) gv = ld8(gamma + c * 8);
+    for (int k = 0; k < NP; ++k) {
+        const int c = 256 * k + 4 * lane;
+        f16x4 gv = (f16x4){0, 0, 0, 0};
+        if (c < H) gv = ld4(gamma + c);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { g[j][e] = (float)gv[e]; dg[j][e] = 0.f; db[j][e] = 0.f; }
+        for (int e = 0; e < 4; ++e) { g[k][e] = (float)gv[e]; dg[k][e] = 0.f; db[k][e] = 0.f; }
     }
-    // software pipeline: the raw 16-byte vectors (and statistics) of the NEXT row are requested before the current row is
+    // software pipeline: the raw vectors (and statistics) of the NEXT row are requested before the current row is
     // reduced, so two rows of HBM traffic are in flight per wave
-    f16x8 xc[MAXJ], dc[MAXJ], xn[MAXJ], dn[MAXJ];
+    f16x4 xc[NP], dc[NP], xn[NP], dn[NP];
     float mu_c = 0.f, rs_c = 0.f, mu_n = 0.f, rs_n = 0.f;
-    auto fetch = [&](int row, f16x8 (&X)[MAXJ], f16x8 (&D)[MAXJ], float& m_, float& r_) {
+    auto fetch = [&](int row, f16x4 (&X)[NP], f16x4 (&D)[NP], float& m_, float& r_) {
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int c = lane + 64 * j;
-            if (c < nch) {
-                X[j] = ld8(x + (int64_t)row * ldx + c * 8);
-                D[j] = ld8(dy + (int64_t)row * lddy + c * 8);
+        for (int k = 0; k < NP; ++k) {
+            const int c = 256 * k + 4 * lane;
+            if (c < H) {
+                X[k] = ld4(x + (int64_t)row * ldx + c);
+                D[k] = ld4(dy + (int64_t)row * lddy + c);
             }
         }
         m_ = mean[row];
@@ -134,64 +137,64 @@ __global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(
         const float mu = mu_c, rs = rs_c;
         const uint32_t rk_dy = dyd.thresh ? drop_rowkey(dyd, (uint64_t)row) : 0u;
         const uint32_t rk_out = outd.thresh ? drop_rowkey(outd, (uint64_t)row) : 0u;
-        float xh[MAXJ][8], d[MAXJ][8];
+        float xh[NP][4], d[NP][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int c = lane + 64 * j;
-            if (c < nch) {
-                const f16x8 xv = xc[j], dv = dc[j];
-                float m8[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-                if (dyd.thresh) drop_mult8(dyd, rk_dy, (uint32_t)(c * 8), m8);
+        for (int k = 0; k < NP; ++k) {
+            const int c = 256 * k + 4 * lane;
+            if (c < H) {
+                const f16x4 xv = xc[k], dv = dc[k];
+                float m4[4] = {1.f, 1.f, 1.f, 1.f};
+                if (dyd.thresh) drop_mult4(dyd, rk_dy, (uint32_t)c, m4);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float dd = (float)dv[e] * m8[e];
-                    xh[j][e] = ((float)xv[e] - mu) * rs;
-                    dg[j][e] += dd * xh[j][e];
-                    db[j][e] += dd;
-                    d[j][e] = dd * g[j][e];
-                    s1 += d[j][e];
-                    s2 += d[j][e] * xh[j][e];
+                for (int e = 0; e < 4; ++e) {
+                    const float dd = (float)dv[e] * m4[e];
+                    xh[k][e] = ((float)xv[e] - mu) * rs;
+                    dg[k][e] += dd * xh[k][e];
+                    db[k][e] += dd;
+                    d[k][e] = dd * g[k][e];
+                    s1 += d[k][e];
+                    s2 += d[k][e] * xh[k][e];
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { xh[j][e] = 0.f; d[j][e] = 0.f; }
+                for (int e = 0; e < 4; ++e) { xh[k][e] = 0.f; d[k][e] = 0.f; }
             }
         }
         s1 = wave_sum(s1) * invH;
         s2 = wave_sum(s2) * invH;
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int c = lane + 64 * j;
-            if (c < nch) {
-                f16x8 o, od;
-                float m8[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-                if (dxd) drop_mult8(outd, rk_out, (uint32_t)(c * 8), m8);
+        for (int k = 0; k < NP; ++k) {
+            const int c = 256 * k + 4 * lane;
+            if (c < H) {
+                f16x4 o, od;
+                float m4[4] = {1.f, 1.f, 1.f, 1.f};
+                if (dxd) drop_mult4(outd, rk_out, (uint32_t)c, m4);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float t = rs * (d[j][e] - s1 - xh[j][e] * s2);
+                for (int e = 0; e < 4; ++e) {
+                    const float t = rs * (d[k][e] - s1 - xh[k][e] * s2);
                     o[e] = (f16)t;
-                    od[e] = (f16)(t * m8[e]);
+                    od[e] = (f16)(t * m4[e]);
                 }
-                st8(dx + (int64_t)row * lddx + c * 8, o);
-                if (dxd) st8(dxd + (int64_t)row * lddxd + c * 8, od);
+                st4(dx + (int64_t)row * lddx + c, o);
+                if (dxd) st4(dxd + (int64_t)row * lddxd + c, od);
             }
         }
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) { xc[j] = xn[j]; dc[j] = dn[j]; }
+        for (int k = 0; k < NP; ++k) { xc[k] = xn[k]; dc[k] = dn[k]; }
         mu_c = mu_n;
         rs_c = rs_n;
     }
-    // block-level reduction of the 4 waves' column partials through LDS, one partial row per block
+    // block-level reduction of the 8 waves' column partials through LDS, one partial row per block
     extern __shared__ float lnb_sh[];      // [LNB_WAVES][2H]
     {
         float* sg = lnb_sh + (threadIdx.x >> 6) * 2 * H;
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int c = lane + 64 * j;
-            if (c < nch) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { sg[c * 8 + e] = dg[j][e]; sg[H + c * 8 + e] = db[j][e]; }
+        for (int k = 0; k < NP; ++k) {
+            const int c = 256 * k + 4 * lane;
+            if (c < H) {
+                *reinterpret_cast<f32x4*>(sg + c) = (f32x4){dg[k][0], dg[k][1], dg[k][2], dg[k][3]};
+                *reinterpret_cast<f32x4*>(sg + H + c) = (f32x4){db[k][0], db[k][1], db[k][2], db[k][3]};
             }
         }
     }
@@ -224,6 +227,18 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __rest
     }
 }
 
+// row-walking blocks of a backward launch (= partial rows in the workspace); VLP_LNB_BLOCKS lowers it for A/B runs
+static int lnb_blocks(int M) {
+    static int cap = 0;
+    if (!cap) {
+        const char* e = getenv("VLP_LNB_BLOCKS");
+        cap = e ? atoi(e) : LNB_BLOCKS;
+        if (cap < 1 || cap > LNB_BLOCKS) cap = LNB_BLOCKS;
+    }
+    const int blocks = cdiv(M, LNB_WAVES);
+    return blocks > cap ? cap : blocks;
+}
+
 extern "C" int64_t vlp_layernorm_bwd_workspace_bytes(int32_t H) {
     return (int64_t)LNB_BLOCKS * 2 * H * (int64_t)sizeof(float);
 }
@@ -238,19 +253,22 @@ extern "C" int vlp_layernorm_bwd(const vlp_layernorm_bwd_args* a, void* stream) 
     if (!a->workspace || a->workspace_bytes < need) return vlp_set_error(VLP_ERR_WORKSPACE, "vlp_layernorm_bwd: workspace %lld < %lld", (long long)a->workspace_bytes, (long long)need);
     DropCtx dyd = make_drop(a->dy_drop_p, a->dy_seed, a->dy_stream);
     DropCtx outd = make_drop(a->out_drop_p, a->out_seed, a->out_stream);
-    int blocks = cdiv(a->M, LNB_WAVES);
-    if (blocks > LNB_BLOCKS) blocks = LNB_BLOCKS;
+    const int blocks = lnb_blocks(a->M);
     hipStream_t s = (hipStream_t)stream;
     float* part = (float*)a->workspace;
     const size_t lnb_smem = (size_t)LNB_WAVES * 2 * a->H * sizeof(float);   // <= 128 KiB at H = 2048
     static bool lnb_attr = false;
     if (!lnb_attr) {
-        hipFuncSetAttribute((const void*)layernorm_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * 1024 * 4);
+        hipFuncSetAttribute((const void*)layernorm_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * 768 * 4);
+        hipFuncSetAttribute((const void*)layernorm_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * 1024 * 4);
         hipFuncSetAttribute((const void*)layernorm_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * 2048 * 4);
         lnb_attr = true;
     }
-    if (a->H <= 1024)
-        hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(LNB_THREADS), lnb_smem, s, (const f16*)a->dy, a->lddy, (const f16*)a->x, a->ldx,
+    if (a->H <= 768)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<3>, dim3(blocks), dim3(LNB_THREADS), lnb_smem, s, (const f16*)a->dy, a->lddy, (const f16*)a->x, a->ldx,
+                           (const f16*)a->gamma, a->mean, a->rstd, (f16*)a->dx, a->lddx, (f16*)a->dx_drop, a->lddxd, part, a->M, a->H, dyd, outd);
+    else if (a->H <= 1024)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(blocks), dim3(LNB_THREADS), lnb_smem, s, (const f16*)a->dy, a->lddy, (const f16*)a->x, a->ldx,
                            (const f16*)a->gamma, a->mean, a->rstd, (f16*)a->dx, a->lddx, (f16*)a->dx_drop, a->lddxd, part, a->M, a->H, dyd, outd);
     else
         hipLaunchKernelGGL(layernorm_bwd_kernel<8>, dim3(blocks), dim3(LNB_THREADS), lnb_smem, s, (const f16*)a->dy, a->lddy, (const f16*)a->x, a->ldx,
@@ -287,8 +305,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_batched_kernel(const float
 extern "C" int vlp_layernorm_bwd_reduce_batched(const float* parts, const void* const* dst, int32_t count, int32_t M, int32_t H, int32_t beta, void* stream) {
     VLP_CHECK_ARG(parts && dst && count > 0 && count <= 65535 && M > 0 && H > 0 && H % 8 == 0 && H <= 2048, "vlp_layernorm_bwd_reduce_batched: bad args");
     VLP_CHECK_ARG(beta == 0 || beta == 1, "vlp_layernorm_bwd_reduce_batched: beta must be 0 or 1");
-    int blocks = cdiv(M, LNB_WAVES);
-    if (blocks > LNB_BLOCKS) blocks = LNB_BLOCKS;
+    const int blocks = lnb_blocks(M);
     hipLaunchKernelGGL(ln_bwd_reduce_batched_kernel, dim3(cdiv(2 * H, 64), count), dim3(1024), 0, (hipStream_t)stream, parts,
                        (int64_t)LNB_BLOCKS * 2 * H, (f16* const*)dst, blocks, H, beta);
     VLP_CHECK_LAUNCH("vlp_layernorm_bwd_reduce_batched");
