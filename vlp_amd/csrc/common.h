@@ -150,6 +150,19 @@ DEVFN float wave_max(float v) {
     return v;
 }
 
+// LDS-DMA of 16 bytes per lane: global -> LDS at (wave-uniform base + lane * 16).  Issued through inline asm, not
+// __builtin_amdgcn_global_load_lds: the compiler's waitcnt pass books the builtin as a FLAT access that may touch LDS, and from then
+// until the VM queue is fully drained it turns EVERY lgkmcnt wait into lgkmcnt(0) -- a ring that keeps DMA stages in flight never
+// drains, so each MFMA group waited for all outstanding fragment reads instead of its own (16 ds_read_b128 in flight, first MFMA
+// after the last of them).  The asm form is invisible to that pass: fragment waits are counted again (lgkmcnt(13), (12), (9) ...).
+// The caller owns the vmcnt accounting of these loads (asm s_waitcnt), as the rings already did.
+DEVFN uint32_t lds_addr_of(const void* p) {     // LDS byte address of a __shared__ pointer (take it once: the generic -> LDS cast carries a null check)
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+DEVFN void glds16(const f16* gsrc, uint32_t lds_wave_base) {      // lds_wave_base: wave-uniform LDS byte address
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(gsrc) : "memory", "m0");
+}
 DEVFN f16x8 ld8(const f16* p) { return *reinterpret_cast<const f16x8*>(p); }
 DEVFN void st8(f16* p, f16x8 v) { *reinterpret_cast<f16x8*>(p) = v; }
 DEVFN f16x4 ld4(const f16* p) { return *reinterpret_cast<const f16x4*>(p); }

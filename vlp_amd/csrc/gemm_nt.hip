@@ -116,19 +116,16 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BN
 #pragma unroll
         for (int i = 0; i < WP; ++i) *reinterpret_cast<u32x4*>(ws + lds_off[i]) = wreg[i];
     };
+    const uint32_t smem_lds = lds_addr_of(smem);
     auto glds = [&](int kt, int buf) {
         // LDS-DMA: destination = wave-uniform base + lane*16 B.  Pass i covers tile rows RPP*i..RPP*i+RPP-1;
         // this wave's 64 lanes cover rows RPP*i + 8*wid .. +7 (8 lanes per 128-B row).
-        f16* xs = smem + buf * (XT + WT);
-        f16* ws = xs + XT;
+        const uint32_t xs = smem_lds + (uint32_t)(buf * (XT + WT)) * 2u;
+        const uint32_t ws = xs + (uint32_t)XT * 2u;
 #pragma unroll
-        for (int i = 0; i < XP; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + (int64_t)kt * BK),
-                                             (__attribute__((address_space(3))) void*)(xs + (RPP * i + 8 * wid) * BK), 16, 0, 0);
+        for (int i = 0; i < XP; ++i) glds16(xsrc[i] + (int64_t)kt * BK, xs + (uint32_t)((RPP * i + 8 * wid) * BK) * 2u);
 #pragma unroll
-        for (int i = 0; i < WP; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (int64_t)kt * BK),
-                                             (__attribute__((address_space(3))) void*)(ws + (RPP * i + 8 * wid) * BK), 16, 0, 0);
+        for (int i = 0; i < WP; ++i) glds16(wsrc[i] + (int64_t)kt * BK, ws + (uint32_t)((RPP * i + 8 * wid) * BK) * 2u);
     };
     auto compute_ks = [&](int buf, int ks) {
         const f16* xs = smem + buf * (XT + WT);
@@ -199,8 +196,45 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BN
             __builtin_amdgcn_s_barrier();
             // (issuing the refill later in the iteration -- staggered between the waves that share a SIMD so that one streams DMA addresses
             // while the other runs MFMAs -- was measured and lost 0.2 ms per step: the refill has to start as early as possible)
+            // the first fragment reads go out BEFORE the refill's DMA instructions: the MFMA pipe idles from the barrier until they
+            // return, and six address computations + global_load_lds in front of them lengthen exactly that window
+            const f16* xs = smem + buf * (XT + WT);
+            const f16* ws = xs + XT;
+            f16x8 xf0[4], wf0[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                xf0[t] = ld8(xs + xrow[t] * BK + ((g ^ swz_x(xrow[t])) << 3));
+                wf0[t] = ld8(ws + wrow[t] * BK + ((g ^ swz_w(wrow[t])) << 3));
+            }
+            __builtin_amdgcn_sched_barrier(0);
             glds(min(kt + NS - 1, nk - 1), nbuf);
-            compute(buf);
+            if (BN_T == 128) {          // 2 waves per SIMD: room for both fragment sets -- the second half's reads fly under the first half's MFMAs
+                f16x8 xf1[4], wf1[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    xf1[t] = ld8(xs + xrow[t] * BK + (((4 + g) ^ swz_x(xrow[t])) << 3));
+                    wf1[t] = ld8(ws + wrow[t] * BK + (((4 + g) ^ swz_w(wrow[t])) << 3));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0[tn], xf0[tm], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[tn], xf1[tm], acc[tm][tn], 0, 0, 0);
+            } else {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0[tn], xf0[tm], acc[tm][tn], 0, 0, 0);
+                compute_ks(buf, 1);
+            }
             buf = (buf + 1 == NS) ? 0 : buf + 1;
             nbuf = (nbuf + 1 == NS) ? 0 : nbuf + 1;
         }

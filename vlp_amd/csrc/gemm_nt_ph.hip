@@ -37,8 +37,7 @@
 
 #define PH_BK 64
 
-#define PH_GLDS(src, dst) \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+#define PH_GLDS(src, dst) glds16((src), lds_addr_of(dst))
 #define PH_SCHED() __builtin_amdgcn_sched_barrier(0)
 #define PH_BAR()        \
     do {                \

@@ -67,12 +67,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_splitk_kernel(SplitKParams q) 
         f16* ws = xs + XT;
 #pragma unroll
         for (int i = 0; i < XP; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + (int64_t)kt * SK_BK),
-                                             (__attribute__((address_space(3))) void*)(xs + (RPP * i + 8 * wid) * SK_BK), 16, 0, 0);
+            glds16(xsrc[i] + (int64_t)kt * SK_BK, lds_addr_of(xs + (RPP * i + 8 * wid) * SK_BK));
 #pragma unroll
         for (int i = 0; i < WP; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (int64_t)kt * SK_BK),
-                                             (__attribute__((address_space(3))) void*)(ws + (RPP * i + 8 * wid) * SK_BK), 16, 0, 0);
+            glds16(wsrc[i] + (int64_t)kt * SK_BK, lds_addr_of(ws + (RPP * i + 8 * wid) * SK_BK));
     };
     auto compute = [&](int buf) {
         const f16* xs = smem + buf * (XT + WT);

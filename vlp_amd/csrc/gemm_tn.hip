@@ -265,19 +265,19 @@ DEVFN void tn_glds_tile(const GemmTnParams& p, int bid, f16* smem) {
     for (int a = 0; a < 4; ++a) bacc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const f16x8 ones = (f16x8){(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
 
+    const uint32_t smem_lds = lds_addr_of(smem);
     auto stage = [&](int st, int buf) {
         f16* as = smem + buf * (ATILE + BTILE);
         f16* bs = as + ATILE;
         const int mbase = m_begin + st * TN_BM;
         if (mbase + TN_BM <= m_end) {            // full stage (wave-uniform): LDS-DMA, 64 lanes = 1 KiB contiguous in LDS
+            const uint32_t as_l = smem_lds + (uint32_t)(buf * (ATILE + BTILE)) * 2u, bs_l = as_l + (uint32_t)ATILE * 2u;
 #pragma unroll
             for (int i = 0; i < AP; ++i)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.A + (int64_t)(mbase + arow + ARP * i) * p.lda + acol[i]),
-                                                 (__attribute__((address_space(3))) void*)(as + (ARP * i) * BN_T + wid * 512), 16, 0, 0);
+                glds16(p.A + (int64_t)(mbase + arow + ARP * i) * p.lda + acol[i], as_l + (uint32_t)((ARP * i) * BN_T + wid * 512) * 2u);
 #pragma unroll
             for (int i = 0; i < BP; ++i)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.B + (int64_t)(mbase + brow + BRP * i) * p.ldb + bcol[i]),
-                                                 (__attribute__((address_space(3))) void*)(bs + (BRP * i) * BK_T + wid * 512), 16, 0, 0);
+                glds16(p.B + (int64_t)(mbase + brow + BRP * i) * p.ldb + bcol[i], bs_l + (uint32_t)((BRP * i) * BK_T + wid * 512) * 2u);
         } else {                                  // ragged tail: through registers with zero fill, same LDS image
 #pragma unroll
             for (int i = 0; i < AP; ++i) {
