@@ -266,18 +266,25 @@ DEVFN void tn_glds_tile(const GemmTnParams& p, int bid, f16* smem) {
     const f16x8 ones = (f16x8){(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
 
     const uint32_t smem_lds = lds_addr_of(smem);
+    // per-thread DMA source of stage 0 (pass i); a stage advances every pointer by TN_BM rows -- one 64-bit add per DMA instead of a
+    // row * pitch multiply
+    const f16* asrc[AP];
+    const f16* bsrc[BP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) asrc[i] = p.A + (int64_t)(m_begin + arow + ARP * i) * p.lda + acol[i];
+#pragma unroll
+    for (int i = 0; i < BP; ++i) bsrc[i] = p.B + (int64_t)(m_begin + brow + BRP * i) * p.ldb + bcol[i];
     auto stage = [&](int st, int buf) {
         f16* as = smem + buf * (ATILE + BTILE);
         f16* bs = as + ATILE;
         const int mbase = m_begin + st * TN_BM;
         if (mbase + TN_BM <= m_end) {            // full stage (wave-uniform): LDS-DMA, 64 lanes = 1 KiB contiguous in LDS
             const uint32_t as_l = smem_lds + (uint32_t)(buf * (ATILE + BTILE)) * 2u, bs_l = as_l + (uint32_t)ATILE * 2u;
+            const int64_t aoff = (int64_t)st * TN_BM * p.lda, boff = (int64_t)st * TN_BM * p.ldb;
 #pragma unroll
-            for (int i = 0; i < AP; ++i)
-                glds16(p.A + (int64_t)(mbase + arow + ARP * i) * p.lda + acol[i], as_l + (uint32_t)((ARP * i) * BN_T + wid * 512) * 2u);
+            for (int i = 0; i < AP; ++i) glds16(asrc[i] + aoff, as_l + (uint32_t)((ARP * i) * BN_T + wid * 512) * 2u);
 #pragma unroll
-            for (int i = 0; i < BP; ++i)
-                glds16(p.B + (int64_t)(mbase + brow + BRP * i) * p.ldb + bcol[i], bs_l + (uint32_t)((BRP * i) * BK_T + wid * 512) * 2u);
+            for (int i = 0; i < BP; ++i) glds16(bsrc[i] + boff, bs_l + (uint32_t)((BRP * i) * BK_T + wid * 512) * 2u);
         } else {                                  // ragged tail: through registers with zero fill, same LDS image
 #pragma unroll
             for (int i = 0; i < AP; ++i) {
@@ -295,47 +302,52 @@ DEVFN void tn_glds_tile(const GemmTnParams& p, int bid, f16* smem) {
             }
         }
     };
-    auto compute = [&](int buf) {
+    // fragments of the m sub-step ms (32 rows) of a stage: 16 transpose reads
+    auto read_frags = [&](int buf, int ms, f16x8 (&xf)[4], f16x8 (&yf)[4]) {
         const f16* as = smem + buf * (ATILE + BTILE);   // dY tile [m][n]
         const f16* bs = as + ATILE;                     // X tile  [m][k]
+        const int r0 = ms * 32 + 8 * g + (li >> 2);     // this lane's piece row (first read); second read: +4 (same swizzle)
+        const int sw = tn_swz(r0);
 #pragma unroll
-        for (int ms = 0; ms < 2; ++ms) {
-            const int r0 = ms * 32 + 8 * g + (li >> 2);     // this lane's piece row (first read); second read: +4 (same swizzle)
-            const int sw = tn_swz(r0);
-            f16x8 xf[4], yf[4];
+        for (int t = 0; t < 4; ++t) {
+            const int cx = wk * 64 + 16 * t + 4 * (li & 3), cy = wn * 64 + 16 * t + 4 * (li & 3);
+            const f16* px = bs + r0 * BK_T + (((cx >> 3) ^ sw) << 3) + (cx & 4);
+            const f16* py = as + r0 * BN_T + (((cy >> 3) ^ sw) << 3) + (cy & 4);
+            const u32x2 x0 = __builtin_bit_cast(u32x2, lds_tr_read(px)), x1 = __builtin_bit_cast(u32x2, lds_tr_read(px + 4 * BK_T));
+            const u32x2 y0 = __builtin_bit_cast(u32x2, lds_tr_read(py)), y1 = __builtin_bit_cast(u32x2, lds_tr_read(py + 4 * BN_T));
+            xf[t] = __builtin_bit_cast(f16x8, (u32x4){x0[0], x0[1], x1[0], x1[1]});
+            yf[t] = __builtin_bit_cast(f16x8, (u32x4){y0[0], y0[1], y1[0], y1[1]});
+        }
+    };
+    auto mfma_frags = [&](const f16x8 (&xf)[4], const f16x8 (&yf)[4]) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int cx = wk * 64 + 16 * t + 4 * (li & 3), cy = wn * 64 + 16 * t + 4 * (li & 3);
-                const f16* px = bs + r0 * BK_T + (((cx >> 3) ^ sw) << 3) + (cx & 4);
-                const f16* py = as + r0 * BN_T + (((cy >> 3) ^ sw) << 3) + (cy & 4);
-                f16x4 x0 = lds_tr_read(px), x1 = lds_tr_read(px + 4 * BK_T);
-                f16x4 y0 = lds_tr_read(py), y1 = lds_tr_read(py + 4 * BN_T);
-                xf[t] = (f16x8){x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-                yf[t] = (f16x8){y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
-            }
+        for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
+            for (int tk = 0; tk < 4; ++tk)
+                acc[tn][tk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[tk], yf[tn], acc[tn][tk], 0, 0, 0);
+        if (do_bias) {
 #pragma unroll
-                for (int tk = 0; tk < 4; ++tk)
-                    acc[tn][tk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[tk], yf[tn], acc[tn][tk], 0, 0, 0);
-            if (do_bias) {
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) bacc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, yf[tn], bacc[tn], 0, 0, 0);
-            }
+            for (int tn = 0; tn < 4; ++tn) bacc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, yf[tn], bacc[tn], 0, 0, 0);
         }
     };
 
     if (nstages > 0) {
         // two LDS stages as a ring: wait for stage st (DMA: vmcnt; the ragged tail's ds_writes: lgkmcnt), ONE raw barrier -- every wave's
-        // pieces have landed and every wave is done with the fragment reads of stage st-1 -- then refill that buffer with stage st+1
-        // right behind the barrier and compute stage st while it streams in (the form that won on the NT side: gemm_nt.hip ring)
+        // pieces have landed and every wave is done with the fragment reads of stage st-1 -- then the first half's fragment reads, the refill
+        // of the freed buffer with stage st+1 (it streams in under this stage's MFMAs), the second half's reads, and the 32 MFMAs
         stage(0, 0);
         for (int st = 0; st < nstages; ++st) {
             const int buf = st & 1;
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            f16x8 x0[4], y0[4], x1[4], y1[4];
+            read_frags(buf, 0, x0, y0);
+            __builtin_amdgcn_sched_barrier(0);
             if (st + 1 < nstages) stage(st + 1, buf ^ 1);
-            compute(buf);
+            read_frags(buf, 1, x1, y1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_frags(x0, y0);
+            mfma_frags(x1, y1);
         }
     }
 
