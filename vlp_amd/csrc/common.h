@@ -163,6 +163,16 @@ DEVFN void glds16(const f16* gsrc, uint32_t lds_wave_base) {      // lds_wave_ba
     const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_wave_base);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(gsrc) : "memory", "m0");
 }
+#ifdef VLP_NT_DEBUG
+DEVFN void glds16_nt(const f16* gsrc, uint32_t lds_wave_base) {
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(m0v), "v"(gsrc) : "memory", "m0");
+}
+DEVFN void glds16_sc1(const f16* gsrc, uint32_t lds_wave_base) {
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1" ::"s"(m0v), "v"(gsrc) : "memory", "m0");
+}
+#endif
 DEVFN f16x8 ld8(const f16* p) { return *reinterpret_cast<const f16x8*>(p); }
 DEVFN void st8(f16* p, f16x8 v) { *reinterpret_cast<f16x8*>(p) = v; }
 DEVFN f16x4 ld4(const f16* p) { return *reinterpret_cast<const f16x4*>(p); }

@@ -17,6 +17,9 @@ struct GemmNtParams {
     DropCtx drop;
     int tiles_n;
     int xcd_remap;   // 1: workgroups of one XCD (blockIdx % 8) take a contiguous range of tiles (X-panel reuse in that XCD's L2)
+#ifdef VLP_NT_DEBUG
+    int dbg;         // investigation build (tools/build_variant_lib.sh): 1 = ring loop without MFMAs, 2 = without refill DMA, 4 = without the epilogue
+#endif
 };
 
 // phased kernels (gemm_nt_ph.hip): bn = 256 or 128 columns per workgroup tile (256 rows); p.xcd_remap honoured

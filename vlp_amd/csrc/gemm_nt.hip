@@ -122,6 +122,18 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BN
         // this wave's 64 lanes cover rows RPP*i + 8*wid .. +7 (8 lanes per 128-B row).
         const uint32_t xs = smem_lds + (uint32_t)(buf * (XT + WT)) * 2u;
         const uint32_t ws = xs + (uint32_t)XT * 2u;
+#ifdef VLP_NT_DEBUG
+        if (p.dbg & 24) {      // cache-policy experiments: 8 = X tile nt, 16 = X tile sc1 (W stays default)
+#pragma unroll
+            for (int i = 0; i < XP; ++i) {
+                if (p.dbg & 8) glds16_nt(xsrc[i] + (int64_t)kt * BK, xs + (uint32_t)((RPP * i + 8 * wid) * BK) * 2u);
+                else glds16_sc1(xsrc[i] + (int64_t)kt * BK, xs + (uint32_t)((RPP * i + 8 * wid) * BK) * 2u);
+            }
+#pragma unroll
+            for (int i = 0; i < WP; ++i) glds16(wsrc[i] + (int64_t)kt * BK, ws + (uint32_t)((RPP * i + 8 * wid) * BK) * 2u);
+            return;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < XP; ++i) glds16(xsrc[i] + (int64_t)kt * BK, xs + (uint32_t)((RPP * i + 8 * wid) * BK) * 2u);
 #pragma unroll
@@ -207,7 +219,13 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BN
                 wf0[t] = ld8(ws + wrow[t] * BK + ((g ^ swz_w(wrow[t])) << 3));
             }
             __builtin_amdgcn_sched_barrier(0);
+#ifdef VLP_NT_DEBUG
+            if (!(p.dbg & 2))
+#endif
             glds(min(kt + NS - 1, nk - 1), nbuf);
+#ifdef VLP_NT_DEBUG
+            if (p.dbg & 1) { buf = (buf + 1 == NS) ? 0 : buf + 1; nbuf = (nbuf + 1 == NS) ? 0 : nbuf + 1; acc[0][0][0] += (float)xf0[0][0] + (float)wf0[0][0]; continue; }
+#endif
             if (BN_T == 128) {          // 2 waves per SIMD: room for both fragment sets -- the second half's reads fly under the first half's MFMAs
                 f16x8 xf1[4], wf1[4];
 #pragma unroll
@@ -241,6 +259,9 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BN
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the clamped tail reloads must land before the LDS is released
     }
 
+#ifdef VLP_NT_DEBUG
+    if ((p.dbg & 4) && acc[0][0][0] != 12345.678f) return;
+#endif
     // ---- epilogue: lane owns row m (per tm) and 16 consecutive n -------------------------------
     const int ncol0 = n0 + wn * 64 + 16 * g;
     const bool full_n = (ncol0 + 16 <= p.N);
@@ -306,6 +327,9 @@ int vlp_gemm_nt_fill_params(const vlp_gemm_nt_args* a, GemmNtParams& p) {
     p.drop = make_drop(a->dropout_p, a->seed, a->rng_stream);
     p.tiles_n = 0;
     p.xcd_remap = 0;
+#ifdef VLP_NT_DEBUG
+    { const char* e = getenv("VLP_NT_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+#endif
     return VLP_OK;
 }
 
