@@ -15,6 +15,7 @@
 // consecutive k -> 16-byte stores.  M is split across blockIdx.z; partial products go to fp32 slabs
 // that a second kernel reduces (deterministic, no atomics) and converts to fp16 (+= when beta = 1).
 #include "common.h"
+#include <cstdlib>
 
 #define TN_BN 128     // output rows (n) per block
 #define TN_BK 128     // output cols (k) per block
@@ -215,7 +216,7 @@ DEVFN int tn_swz(int r) { return ((r & 3) | (((r >> 3) & 1) << 2)) << 1; }
 
 // BN_T x BK_T output tile (each 128 or 256); one wave per 64x64 sub-tile -> 4 or 8 waves.  `bid` = linear tile index of this workgroup
 // inside the problem p (after any XCD remap): shared by the single-problem kernel and the grouped launch below.
-template <int BN_T, int BK_T>
+template <int BN_T, int BK_T, int NS = 2>      // NS = LDS stages of the ring (2: refill waits for vmcnt(0) every stage; 3: one more stage stays in flight)
 DEVFN void tn_glds_tile(const GemmTnParams& p, int bid, f16* smem) {
     constexpr int WK_ = BK_T / 64;
     constexpr int T = (BN_T / 64) * WK_ * 64;            // threads
@@ -335,19 +336,28 @@ DEVFN void tn_glds_tile(const GemmTnParams& p, int bid, f16* smem) {
         // two LDS stages as a ring: wait for stage st (DMA: vmcnt; the ragged tail's ds_writes: lgkmcnt), ONE raw barrier -- every wave's
         // pieces have landed and every wave is done with the fragment reads of stage st-1 -- then the first half's fragment reads, the refill
         // of the freed buffer with stage st+1 (it streams in under this stage's MFMAs), the second half's reads, and the 32 MFMAs
-        stage(0, 0);
+        constexpr int LPS = AP + BP;                  // DMA instructions per thread per full stage
+#pragma unroll
+        for (int i = 0; i < NS - 1; ++i)
+            if (i < nstages) stage(i, i);
+        int buf = 0, nbuf = NS - 1;
         for (int st = 0; st < nstages; ++st) {
-            const int buf = st & 1;
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            // stage st must have landed; with NS = 3 the next stage (if it exists and is a full DMA stage) may stay in flight.  The
+            // ragged last stage goes through registers + ds_write (compiler-tracked loads, waited for inside stage()), so its
+            // presence only lowers the number of outstanding DMA instructions -- then wait for everything.
+            if (NS == 3 && st + 1 < nstages && m_begin + (st + 2) * TN_BM <= m_end) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             f16x8 x0[4], y0[4], x1[4], y1[4];
             read_frags(buf, 0, x0, y0);
             __builtin_amdgcn_sched_barrier(0);
-            if (st + 1 < nstages) stage(st + 1, buf ^ 1);
+            if (st + NS - 1 < nstages) stage(st + NS - 1, nbuf);
             read_frags(buf, 1, x1, y1);
             __builtin_amdgcn_sched_barrier(0);
             mfma_frags(x0, y0);
             mfma_frags(x1, y1);
+            buf = (buf + 1 == NS) ? 0 : buf + 1;
+            nbuf = (nbuf + 1 == NS) ? 0 : nbuf + 1;
         }
     }
 
@@ -410,7 +420,8 @@ struct TnGroupParams {
     int count, total_tiles, xcd_remap;
 };
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(TnGroupParams gp) {
+template <int BN_T, int BK_T, int NS>
+__global__ __launch_bounds__((BN_T / 64) * (BK_T / 64) * 64, 2) void gemm_tn_grouped_kernel(TnGroupParams gp) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     int bid = blockIdx.x;
     if (gp.xcd_remap) bid = tn_xcd_remap(bid, gridDim.x);
@@ -424,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(TnGroupParams g
     p.slab = nullptr; p.bias_slab = nullptr; p.bias_out = e.bias_out;
     p.M = e.M; p.N = e.N; p.K = e.K; p.beta = e.beta; p.splits = 1; p.rows_per_split = (e.M + TN_BM - 1) / TN_BM * TN_BM;
     p.tiles_k = e.tiles_k; p.tiles_n = 0; p.xcd_remap = 0; p.split_major = 0;
-    tn_glds_tile<128, 128>(p, bid - e.tile_begin, reinterpret_cast<f16*>(smem_raw));
+    tn_glds_tile<BN_T, BK_T, NS>(p, bid - e.tile_begin, reinterpret_cast<f16*>(smem_raw));
 }
 
 // out[n,k] = (beta ? out : 0) + sum_s slab[s][n][k]; the tail of the grid reduces the fused bias partials [s][N]
@@ -568,6 +579,11 @@ static int tn_check_one(const vlp_gemm_tn_args* a) {
 
 extern "C" int vlp_gemm_tn_grouped(const vlp_gemm_tn_args* list, int32_t count, void* stream) {
     VLP_CHECK_ARG(list != nullptr && count >= 1 && count <= TN_GROUP_MAX, "vlp_gemm_tn_grouped: 1..%d problems", TN_GROUP_MAX);
+    // tile shape / ring depth of the grouped launch: 0 = 128x128 tiles, 2 stages (two 4-wave workgroups per CU); 1 = 256x128, 2 stages;
+    // 2 = 256x128, 3 stages; 3 = 128x256, 3 stages (8-wave workgroups, one per CU).  VLP_TN_GROUP_MODE overrides (A/B runs).
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("VLP_TN_GROUP_MODE"); mode = e ? atoi(e) : 0; if (mode < 0 || mode > 3) mode = 0; }
+    const int bn = mode == 0 ? 128 : (mode == 3 ? 128 : 256), bk = mode == 3 ? 256 : 128, ns = mode >= 2 ? 3 : 2;
     TnGroupParams gp;
     int tiles = 0;
     for (int i = 0; i < count; ++i) {
@@ -578,16 +594,24 @@ extern "C" int vlp_gemm_tn_grouped(const vlp_gemm_tn_args* list, int32_t count, 
         e.A = (const f16*)a->A; e.lda = a->lda; e.B = (const f16*)a->B; e.ldb = a->ldb; e.C = (f16*)a->C; e.ldc = a->ldc;
         e.bias_out = (f16*)a->bias_out;
         e.M = a->M; e.N = a->N; e.K = a->K; e.beta = a->beta;
-        e.tiles_k = cdiv(a->K, 128);
+        e.tiles_k = cdiv(a->K, bk);
         e.tile_begin = tiles;
-        tiles += e.tiles_k * cdiv(a->N, 128);
+        tiles += e.tiles_k * cdiv(a->N, bn);
     }
     for (int i = count; i < TN_GROUP_MAX; ++i) { gp.e[i] = gp.e[0]; gp.e[i].tile_begin = 0x7fffffff; }
     gp.count = count; gp.total_tiles = tiles; gp.xcd_remap = 1;
-    const size_t smem = (size_t)2 * TN_BM * (128 + 128) * sizeof(f16);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
-    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(tiles), dim3(256), smem, (hipStream_t)stream, gp);
+#define LAUNCH_TN_GROUP(BNT, BKT, NSV)                                                                                                  \
+    do {                                                                                                                                \
+        const size_t smem = (size_t)(NSV) * TN_BM * ((BNT) + (BKT)) * sizeof(f16);                                                      \
+        static bool attr = false;                                                                                                       \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<BNT, BKT, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; } \
+        hipLaunchKernelGGL((gemm_tn_grouped_kernel<BNT, BKT, NSV>), dim3(tiles), dim3(((BNT) / 64) * ((BKT) / 64) * 64), smem, (hipStream_t)stream, gp); \
+    } while (0)
+    if (mode == 0) LAUNCH_TN_GROUP(128, 128, 2);
+    else if (mode == 1) LAUNCH_TN_GROUP(256, 128, 2);
+    else if (mode == 2) LAUNCH_TN_GROUP(256, 128, 3);
+    else LAUNCH_TN_GROUP(128, 256, 3);
+#undef LAUNCH_TN_GROUP
     VLP_CHECK_LAUNCH("vlp_gemm_tn_grouped");
     return VLP_OK;
 }
