@@ -89,6 +89,14 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BN
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+#ifdef VLP_NT_DEBUG
+    // start-stagger experiment: every other workgroup of an XCD (first round only) starts (dbg >> 8) / 10 us late, so that the store-bound
+    // epilogues of the two halves of the chip do not coincide
+    if ((p.dbg >> 8) && ((blockIdx.x >> 3) & 1) && blockIdx.x < 256) {
+        const uint64_t t0 = wall_clock64();
+        while (wall_clock64() - t0 < (uint64_t)(p.dbg >> 8) * 10u) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     const int nk = p.K / BK;
 
     // fragment read rows inside a tile

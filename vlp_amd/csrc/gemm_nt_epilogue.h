@@ -5,6 +5,16 @@
 // one 8-wide output vector of row m: bias, pre-activation store, activation, gelu'/relu-mask multiply, dropout, residual, store
 // SG (compile time) = the VLP_ACT_GELU_SAVE_GRAD form; it lives in its own kernel instantiations so that the generic epilogue keeps
 // its register footprint (the erf/exp pair + derivative of 8 elements in flight costs ~25 VGPRs: the 128-VGPR variants spilled).
+#ifdef VLP_NT_DEBUG
+DEVFN void st8_pol(const GemmNtParams& p, f16* dst, f16x8 v) {      // store cache-policy experiment: dbg & 32 = nontemporal, & 64 = sc1
+    if (p.dbg & 32) __builtin_nontemporal_store(v, reinterpret_cast<f16x8*>(dst));
+    else if (p.dbg & 64) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+    else st8(dst, v);
+}
+#define ST8_OUT(p, dst, v) st8_pol(p, dst, v)
+#else
+#define ST8_OUT(p, dst, v) st8(dst, v)
+#endif
 template <bool SG = false>
 DEVFN void nt_epilogue8(const GemmNtParams& p, int m, int nc, float* vv, uint32_t rkey, bool bias_done = false) {
     if (nc >= p.N) return;
@@ -33,8 +43,8 @@ DEVFN void nt_epilogue8(const GemmNtParams& p, int m, int nc, float* vv, uint32_
             for (int j = 0; j < 8; ++j)
                 if (nc + j >= p.N) { o[j] = (f16)0.f; d[j] = (f16)0.f; }
         }
-        st8(p.preact + (int64_t)m * p.ldp + nc, d);
-        st8(p.Y + (int64_t)m * p.ldy + nc, o);
+        ST8_OUT(p, p.preact + (int64_t)m * p.ldp + nc, d);
+        ST8_OUT(p, p.Y + (int64_t)m * p.ldy + nc, o);
         return;
     } else {
         if (p.preact) {
@@ -80,5 +90,5 @@ DEVFN void nt_epilogue8(const GemmNtParams& p, int m, int nc, float* vv, uint32_
     f16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (nc + j < p.N) ? (f16)vv[j] : (f16)0.f;
-    st8(p.Y + (int64_t)m * p.ldy + nc, o);
+    ST8_OUT(p, p.Y + (int64_t)m * p.ldy + nc, o);
 }
