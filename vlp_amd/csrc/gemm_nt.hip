@@ -25,6 +25,14 @@
 #define BK 64
 
 
+#ifdef VLP_NT_DEBUG
+// investigation build: wave 0 of every workgroup records the 100 MHz wall clock at phase boundaries (tools/nt_trace.py)
+__device__ unsigned long long g_nt_trace[4096 * 4];
+#define NT_TRACE(slot) do { if (wid == 0 && lane == 0 && blockIdx.x < 4096) g_nt_trace[blockIdx.x * 4 + (slot)] = wall_clock64(); } while (0)
+extern "C" int vlp_debug_read_nt_trace(void* dst, int64_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_nt_trace), bytes); }
+#else
+#define NT_TRACE(slot) do { } while (0)
+#endif
 DEVFN int swz_x(int r) { return r & 7; }
 DEVFN int swz_w(int r) { return (((r >> 4) & 3) << 1) | ((r >> 1) & 1); }
 
@@ -98,6 +106,7 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BN
     }
 #endif
     const int nk = p.K / BK;
+    NT_TRACE(0);
 
     // fragment read rows inside a tile
     // X tile (natural rows): row = wm*64 + 16*tm + li ; W tile (permuted rows): row = wn*64 + 16*(li>>2) + 4*tn + (li&3)
@@ -267,6 +276,7 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BN
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the clamped tail reloads must land before the LDS is released
     }
 
+    NT_TRACE(1);
 #ifdef VLP_NT_DEBUG
     if ((p.dbg & 4) && acc[0][0][0] != 12345.678f) return;
 #endif
@@ -300,6 +310,11 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BN
         for (int h = 0; h < 2; ++h)              // two 8-wide vectors through the shared epilogue (bias already added)
             nt_epilogue8<SG>(p, m, ncol0 + 8 * h, v + 8 * h, rkey, true);
     }
+#ifdef VLP_NT_DEBUG
+    NT_TRACE(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NT_TRACE(3);
+#endif
 }
 
 int vlp_gemm_nt_fill_params(const vlp_gemm_nt_args* a, GemmNtParams& p) {
