@@ -11,38 +11,37 @@
 #define LN_THREADS 256
 #define LN_WAVES 4
 
-template <int MAXJ>   // per-lane chunks of 8 halfs: H <= 512*MAXJ
+template <int NP>   // per-lane pieces of 4 halfs (piece k = columns 256k + 4*lane .. +3): H <= 256*NP; at H = 768 every lane holds 12 columns
 __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(
     const f16* __restrict__ x, int64_t ldx, const f16* __restrict__ gamma, const f16* __restrict__ beta,
     f16* __restrict__ y, int64_t ldy, float* __restrict__ mean, float* __restrict__ rstd, int M, int H, float eps, DropCtx drop) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * LN_WAVES;
-    const int nch = H >> 3;
     const float invH = 1.f / (float)H;
     for (int row = wave; row < M; row += nwaves) {
         const f16* xr = x + (int64_t)row * ldx;
-        float v[MAXJ][8];
+        float v[NP][4];
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int c = lane + 64 * j;
-            if (c < nch) {
-                f16x8 t = ld8(xr + c * 8);
+        for (int k = 0; k < NP; ++k) {
+            const int c = 256 * k + 4 * lane;
+            if (c < H) {
+                f16x4 t = ld4(xr + c);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { v[j][e] = (float)t[e]; s += v[j][e]; }
+                for (int e = 0; e < 4; ++e) { v[k][e] = (float)t[e]; s += v[k][e]; }
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+                for (int e = 0; e < 4; ++e) v[k][e] = 0.f;
             }
         }
         const float mu = wave_sum(s) * invH;
         float q = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j)
-            if (lane + 64 * j < nch) {
+        for (int k = 0; k < NP; ++k)
+            if (256 * k + 4 * lane < H) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float d = v[j][e] - mu; q += d * d; }
+                for (int e = 0; e < 4; ++e) { const float d = v[k][e] - mu; q += d * d; }
             }
         const float var = wave_sum(q) * invH;
         const float rs = 1.f / sqrtf(var + eps);
@@ -53,18 +52,30 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(
         f16* yr = y + (int64_t)row * ldy;
         const uint32_t rkey = drop.thresh ? drop_rowkey(drop, (uint64_t)row) : 0u;   // dropout element = (row, col)
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int c = lane + 64 * j;
-            if (c < nch) {
-                f16x8 gv = ld8(gamma + c * 8), bv = ld8(beta + c * 8), o;
-                float m8[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-                if (drop.thresh) drop_mult8(drop, rkey, (uint32_t)(c * 8), m8);
+        for (int k = 0; k < NP; ++k) {
+            const int c = 256 * k + 4 * lane;
+            if (c < H) {
+                f16x4 gv = ld4(gamma + c), bv = ld4(beta + c), o;
+                float m4[4] = {1.f, 1.f, 1.f, 1.f};
+                if (drop.thresh) drop_mult4(drop, rkey, (uint32_t)c, m4);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (f16)(((float)gv[e] * ((v[j][e] - mu) * rs) + (float)bv[e]) * m8[e]);
-                st8(yr + c * 8, o);
+                for (int e = 0; e < 4; ++e) o[e] = (f16)(((float)gv[e] * ((v[k][e] - mu) * rs) + (float)bv[e]) * m4[e]);
+                st4(yr + c, o);
             }
         }
     }
+}
+
+// one row per wave up to this many blocks (VLP_LN_BLOCKS overrides for A/B runs)
+static int ln_fwd_blocks(int M) {
+    static int cap = 0;
+    if (!cap) {
+        const char* e = getenv("VLP_LN_BLOCKS");
+        cap = e ? atoi(e) : 4096;
+        if (cap < 1) cap = 4096;
+    }
+    const int blocks = cdiv(M, LN_WAVES);
+    return blocks > cap ? cap : blocks;
 }
 
 extern "C" int vlp_layernorm_fwd(const vlp_layernorm_fwd_args* a, void* stream) {
@@ -73,15 +84,16 @@ extern "C" int vlp_layernorm_fwd(const vlp_layernorm_fwd_args* a, void* stream) 
     VLP_CHECK_ARG(a->ldx % 8 == 0 && a->ldy % 8 == 0 && a->ldx >= a->H && a->ldy >= a->H, "vlp_layernorm_fwd: leading dims");
     VLP_CHECK_ARG(((uintptr_t)a->x | (uintptr_t)a->y | (uintptr_t)a->gamma | (uintptr_t)a->beta) % 16 == 0, "vlp_layernorm_fwd: alignment");
     DropCtx d = make_drop(a->dropout_p, a->seed, a->rng_stream);
-    int blocks = cdiv(a->M, LN_WAVES);
-    if (blocks > 2048) blocks = 2048;
+    const int blocks = ln_fwd_blocks(a->M);
     hipStream_t s = (hipStream_t)stream;
-    if (a->H <= 1024)
-        hipLaunchKernelGGL(layernorm_fwd_kernel<2>, dim3(blocks), dim3(LN_THREADS), 0, s, (const f16*)a->x, a->ldx, (const f16*)a->gamma,
-                           (const f16*)a->beta, (f16*)a->y, a->ldy, a->mean, a->rstd, a->M, a->H, a->eps, d);
-    else
-        hipLaunchKernelGGL(layernorm_fwd_kernel<8>, dim3(blocks), dim3(LN_THREADS), 0, s, (const f16*)a->x, a->ldx, (const f16*)a->gamma,
-                           (const f16*)a->beta, (f16*)a->y, a->ldy, a->mean, a->rstd, a->M, a->H, a->eps, d);
+#define LAUNCH_LN_FWD(NP_)                                                                                                              \
+    hipLaunchKernelGGL(layernorm_fwd_kernel<NP_>, dim3(blocks), dim3(LN_THREADS), 0, s, (const f16*)a->x, a->ldx, (const f16*)a->gamma, \
+                       (const f16*)a->beta, (f16*)a->y, a->ldy, a->mean, a->rstd, a->M, a->H, a->eps, d)
+    if (a->H <= 768) LAUNCH_LN_FWD(3);
+    else if (a->H <= 1024) LAUNCH_LN_FWD(4);
+    else if (a->H <= 2048) LAUNCH_LN_FWD(8);
+    else LAUNCH_LN_FWD(16);
+#undef LAUNCH_LN_FWD
     VLP_CHECK_LAUNCH("vlp_layernorm_fwd");
     return VLP_OK;
 }
