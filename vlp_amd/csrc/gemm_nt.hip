@@ -230,6 +230,12 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BN
             const f16* xs = smem + buf * (XT + WT);
             const f16* ws = xs + XT;
             f16x8 xf0[4], wf0[4];
+#ifdef VLP_NT_DEBUG
+            if (p.dbg & 256) {          // no fragment reads at all (with 128: MFMAs + DMA only)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { xf0[t] = __builtin_bit_cast(f16x8, (u32x4){(uint32_t)kt, 1u, 2u, 3u}); wf0[t] = xf0[t]; }
+            } else
+#endif
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 xf0[t] = ld8(xs + xrow[t] * BK + ((g ^ swz_x(xrow[t])) << 3));
@@ -242,6 +248,17 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BN
             glds(min(kt + NS - 1, nk - 1), nbuf);
 #ifdef VLP_NT_DEBUG
             if (p.dbg & 1) { buf = (buf + 1 == NS) ? 0 : buf + 1; nbuf = (nbuf + 1 == NS) ? 0 : nbuf + 1; acc[0][0][0] += (float)xf0[0][0] + (float)wf0[0][0]; continue; }
+#endif
+#ifdef VLP_NT_DEBUG
+            if (p.dbg & 128) {          // half the fragment reads: the second half's MFMAs reuse the first half's operands (wrong results, LDS-read cost probe)
+#pragma unroll
+                for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+                    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < 4; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0[tn], xf0[tm], acc[tm][tn], 0, 0, 0);
+            } else
 #endif
             if (BN_T == 128) {          // 2 waves per SIMD: room for both fragment sets -- the second half's reads fly under the first half's MFMAs
                 f16x8 xf1[4], wf1[4];
