@@ -75,6 +75,7 @@ typedef struct {
                                             17 / 19 = variants 1 / 3 with a 4- / 3-stage LDS-DMA ring and counted vmcnt (17: latency hiding for skinny M);
                                             +8 = XCD-aware tile order;
                                             21 = variant 5 (256x256) as a 2-stage ring: one raw s_barrier per k tile, DMA issued right behind it, counted vmcnt.
+                                            53 = variant 5 with k tiles of 32 in a 4-stage ring (three stages in flight; measured slower than 21, kept for A/B runs).
                                             Every variant computes the same result. */
 } vlp_gemm_nt_args;
 int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream);

@@ -413,7 +413,8 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
         case 2: LAUNCH_NT(2, 128, 128, 1); break;
         case 4: LAUNCH_NT(2, 256, 128, 1); break;
         case 5:
-            if (a->variant & 16) LAUNCH_RING(256, 256, 2);
+            if ((a->variant & 48) == 48) { const int rc = vlp_gemm_nt_k32_launch(p, sg, s); if (rc != VLP_OK) return rc; }      /* 53 / 61: k tiles of 32, 4 stages */
+            else if (a->variant & 16) LAUNCH_RING(256, 256, 2);
             else LAUNCH_NT(1, 256, 256, 2);
             break;
         default: LAUNCH_NT(1, 128, 128, 2); break;
