@@ -411,7 +411,7 @@ def test_attention_dropout_exact_mask(gen):
 # =====================================================================================================
 # layernorm
 # =====================================================================================================
-@pytest.mark.parametrize("M,H", [(5, 768), (1000, 768), (300, 2048), (64, 64)])
+@pytest.mark.parametrize("M,H", [(5, 768), (1000, 768), (300, 2048), (64, 64), (129, 1032), (77, 520)])
 def test_layernorm_fwd_bwd(M, H, gen):
     x, gamma, beta = h16(M, H, scale=2.0, gen=gen), (1 + 0.1 * torch.randn(H, device=DEV, generator=gen)).half(), h16(H, scale=0.1, gen=gen)
     y = torch.empty_like(x)
@@ -430,6 +430,18 @@ def test_layernorm_fwd_bwd(M, H, gen):
     assert rel(dg.float(), g64.grad) < 3e-3 and rel(db.float(), b64.grad) < 3e-3
     K.layernorm_bwd(dy, x, gamma, mean, rstd, dx, dg, db, M, H, ws, beta=1)
     assert rel(dg.float(), 2 * g64.grad) < 4e-3
+
+
+@pytest.mark.parametrize("M,H", [(33, 4096), (10, 2056)])
+def test_layernorm_fwd_wide(M, H, gen):
+    """forward only: H up to 4096 (16 four-column pieces per lane); the backward stops at 2048"""
+    x, gamma, beta = h16(M, H, scale=2.0, gen=gen), (1 + 0.1 * torch.randn(H, device=DEV, generator=gen)).half(), h16(H, scale=0.1, gen=gen)
+    y = torch.empty_like(x)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    K.layernorm_fwd(x, gamma, beta, y, M, H, mean, rstd)
+    ref = O.layer_norm(x.double(), gamma.double(), beta.double())
+    assert rel(y.float(), ref) < 1.5e-3
+    assert rel(mean, x.double().mean(1)) < 1e-5
 
 
 @pytest.mark.parametrize("M,H", [(1000, 768), (37, 768), (4000, 1024)])

@@ -216,13 +216,15 @@ DEVFN int tn_swz(int r) { return ((r & 3) | (((r >> 3) & 1) << 2)) << 1; }
 
 // BN_T x BK_T output tile (each 128 or 256); one wave per 64x64 sub-tile -> 4 or 8 waves.  `bid` = linear tile index of this workgroup
 // inside the problem p (after any XCD remap): shared by the single-problem kernel and the grouped launch below.
-template <int BN_T, int BK_T, int NS = 2>      // NS = LDS stages of the ring (2: refill waits for vmcnt(0) every stage; 3: one more stage stays in flight)
+// NS = LDS stages of the ring (NS - 2 stages stay in flight across a stage's barrier), BM_T = contraction rows per stage (64 or 32: with 32 rows a
+// 128x128 tile fits FOUR stages in the 64 KiB that let two workgroups share a CU)
+template <int BN_T, int BK_T, int NS = 2, int BM_T = TN_BM>
 DEVFN void tn_glds_tile(const GemmTnParams& p, int bid, f16* smem) {
     constexpr int WK_ = BK_T / 64;
     constexpr int T = (BN_T / 64) * WK_ * 64;            // threads
-    constexpr int ATILE = TN_BM * BN_T, BTILE = TN_BM * BK_T;   // halfs
+    constexpr int ATILE = BM_T * BN_T, BTILE = BM_T * BK_T;   // halfs
     constexpr int ACH = BN_T / 8, BCH = BK_T / 8;        // 16-B chunks per tile row (16 or 32)
-    constexpr int AP = TN_BM * ACH / T, BP = TN_BM * BCH / T;   // staging passes
+    constexpr int AP = BM_T * ACH / T, BP = BM_T * BCH / T;   // staging passes
     constexpr int ARP = T / ACH, BRP = T / BCH;          // tile rows covered per pass
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -244,7 +246,7 @@ DEVFN void tn_glds_tile(const GemmTnParams& p, int bid, f16* smem) {
     const int k0 = ktile * BK_T;
     const int m_begin = split * p.rows_per_split;
     const int m_end = min(p.M, m_begin + p.rows_per_split);
-    const int nstages = (m_end - m_begin + TN_BM - 1) / TN_BM;
+    const int nstages = (m_end - m_begin + BM_T - 1) / BM_T;
 
     // staging: pass i covers tile rows ARP*i .. ; thread -> (row = ARP*i + tid/ACH, physical chunk = tid%ACH).  The swizzle acts on
     // the low 4 bits of the chunk index (one 256-byte bank row), so 512-byte rows behave like two independent 256-byte halves.
@@ -267,7 +269,7 @@ DEVFN void tn_glds_tile(const GemmTnParams& p, int bid, f16* smem) {
     const f16x8 ones = (f16x8){(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
 
     const uint32_t smem_lds = lds_addr_of(smem);
-    // per-thread DMA source of stage 0 (pass i); a stage advances every pointer by TN_BM rows -- one 64-bit add per DMA instead of a
+    // per-thread DMA source of stage 0 (pass i); a stage advances every pointer by BM_T rows -- one 64-bit add per DMA instead of a
     // row * pitch multiply
     const f16* asrc[AP];
     const f16* bsrc[BP];
@@ -278,10 +280,10 @@ DEVFN void tn_glds_tile(const GemmTnParams& p, int bid, f16* smem) {
     auto stage = [&](int st, int buf) {
         f16* as = smem + buf * (ATILE + BTILE);
         f16* bs = as + ATILE;
-        const int mbase = m_begin + st * TN_BM;
-        if (mbase + TN_BM <= m_end) {            // full stage (wave-uniform): LDS-DMA, 64 lanes = 1 KiB contiguous in LDS
+        const int mbase = m_begin + st * BM_T;
+        if (mbase + BM_T <= m_end) {            // full stage (wave-uniform): LDS-DMA, 64 lanes = 1 KiB contiguous in LDS
             const uint32_t as_l = smem_lds + (uint32_t)(buf * (ATILE + BTILE)) * 2u, bs_l = as_l + (uint32_t)ATILE * 2u;
-            const int64_t aoff = (int64_t)st * TN_BM * p.lda, boff = (int64_t)st * TN_BM * p.ldb;
+            const int64_t aoff = (int64_t)st * BM_T * p.lda, boff = (int64_t)st * BM_T * p.ldb;
 #pragma unroll
             for (int i = 0; i < AP; ++i) glds16(asrc[i] + aoff, as_l + (uint32_t)((ARP * i) * BN_T + wid * 512) * 2u);
 #pragma unroll
@@ -341,21 +343,26 @@ DEVFN void tn_glds_tile(const GemmTnParams& p, int bid, f16* smem) {
         for (int i = 0; i < NS - 1; ++i)
             if (i < nstages) stage(i, i);
         int buf = 0, nbuf = NS - 1;
+        const bool tail_ragged = ((m_end - m_begin) % BM_T) != 0;
         for (int st = 0; st < nstages; ++st) {
-            // stage st must have landed; with NS = 3 the next stage (if it exists and is a full DMA stage) may stay in flight.  The
-            // ragged last stage goes through registers + ds_write (compiler-tracked loads, waited for inside stage()), so its
-            // presence only lowers the number of outstanding DMA instructions -- then wait for everything.
-            if (NS == 3 && st + 1 < nstages && m_begin + (st + 2) * TN_BM <= m_end) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS) : "memory");
+            // stage st must have landed; up to NS - 2 younger FULL stages may stay in flight.  A ragged last stage goes through registers +
+            // ds_write (compiler-tracked loads, waited for -- with everything older -- inside stage()): once it is among the younger
+            // ones the queue has been drained already, and vmcnt(0) costs nothing.
+            const int left = nstages - 1 - st;
+            int younger = left < NS - 2 ? left : NS - 2;
+            if (tail_ragged && st + younger >= nstages - 1) younger = 0;
+            if (NS >= 4 && younger == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LPS) : "memory");
+            else if (NS >= 3 && younger >= 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             f16x8 x0[4], y0[4], x1[4], y1[4];
             read_frags(buf, 0, x0, y0);
             __builtin_amdgcn_sched_barrier(0);
             if (st + NS - 1 < nstages) stage(st + NS - 1, nbuf);
-            read_frags(buf, 1, x1, y1);
+            if (BM_T == 64) read_frags(buf, 1, x1, y1);
             __builtin_amdgcn_sched_barrier(0);
             mfma_frags(x0, y0);
-            mfma_frags(x1, y1);
+            if (BM_T == 64) mfma_frags(x1, y1);
             buf = (buf + 1 == NS) ? 0 : buf + 1;
             nbuf = (nbuf + 1 == NS) ? 0 : nbuf + 1;
         }
@@ -420,7 +427,7 @@ struct TnGroupParams {
     int count, total_tiles, xcd_remap;
 };
 
-template <int BN_T, int BK_T, int NS>
+template <int BN_T, int BK_T, int NS, int BM_T>
 __global__ __launch_bounds__((BN_T / 64) * (BK_T / 64) * 64, 2) void gemm_tn_grouped_kernel(TnGroupParams gp) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     int bid = blockIdx.x;
@@ -435,7 +442,7 @@ __global__ __launch_bounds__((BN_T / 64) * (BK_T / 64) * 64, 2) void gemm_tn_gro
     p.slab = nullptr; p.bias_slab = nullptr; p.bias_out = e.bias_out;
     p.M = e.M; p.N = e.N; p.K = e.K; p.beta = e.beta; p.splits = 1; p.rows_per_split = (e.M + TN_BM - 1) / TN_BM * TN_BM;
     p.tiles_k = e.tiles_k; p.tiles_n = 0; p.xcd_remap = 0; p.split_major = 0;
-    tn_glds_tile<BN_T, BK_T, NS>(p, bid - e.tile_begin, reinterpret_cast<f16*>(smem_raw));
+    tn_glds_tile<BN_T, BK_T, NS, BM_T>(p, bid - e.tile_begin, reinterpret_cast<f16*>(smem_raw));
 }
 
 // out[n,k] = (beta ? out : 0) + sum_s slab[s][n][k]; the tail of the grid reduces the fused bias partials [s][N]
@@ -580,10 +587,11 @@ static int tn_check_one(const vlp_gemm_tn_args* a) {
 extern "C" int vlp_gemm_tn_grouped(const vlp_gemm_tn_args* list, int32_t count, void* stream) {
     VLP_CHECK_ARG(list != nullptr && count >= 1 && count <= TN_GROUP_MAX, "vlp_gemm_tn_grouped: 1..%d problems", TN_GROUP_MAX);
     // tile shape / ring depth of the grouped launch: 0 = 128x128 tiles, 2 stages (two 4-wave workgroups per CU); 1 = 256x128, 2 stages;
-    // 2 = 256x128, 3 stages; 3 = 128x256, 3 stages (8-wave workgroups, one per CU).  VLP_TN_GROUP_MODE overrides (A/B runs).
+    // 2 = 256x128, 3 stages; 3 = 128x256, 3 stages (8-wave workgroups, one per CU); 4 = 128x128, FOUR stages of 32 contraction rows (same 64 KiB:
+    // two workgroups per CU, three stages in flight).  VLP_TN_GROUP_MODE overrides (A/B runs).
     static int mode = -1;
-    if (mode < 0) { const char* e = getenv("VLP_TN_GROUP_MODE"); mode = e ? atoi(e) : 0; if (mode < 0 || mode > 3) mode = 0; }
-    const int bn = mode == 0 ? 128 : (mode == 3 ? 128 : 256), bk = mode == 3 ? 256 : 128, ns = mode >= 2 ? 3 : 2;
+    if (mode < 0) { const char* e = getenv("VLP_TN_GROUP_MODE"); mode = e ? atoi(e) : 0; if (mode < 0 || mode > 4) mode = 0; }
+    const int bn = (mode == 0 || mode >= 3) ? 128 : 256, bk = mode == 3 ? 256 : 128;
     TnGroupParams gp;
     int tiles = 0;
     for (int i = 0; i < count; ++i) {
@@ -600,17 +608,18 @@ extern "C" int vlp_gemm_tn_grouped(const vlp_gemm_tn_args* list, int32_t count, 
     }
     for (int i = count; i < TN_GROUP_MAX; ++i) { gp.e[i] = gp.e[0]; gp.e[i].tile_begin = 0x7fffffff; }
     gp.count = count; gp.total_tiles = tiles; gp.xcd_remap = 1;
-#define LAUNCH_TN_GROUP(BNT, BKT, NSV)                                                                                                  \
+#define LAUNCH_TN_GROUP(BNT, BKT, NSV, BMV)                                                                                             \
     do {                                                                                                                                \
-        const size_t smem = (size_t)(NSV) * TN_BM * ((BNT) + (BKT)) * sizeof(f16);                                                      \
+        const size_t smem = (size_t)(NSV) * (BMV) * ((BNT) + (BKT)) * sizeof(f16);                                                      \
         static bool attr = false;                                                                                                       \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<BNT, BKT, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; } \
-        hipLaunchKernelGGL((gemm_tn_grouped_kernel<BNT, BKT, NSV>), dim3(tiles), dim3(((BNT) / 64) * ((BKT) / 64) * 64), smem, (hipStream_t)stream, gp); \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<BNT, BKT, NSV, BMV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; } \
+        hipLaunchKernelGGL((gemm_tn_grouped_kernel<BNT, BKT, NSV, BMV>), dim3(tiles), dim3(((BNT) / 64) * ((BKT) / 64) * 64), smem, (hipStream_t)stream, gp); \
     } while (0)
-    if (mode == 0) LAUNCH_TN_GROUP(128, 128, 2);
-    else if (mode == 1) LAUNCH_TN_GROUP(256, 128, 2);
-    else if (mode == 2) LAUNCH_TN_GROUP(256, 128, 3);
-    else LAUNCH_TN_GROUP(128, 256, 3);
+    if (mode == 0) LAUNCH_TN_GROUP(128, 128, 2, 64);
+    else if (mode == 1) LAUNCH_TN_GROUP(256, 128, 2, 64);
+    else if (mode == 2) LAUNCH_TN_GROUP(256, 128, 3, 64);
+    else if (mode == 3) LAUNCH_TN_GROUP(128, 256, 3, 64);
+    else LAUNCH_TN_GROUP(128, 128, 4, 32);
 #undef LAUNCH_TN_GROUP
     VLP_CHECK_LAUNCH("vlp_gemm_tn_grouped");
     return VLP_OK;
