@@ -123,38 +123,52 @@ __global__ __launch_bounds__(256) void fused_adam_kernel(vlp_fused_adam_args a) 
     const float inv = 1.f / combined;
     const f16* g = (const f16*)a.g16;
     f16* p16 = (f16*)a.p16;
-    const int64_t n8 = a.n >> 3;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
-        const f16x8 gv = ld8(g + i * 8);
-        float pp[8], mm[8], vv[8];
-        {
-            const f32x4 p0 = *reinterpret_cast<const f32x4*>(a.p32 + i * 8), p1 = *reinterpret_cast<const f32x4*>(a.p32 + i * 8 + 4);
-            const f32x4 m0 = *reinterpret_cast<const f32x4*>(a.m + i * 8), m1 = *reinterpret_cast<const f32x4*>(a.m + i * 8 + 4);
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(a.v + i * 8), v1 = *reinterpret_cast<const f32x4*>(a.v + i * 8 + 4);
+    // a wave covers 512 consecutive elements per iteration as two runs of 256: lane l owns elements 4l..4l+3 of each run, so every
+    // load / store instruction of the wave touches one contiguous 1 KiB (fp32 arrays) or 512 B (fp16 arrays) span -- with 8 consecutive
+    // elements per lane the two 16-byte halves of a lane's fp32 data sat 32 bytes apart in every instruction.  Same arithmetic per element.
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t base = wave * 512; base < a.n; base += nwaves * 512) {
+        f16x4 gv[2];
+        f32x4 p0[2], m0[2], v0[2];
+        bool ok[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { pp[e] = p0[e]; pp[4 + e] = p1[e]; mm[e] = m0[e]; mm[4 + e] = m1[e]; vv[e] = v0[e]; vv[4 + e] = v1[e]; }
+        for (int h = 0; h < 2; ++h) {            // all eight loads of the wave's 512 elements are in flight before the first use
+            const int64_t i = base + 256 * h + 4 * lane;
+            ok[h] = i < a.n;                      // n is a multiple of 8, i of 4: a run is whole or absent per lane
+            if (ok[h]) {
+                gv[h] = ld4(g + i);
+                p0[h] = *reinterpret_cast<const f32x4*>(a.p32 + i);
+                m0[h] = *reinterpret_cast<const f32x4*>(a.m + i);
+                v0[h] = *reinterpret_cast<const f32x4*>(a.v + i);
+            }
         }
-        f16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float sg = (float)gv[e] * inv;
-            mm[e] = a.b1 * mm[e] + (1.f - a.b1) * sg;
-            vv[e] = a.b2 * vv[e] + (1.f - a.b2) * sg * sg;
-            const float denom = a.eps_inside_sqrt ? sqrtf(vv[e] + a.eps) : sqrtf(vv[e]) + a.eps;
-            pp[e] = pp[e] - step_size * (mm[e] / denom + a.decay * pp[e]);
-            // the fp16 model copy is the rounding of the STORED fp32 master (apex: p_copy = (half) p).  Without the opaque copy the
-            // compiler folds the last fma and the conversion into v_fma_mixlo_f16 (one rounding of the exact fma), which differs from
-            // half(master) in double-rounding cases -- a resumed run, which can only rebuild the copy from the master, would diverge.
-            asm volatile("" : "+v"(pp[e]));
-            o[e] = (f16)pp[e];
+        for (int h = 0; h < 2; ++h) {
+            if (!ok[h]) continue;
+            const int64_t i = base + 256 * h + 4 * lane;
+            float pp[4], mm[4], vv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pp[e] = p0[h][e]; mm[e] = m0[h][e]; vv[e] = v0[h][e]; }
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float sg = (float)gv[h][e] * inv;
+                mm[e] = a.b1 * mm[e] + (1.f - a.b1) * sg;
+                vv[e] = a.b2 * vv[e] + (1.f - a.b2) * sg * sg;
+                const float denom = a.eps_inside_sqrt ? sqrtf(vv[e] + a.eps) : sqrtf(vv[e]) + a.eps;
+                pp[e] = pp[e] - step_size * (mm[e] / denom + a.decay * pp[e]);
+                // the fp16 model copy is the rounding of the STORED fp32 master (apex: p_copy = (half) p).  Without the opaque copy the
+                // compiler folds the last fma and the conversion into v_fma_mixlo_f16 (one rounding of the exact fma), which differs from
+                // half(master) in double-rounding cases -- a resumed run, which can only rebuild the copy from the master, would diverge.
+                asm volatile("" : "+v"(pp[e]));
+                o[e] = (f16)pp[e];
+            }
+            *reinterpret_cast<f32x4*>(a.p32 + i) = (f32x4){pp[0], pp[1], pp[2], pp[3]};
+            *reinterpret_cast<f32x4*>(a.m + i) = (f32x4){mm[0], mm[1], mm[2], mm[3]};
+            *reinterpret_cast<f32x4*>(a.v + i) = (f32x4){vv[0], vv[1], vv[2], vv[3]};
+            st4(p16 + i, o);
         }
-        *reinterpret_cast<f32x4*>(a.p32 + i * 8) = (f32x4){pp[0], pp[1], pp[2], pp[3]};
-        *reinterpret_cast<f32x4*>(a.p32 + i * 8 + 4) = (f32x4){pp[4], pp[5], pp[6], pp[7]};
-        *reinterpret_cast<f32x4*>(a.m + i * 8) = (f32x4){mm[0], mm[1], mm[2], mm[3]};
-        *reinterpret_cast<f32x4*>(a.m + i * 8 + 4) = (f32x4){mm[4], mm[5], mm[6], mm[7]};
-        *reinterpret_cast<f32x4*>(a.v + i * 8) = (f32x4){vv[0], vv[1], vv[2], vv[3]};
-        *reinterpret_cast<f32x4*>(a.v + i * 8 + 4) = (f32x4){vv[4], vv[5], vv[6], vv[7]};
-        st8(p16 + i * 8, o);
     }
 }
 extern "C" int vlp_fused_adam(const vlp_fused_adam_args* a, void* stream) {
