@@ -82,12 +82,12 @@ def test_gemm_nt_plain(variant, M, N, K, gen):
         assert float(y[:, N:].abs().max()) == 0.0        # padding columns are written as zero
 
 
-@pytest.mark.parametrize("variant", [6, 7, 14, 15, 22, 23, 54, 17, 19, 27, 21, 29, 53, 61])
+@pytest.mark.parametrize("variant", [6, 7, 14, 15, 22, 23, 54, 17, 19, 27, 21, 29, 53, 61, 64, 65, 66, 67, 68, 69, 70, 71, 72, 76, 78])
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 768, 768), (77, 1000, 192), (256, 2304, 768), (515, 520, 1664),
                                    (10688, 768, 3072), (10688, 2304, 768)])
 def test_gemm_nt_phased(variant, M, N, K, gen):
     """Phased 256-row kernels (gemm_nt_ph.hip: counted-vmcnt LDS-DMA pipeline with two staggered wave groups) and the ring kernels of
-    gemm_nt.hip (17 / 19 / 21, +8 XCD order).  Repeated launches
+    gemm_nt.hip (17 / 19 / 21, +8 XCD order), and the wave-pipelined family of gemm_nt_wp.hip (64 + cfg, +8 XCD order).  Repeated launches
     on the same inputs must be bit-identical (a race between DMA and fragment reads would show up as run-to-run differences)."""
     Kd = K
     from vlp_amd import _lib as K
@@ -140,7 +140,7 @@ def test_gemm_nt_splitk(M, N, K, splits, gen):
         K.gemm_nt_splitk(x, w, y, M, N, Kd, splits, ws[:16])                # workspace too small is refused
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 64, 65, 66, 67, 68, 69, 70, 71])
 def test_gemm_nt_asymmetric_identity(variant):
     """A = I against an asymmetric B catches swapped row/col in the MFMA C-layout handling."""
     M = N = Kd = 128
@@ -151,7 +151,7 @@ def test_gemm_nt_asymmetric_identity(variant):
     assert torch.equal(y, w.t().contiguous())
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, 6, 7, 19, 27, 29, 61])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, 6, 7, 19, 27, 29, 61, 64, 65, 66, 67, 68, 69, 70, 71])
 def test_gemm_nt_epilogues(variant, gen):
     M, N, Kd = 200, 384, 256
     x, w = h16(M, Kd, gen=gen), h16(N, Kd, scale=0.06, gen=gen)

@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 3: correctness of the wave-pipelined NT family + cold-operand lab against the rings.  usage: tools/gpu_wp_lab.sh [variants]
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+V=${1:-27,29,72,73,74,75,76,77,78,79}
+timeout 900 python -m pytest tests/test_00_kernels_gpu.py -x -q -k "gemm_nt_phased or gemm_nt_asymmetric or gemm_nt_epilogues" 2>&1 | tail -15 | tee gpurun_out/wp_tests.log
+timeout 600 python tools/nt_lab.py --rotate=12 --variants=$V 2>&1 | tee gpurun_out/wp_lab.log

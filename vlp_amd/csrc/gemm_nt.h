@@ -28,6 +28,9 @@ int vlp_gemm_nt_ph_launch(GemmNtParams& p, int bn, int mode, hipStream_t s);
 // 256x256 tile, k tiles of 32, 4-stage ring (gemm_nt_k32.hip); p.xcd_remap honoured
 int vlp_gemm_nt_k32_launch(GemmNtParams& p, bool sg, hipStream_t s);
 
+// wave-pipelined kernels (gemm_nt_wp.hip): cfg 0..7, see the table there; p.xcd_remap honoured
+int vlp_gemm_nt_wp_launch(GemmNtParams& p, int cfg, bool sg, hipStream_t s);
+
 // argument validation + parameter block of vlp_gemm_nt (shared by the split-K entry point)
 int vlp_gemm_nt_fill_params(const vlp_gemm_nt_args* a, GemmNtParams& p);
 // split-K kernels (gemm_nt_splitk.hip)

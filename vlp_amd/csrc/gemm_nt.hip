@@ -392,29 +392,38 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
 #define LAUNCH_RING(BMT, BNT, NSV) \
     do { if (sg) LAUNCH_NT_(3, BMT, BNT, NSV, true, NSV); else LAUNCH_NT_(3, BMT, BNT, NSV, false, NSV); } while (0)
     const bool sg = a->act == VLP_ACT_GELU_SAVE_GRAD;
+    int variant = a->variant;
+    // the wave-pipelined family carries the light epilogues + save-grad GeLU; anything else (erf / tanh in the epilogue) runs on the rings
+    if ((variant & 64) && !sg && !nt_epilogue_is_light(p)) variant = (a->N > 1024) ? 29 : 27;
     if (sg) {
         VLP_CHECK_ARG(!a->residual && a->mul_mode == VLP_MUL_NONE && a->dropout_p == 0.f,
                       "vlp_gemm_nt: VLP_ACT_GELU_SAVE_GRAD fuses bias + gelu + derivative only (no residual / multiplier / dropout)");
-        VLP_CHECK_ARG((a->variant & 7) != 6 && (a->variant & 7) != 7, "vlp_gemm_nt: VLP_ACT_GELU_SAVE_GRAD is not provided by the phased variants (6, 7)");
+        VLP_CHECK_ARG((variant & 64) || ((variant & 7) != 6 && (variant & 7) != 7), "vlp_gemm_nt: VLP_ACT_GELU_SAVE_GRAD is not provided by the phased variants (6, 7)");
     }
-    p.xcd_remap = (a->variant & 8) ? 1 : 0;
-    switch (a->variant & 7) {
+    p.xcd_remap = (variant & 8) ? 1 : 0;
+    if (variant & 64) {          // wave-pipelined family (gemm_nt_wp.hip): 64 + cfg (+ 8 = XCD-aware tile order)
+        const int rc = vlp_gemm_nt_wp_launch(p, variant & 7, sg, s);
+        if (rc != VLP_OK) return rc;
+        VLP_CHECK_LAUNCH("vlp_gemm_nt");
+        return VLP_OK;
+    }
+    switch (variant & 7) {
         case 6: case 7: {
-            const int rc = vlp_gemm_nt_ph_launch(p, (a->variant & 7) == 6 ? 256 : 128, (a->variant >> 4) & 3, s);
+            const int rc = vlp_gemm_nt_ph_launch(p, (variant & 7) == 6 ? 256 : 128, (variant >> 4) & 3, s);
             if (rc != VLP_OK) return rc;
             break;
         }
         case 0: LAUNCH_NT(0, 128, 128, 2); break;
-        case 1: if (a->variant & 16) LAUNCH_NT(3, 128, 128, 4); else LAUNCH_NT(1, 128, 128, 2); break;
+        case 1: if (variant & 16) LAUNCH_NT(3, 128, 128, 4); else LAUNCH_NT(1, 128, 128, 2); break;
         case 3:
-            if (a->variant & 16) LAUNCH_NT(3, 256, 128, 3);
+            if (variant & 16) LAUNCH_NT(3, 256, 128, 3);
             else LAUNCH_NT(1, 256, 128, 2);
             break;
         case 2: LAUNCH_NT(2, 128, 128, 1); break;
         case 4: LAUNCH_NT(2, 256, 128, 1); break;
         case 5:
-            if ((a->variant & 48) == 48) { const int rc = vlp_gemm_nt_k32_launch(p, sg, s); if (rc != VLP_OK) return rc; }      /* 53 / 61: k tiles of 32, 4 stages */
-            else if (a->variant & 16) LAUNCH_RING(256, 256, 2);
+            if ((variant & 48) == 48) { const int rc = vlp_gemm_nt_k32_launch(p, sg, s); if (rc != VLP_OK) return rc; }      /* 53 / 61: k tiles of 32, 4 stages */
+            else if (variant & 16) LAUNCH_RING(256, 256, 2);
             else LAUNCH_NT(1, 256, 256, 2);
             break;
         default: LAUNCH_NT(1, 128, 128, 2); break;

@@ -15,7 +15,12 @@ DEVFN void st8_pol(const GemmNtParams& p, f16* dst, f16x8 v) {      // store cac
 #else
 #define ST8_OUT(p, dst, v) st8(dst, v)
 #endif
-template <bool SG = false>
+// LIGHT (compile time): the caller guarantees act is NONE / RELU and mul_mode is not GELU_GRAD (nt_epilogue_is_light): the erf / exp /
+// tanh expansions are compiled out -- the wave-pipelined kernels inline this function 16-32 times per lane.
+static inline bool nt_epilogue_is_light(const GemmNtParams& p) {
+    return (p.act == VLP_ACT_NONE || p.act == VLP_ACT_RELU) && p.mulmode != VLP_MUL_GELU_GRAD;
+}
+template <bool SG = false, bool LIGHT = false>
 DEVFN void nt_epilogue8(const GemmNtParams& p, int m, int nc, float* vv, uint32_t rkey, bool bias_done = false) {
     if (nc >= p.N) return;
     if (p.bias && !bias_done) {
@@ -55,20 +60,20 @@ DEVFN void nt_epilogue8(const GemmNtParams& p, int m, int nc, float* vv, uint32_
 #pragma unroll
             for (int j = 0; j < 8; ++j) vv[j] = (float)z[j];      // the activation sees the fp16-rounded pre-activation (as backward will)
         }
-        if (p.act == VLP_ACT_GELU) {
+        if (!LIGHT && p.act == VLP_ACT_GELU) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) vv[j] = gelu_f(vv[j]);
         } else if (p.act == VLP_ACT_RELU) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) vv[j] = fmaxf(vv[j], 0.f);
-        } else if (p.act == VLP_ACT_TANH) {
+        } else if (!LIGHT && p.act == VLP_ACT_TANH) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) vv[j] = tanhf(vv[j]);
         }
     }
     if (p.mulmode != VLP_MUL_NONE) {
         const f16x8 s = ld8(p.mulsrc + (int64_t)m * p.ldm + nc);
-        if (p.mulmode == VLP_MUL_GELU_GRAD) {
+        if (!LIGHT && p.mulmode == VLP_MUL_GELU_GRAD) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) vv[j] *= gelu_grad_f((float)s[j]);
         } else if (p.mulmode == VLP_MUL_PLAIN) {
