@@ -76,7 +76,11 @@ typedef struct {
                                             +8 = XCD-aware tile order;
                                             21 = variant 5 (256x256) as a 2-stage ring: one raw s_barrier per k tile, DMA issued right behind it, counted vmcnt.
                                             53 = variant 5 with k tiles of 32 in a 4-stage ring (three stages in flight; measured slower than 21, kept for A/B runs).
-                                            Every variant computes the same result. */
+                                            64 + cfg (+ 8 = XCD-aware tile order; cfg 8.. = 192 + cfg - 8): wave-pipelined family (gemm_nt_wp.hip: 32x32x16 MFMA,
+                                            128x128 / 128x64 / 64x64 wave tiles, fragments read one or two k16 steps ahead of their MFMAs, LDS-transposed epilogue
+                                            with whole-line stores; cfg table in that file).  They carry the bias / ReLU / multiplier / dropout / residual and
+                                            save-grad GeLU epilogues; a call that needs erf / tanh in the epilogue runs on the rings (27 / 29) instead.
+                                            Every variant computes the same result (up to the fp32 summation order). */
 } vlp_gemm_nt_args;
 int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream);
 /* Split-K form for skinny problems (incremental decoding, M = 128..640 rows: only N/128 output tiles): the k range is cut into `splits`

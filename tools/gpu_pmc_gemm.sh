@@ -14,8 +14,8 @@ by = collections.OrderedDict()
 for d in ("/tmp/pg1", "/tmp/pg2", "/tmp/pg3", "/tmp/pg4"):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            name = r["Kernel_Name"].split("(")[0][-34:]
-            if "gemm" not in name: continue
+            if "gemm" not in r["Kernel_Name"]: continue
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("gemm_nt_", "")[-44:]
             by.setdefault((name, r.get("Grid_Size", ""), int(r["Dispatch_Id"])), {})[r["Counter_Name"]] = float(r["Counter_Value"])
 groups = collections.OrderedDict()
 for (name, grid, d), c in by.items():
@@ -24,6 +24,6 @@ for (name, grid), lst in groups.items():
     lst.sort(key=lambda t: t[0])
     c = lst[-1][1]
     wc = max(c.get("SQ_WAVE_CYCLES", 1), 1)
-    print("%-34s grid=%-8s " % (name, grid) + " ".join("%s=%.4g" % (k.replace("SQ_", ""), (v / wc if k.startswith("SQ_") and k != "SQ_WAVE_CYCLES" else v)) for k, v in sorted(c.items())))
+    print("%-44s grid=%-8s " % (name, grid) + " ".join("%s=%.4g" % (k.replace("SQ_", ""), (v / wc if k.startswith("SQ_") and k != "SQ_WAVE_CYCLES" else v)) for k, v in sorted(c.items())))
 PY
 for f in gpurun_out/pg?.err; do grep -i "error\|invalid\|unknown\|not found" $f | head -3; done

@@ -68,7 +68,7 @@ def main():
         for v in variants:
             if v < 64 and v & 7 == 5 and n < 1024:
                 continue
-            if v >= 64 and (v & 7) < 4 and n < 1024:      # wave-pipelined 256x256 tiles: 126 workgroups at N = 768
+            if 64 <= v < 128 and (v & 7) < 4 and n < 1024:      # wave-pipelined 256x256 tiles: 126 workgroups at N = 768
                 continue
             ctr = [0]
 

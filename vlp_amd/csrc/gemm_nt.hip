@@ -395,14 +395,15 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
     int variant = a->variant;
     // the wave-pipelined family carries the light epilogues + save-grad GeLU; anything else (erf / tanh in the epilogue) runs on the rings
     if ((variant & 64) && !sg && !nt_epilogue_is_light(p)) variant = (a->N > 1024) ? 29 : 27;
+    // the phased kernels (6, 7) do not instantiate the save-grad epilogue: same fallback instead of an error for a table / override entry
+    if (sg && !(variant & 64) && ((variant & 7) == 6 || (variant & 7) == 7)) variant = (a->N > 1024) ? 29 : 27;
     if (sg) {
         VLP_CHECK_ARG(!a->residual && a->mul_mode == VLP_MUL_NONE && a->dropout_p == 0.f,
                       "vlp_gemm_nt: VLP_ACT_GELU_SAVE_GRAD fuses bias + gelu + derivative only (no residual / multiplier / dropout)");
-        VLP_CHECK_ARG((variant & 64) || ((variant & 7) != 6 && (variant & 7) != 7), "vlp_gemm_nt: VLP_ACT_GELU_SAVE_GRAD is not provided by the phased variants (6, 7)");
     }
     p.xcd_remap = (variant & 8) ? 1 : 0;
     if (variant & 64) {          // wave-pipelined family (gemm_nt_wp.hip): 64 + cfg (+ 8 = XCD-aware tile order)
-        const int rc = vlp_gemm_nt_wp_launch(p, variant & 7, sg, s);
+        const int rc = vlp_gemm_nt_wp_launch(p, (variant & 7) + ((variant & 128) ? 8 : 0), sg, s);
         if (rc != VLP_OK) return rc;
         VLP_CHECK_LAUNCH("vlp_gemm_nt");
         return VLP_OK;

@@ -1,25 +1,25 @@
-// Wave-pipelined NT GEMM for gfx950:  Y[M,N] = epi( alpha * X[M,K] . W[N,K]^T ), same contract and epilogue as gemm_nt.hip
+// Wave-pipelined NT GEMM for gfx950:  Y[M,N] = epi( alpha * X[M,K] . W[N,K]^T ), same contract as gemm_nt.hip
 // (replaces the nn.Linear forwards / dgrads listed there: modeling.py:270-272, :314, :341, :354, :432, :481, :1003-1029).
 //
 // Why a third kernel family.  The rings of gemm_nt.hip give every wave a 64x64 output in arch VGPRs and run "barrier -> all fragment
-// reads -> all MFMAs" per k tile: both waves of a SIMD are in the same phase, so the matrix pipe idles while the LDS serves 128 KB of
-// fragment reads, and the refill DMA competes with those reads (profiles/r02_nt_loop_decomposition.txt: reads +0.17 us and DMA
-// +0.2 us ADD to the 0.56 us of MFMAs per k tile).  Here the loop is software-pipelined INSIDE the wave:
-//   * 256 x BN_T block tile (BN_T = 256 | 128), wave tiles of 128x128 / 128x64 (4 waves, one per SIMD, up to 256 fp32 accumulators
-//     in the unified VGPR/AGPR file) or 128x64 / 64x64 (8 waves), built from v_mfma_f32_32x32x16_f16;
-//   * a k tile (BK_T = 64 | 32) is walked in k16 steps; the fragments of step s+1 are read (ds_read_b128, double-buffered registers)
-//     BETWEEN the MFMAs of step s, so the pipe never waits for the LDS and the reads are spread over the whole tile;
-//   * one raw s_barrier per k tile, placed inside the last step: it publishes stage kt+1 (counted vmcnt: the younger stages stay in
-//     flight) and frees slot kt, which is refilled with stage kt+NS by LDS-DMA (global_load_lds_dwordx4, SGPR base + 32-bit lane
-//     offset, issued through inline asm so the compiler's waitcnt pass does not drain the queue -- common.h);
-//   * DMA issue policy: SPREAD = 1 issues the whole stage right behind the barrier (needed with 2 stages), SPREAD = S spreads it over
-//     the S k16 steps that follow; LOADER = true adds four DMA-only waves (one per SIMD) so the MFMA waves never wait on VMEM issue.
+// reads -> all MFMAs" per k tile.  Here the loop is software-pipelined INSIDE the wave and the ring is shaped by what round 3 measured
+// (profiles/r03_nt_wp_decomposition.txt, tools/dma_path_bench.hip):
+//   * 256 x BN_T block tile (BN_T = 256 | 128), k tiles of 64, wave tiles of 128x128 / 128x64 (4 waves, one per SIMD, up to 256 fp32
+//     accumulators in AGPRs) or 128x64 / 64x64 (8 waves), built from v_mfma_f32_32x32x16_f16;
+//   * a k tile is walked in four k16 steps; the fragments of step s+1 are read (ds_read_b128, double-buffered registers) BETWEEN the
+//     MFMAs of step s, one raw s_barrier per k tile sits inside the last step (counted vmcnt: the younger stages stay in flight);
+//   * the staging side, not the matrix pipe, bounds these GEMMs: a CU streams cold operands at (bytes in flight) / (1.3 - 1.8 us), the
+//     same through LDS-DMA or through VGPRs.  The X stream (activations: HBM / Infinity Cache) is the slow one, W hits L2.  ROLES = true
+//     therefore gives X and W their OWN rings -- X deep (NSX slots), W shallow (NSW = 2) inside the same 160 KiB -- and lets half of the
+//     waves issue only X pieces and the other half only W pieces: vmcnt is per wave and in order, so a wave that mixed the two streams
+//     would have to drain its deep X stages every time it waits for the young W stage.
 // The MFMA computes Y^T tiles (A operand = W rows, B operand = X rows): in the 32x32 C/D layout (col = lane & 31,
-// row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) a lane then owns ONE output row m per m-tile; with the W rows of the wave's slice
-// visited in the order  n = 16 TN i2 + 16 tn + 4 (i >> 3) + (i & 3)  (i = A row, i2 = bit 2 of i) the TN tiles x 16 registers of a
-// lane are 16 TN consecutive n: bias / residual / multiplier inputs are read and Y is written as 16-byte vectors from registers.
-// LDS rows are BK_T halfs (128 | 64 bytes) with a 16-byte-chunk XOR swizzle on lane bits (4,3,1) | (4,3), applied on the DMA
-// source address (the LDS destination of an LDS-DMA is lane-linear): every ds_read_b128 lane group touches 16 distinct slots.
+// row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) a lane owns ONE output row per m-tile and, with the W rows of the wave's slice
+// visited in the order  n = 16 TN i2 + 16 tn + 4 (i >> 3) + (i & 3)  (i = A row, i2 = bit 2 of i), 16 TN consecutive n.
+// LDS rows are 128 bytes with a 16-byte-chunk XOR swizzle on lane bits (4,3,1), applied on the DMA source address (the LDS
+// destination of an LDS-DMA is lane-linear): every ds_read_b128 lane group touches 16 distinct slots.
+// Epilogue: each wave transposes its tile through LDS (fp32, one 32-row m-tile at a time) so that 4 TN lanes cover one row: residual /
+// multiplier loads and the Y store are whole 128-byte lines (in the accumulator layout a store touched 64 rows x 16 bytes: 25-29 us).
 #include <type_traits>
 
 #include "common.h"
@@ -35,6 +35,7 @@ DEVFN void static_for(F&& f) {
         static_for<I + 1, N>(f);
     }
 }
+template <int V> using IC = std::integral_constant<int, V>;
 
 // LDS-DMA with a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset
 DEVFN void glds16_s(const char* sbase, uint32_t voff, uint32_t lds_dst) {
@@ -42,40 +43,44 @@ DEVFN void glds16_s(const char* sbase, uint32_t voff, uint32_t lds_dst) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(voff), "s"(sbase) : "memory", "m0");
 }
 #define WP_SCHED() __builtin_amdgcn_sched_barrier(0)
+// investigation builds (tools/build_wp_dbg.sh): WP_DBG bit 0 = no MFMAs, 1 = no DMA, 2 = no epilogue, 3 = no fragment reads,
+// 4 = fragment reads issued (asm, never waited for except at the barrier) while the MFMAs run on constant fragments: issue cost without latency
+#ifndef WP_DBG
+#define WP_DBG 0
+#endif
 
-template <int BK_T>
-DEVFN int wp_swz(int r) {      // XOR applied to the 16-byte chunk index of LDS row r (both operands: bits 4,3,1 | 4,3 of the reading lane)
-    if constexpr (BK_T == 64) return (((r >> 4) & 1) << 2) | (((r >> 3) & 1) << 1) | ((r >> 1) & 1);
-    else return (r >> 3) & 3;
-}
-template <int BK_T>
-DEVFN int wp_swz_w(int R) {    // the same lane bits seen from the W tile's row index (rows are visited in permuted order)
-    if constexpr (BK_T == 64) return (R >> 1) & 7;
-    else return (R >> 2) & 3;
-}
+DEVFN int wp_swz(int r) { return (((r >> 4) & 1) << 2) | (((r >> 3) & 1) << 1) | ((r >> 1) & 1); }   // X tile row -> chunk XOR (lane bits 4,3,1)
+DEVFN int wp_swz_w(int R) { return (R >> 1) & 7; }                                                    // the same lane bits seen from the permuted W row
 
-// BN_T: columns of the block tile; WGM x WGN: compute waves; BK_T: k per stage; NS: ring slots; SPREAD: 1 | BK_T / 16; LOADER: 4 extra
-// DMA-only waves; SG: save-grad GeLU epilogue; PB: MFMAs of the barrier step issued in front of the barrier
-template <int BN_T, int WGM, int WGN, int BK_T, int NS, int SPREAD, bool LOADER, bool SG, int PB>
-__global__ __launch_bounds__((WGM * WGN + (LOADER ? 4 : 0)) * 64, (WGM * WGN + (LOADER ? 4 : 0)) / 4) void gemm_nt_wp_kernel(GemmNtParams p) {
+// what a step may issue: a group of X stage kx into X slot sx (if dox), a group of W stage kw into W slot sw (if dow)
+struct WpDma { int kx, sx, kw, sw; bool dox, dow; };
+
+// BN_T: columns of the block tile; WGM x WGN: waves; NSX / NSW: slots of the X / W ring; ROLES: waves 0 .. NW/2-1 issue the X pieces,
+// the others the W pieces (needed when NSX != NSW); SPREAD: rings with >= 3 slots issue a stage over the four k16 steps behind the
+// barrier instead of right behind it; SG: save-grad GeLU epilogue; PB: MFMAs of the barrier step issued in front of the barrier;
+// LEAD: fragments are read LEAD k16 steps ahead of their MFMAs (2 LEAD register sets; the barrier sits in step S - LEAD)
+template <int BN_T, int WGM, int WGN, int NSX, int NSW, bool ROLES, bool SPREAD, bool SG, int PB, int LEAD>
+__global__ __launch_bounds__(WGM * WGN * 64, WGM * WGN / 4) void gemm_nt_wp_kernel(GemmNtParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BM = 256;
-    constexpr int NWC = WGM * WGN;                 // compute waves
-    constexpr int NWL = LOADER ? 4 : NWC;          // waves that issue DMA
+    constexpr int BM = 256, BK_T = 64, S = 4;
+    constexpr int NW = WGM * WGN;
     constexpr int WROWS_M = BM / WGM, WROWS_N = BN_T / WGN;
     constexpr int TM = WROWS_M / 32, TN = WROWS_N / 32;
     constexpr int NM = TM * TN;                    // MFMAs per k16 step
     constexpr int NR = TM + TN;                    // fragment reads per k16 step
     constexpr int ROWB = BK_T * 2;                 // bytes per LDS row
-    constexpr int CPR = BK_T / 8;                  // 16-byte chunks per row
-    constexpr int RPB = 1024 / ROWB;               // rows per 1-KiB DMA piece
-    constexpr int LPX = BM / RPB / NWL, LPW = BN_T / RPB / NWL, LPS = LPX + LPW;   // DMA pieces per issuing wave per stage
-    constexpr int XBYTES = BM * ROWB, STAGE = (BM + BN_T) * ROWB;
-    constexpr int S = BK_T / 16;                   // k16 steps per k tile
-    static_assert(TN >= 2 && (BM / RPB) % NWL == 0 && (BN_T / RPB) % NWL == 0, "tile / wave geometry");
-    static_assert(SPREAD == 1 || SPREAD == S, "SPREAD");
-    static_assert((NS - 1) * LPS <= 63, "vmcnt range");
+    constexpr int NIS = ROLES ? NW / 2 : NW;       // waves issuing each operand's pieces
+    constexpr int LPX = BM / 8 / NIS, LPW = BN_T / 8 / NIS;   // 1-KiB pieces (8 rows) per issuing wave per stage
+    constexpr int XBYTES = BM * ROWB, WBYTES = BN_T * ROWB;
+    constexpr int WRING = NSX * XBYTES;            // LDS offset of the W ring
+    constexpr int NSMAX = NSX > NSW ? NSX : NSW;
+    constexpr bool SPX = SPREAD && NSX >= 3, SPW = SPREAD && NSW >= 3;
+    static_assert(ROLES || NSX == NSW, "one wave mixing both streams needs equal ring depths");
+    static_assert(TN >= 2 && (BM / 8) % NIS == 0 && (BN_T / 8) % NIS == 0, "tile / wave geometry");
+    static_assert((NSX - 1) * LPX + (ROLES ? 0 : (NSW - 1) * LPW) <= 63 && (NSW - 1) * LPW <= 63, "vmcnt range");
     static_assert(PB < NM, "PB");
+    constexpr int NB = 2 * LEAD;                   // fragment register sets
+    static_assert(LEAD == 1 || LEAD == 2, "LEAD");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -93,84 +98,55 @@ __global__ __launch_bounds__((WGM * WGN + (LOADER ? 4 : 0)) * 64, (WGM * WGN + (
     const char* const xg = reinterpret_cast<const char*>(p.X);
     const char* const wg = reinterpret_cast<const char*>(p.W);
 
-    // ---- DMA geometry: piece j of issuing wave lw = tile rows RPB*(lw + NWL*j) .. +RPB-1; lane -> (row lane / CPR, physical chunk lane % CPR)
-    const bool issuer = LOADER ? (wid >= NWC) : true;
-    const int lw = LOADER ? wid - NWC : wid;
-    uint32_t voff[LPS];
-    if (issuer) {
-        const int rb = lane / CPR, pc = lane % CPR;
-        static_for<0, LPS>([&](auto J) {
+    // ---- DMA geometry: piece j of issuing wave lw = tile rows 8 (lw + NIS j) .. +7; lane -> (row lane >> 3, physical chunk lane & 7)
+    const bool xrole = ROLES ? (wid < NW / 2) : true;
+    const int lw = ROLES ? (xrole ? wid : wid - NW / 2) : wid;
+    uint32_t voffx[LPX], voffw[LPW];
+    {
+        const int rb = lane >> 3, pc = lane & 7;
+        static_for<0, LPX>([&](auto J) {
             constexpr int j = decltype(J)::value;
-            if constexpr (j < LPX) {
-                const int r = (lw + NWL * j) * RPB + rb;
-                const int mr = min(m0 + r, p.M - 1);
-                voff[j] = (uint32_t)mr * (uint32_t)p.ldx * 2u + (uint32_t)((pc ^ wp_swz<BK_T>(r)) << 4);
-            } else {
-                const int R = (lw + NWL * (j - LPX)) * RPB + rb;
-                const int nr = min(n0 + R, p.N - 1);
-                voff[j] = (uint32_t)nr * (uint32_t)p.ldw * 2u + (uint32_t)((pc ^ wp_swz_w<BK_T>(R)) << 4);
-            }
+            const int r = (lw + NIS * j) * 8 + rb;
+            voffx[j] = (uint32_t)min(m0 + r, p.M - 1) * (uint32_t)p.ldx * 2u + (uint32_t)((pc ^ wp_swz(r)) << 4);
+        });
+        static_for<0, LPW>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            const int R = (lw + NIS * j) * 8 + rb;
+            voffw[j] = (uint32_t)min(n0 + R, p.N - 1) * (uint32_t)p.ldw * 2u + (uint32_t)((pc ^ wp_swz_w(R)) << 4);
         });
     }
-    // pieces [J0, J1) of stage kt into ring slot `slot`
-    auto issue = [&](auto J0_, auto J1_, int kt, int slot) {
-        constexpr int J0 = decltype(J0_)::value, J1 = decltype(J1_)::value;
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)slot * STAGE);
+    // X pieces [J0, J1) of stage kt into X ring slot `slot`; W likewise
+    auto issue_x = [&](auto J0_, auto J1_, int kt, int slot) {
+        if constexpr (WP_DBG & 2) return;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)slot * XBYTES);
         const char* xs = xg + (int64_t)kt * ROWB;
-        const char* ws = wg + (int64_t)kt * ROWB;
-        static_for<J0, J1>([&](auto J) {
+        static_for<decltype(J0_)::value, decltype(J1_)::value>([&](auto J) {
             constexpr int j = decltype(J)::value;
-            if constexpr (j < LPX) glds16_s(xs, voff[j], dst + (uint32_t)(lw + NWL * j) * 1024u);
-            else glds16_s(ws, voff[j], dst + (uint32_t)XBYTES + (uint32_t)(lw + NWL * (j - LPX)) * 1024u);
+            glds16_s(xs, voffx[j], dst + (uint32_t)(lw + NIS * j) * 1024u);
         });
     };
-    using I0 = std::integral_constant<int, 0>;
-    using ILPS = std::integral_constant<int, LPS>;
+    auto issue_w = [&](auto J0_, auto J1_, int kt, int slot) {
+        if constexpr (WP_DBG & 2) return;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)WRING + (uint32_t)slot * WBYTES);
+        const char* ws = wg + (int64_t)kt * ROWB;
+        static_for<decltype(J0_)::value, decltype(J1_)::value>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            glds16_s(ws, voffw[j], dst + (uint32_t)(lw + NIS * j) * 1024u);
+        });
+    };
 
-    // =====================================================================================================================
-    // loader waves: issue, wait, barrier -- the same barrier sequence as the compute waves (1 + (nk - 1))
-    // =====================================================================================================================
-    if (LOADER && wid >= NWC) {
-        const int pre = min(NS, nk);
-        for (int st = 0; st < pre; ++st) issue(I0{}, ILPS{}, st, st);
-        // stage 0 landed
-        if (nk >= NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * LPS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int slot = 0;
-        for (int kt = 0; kt + 1 < nk; ++kt) {
-            // barrier B_kt: stage kt+1 landed; outstanding stages kt+1 .. min(kt+NS-1, nk-1)
-            const int outst = min(NS - 1, nk - 1 - kt);
-            if (outst == NS - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
-            else {
-                bool done = false;
-                static_for<1, NS - 1>([&](auto Jc) {
-                    constexpr int jc = decltype(Jc)::value;
-                    if (!done && outst == jc) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((jc - 1) * LPS) : "memory"); done = true; }
-                });
-            }
-            __builtin_amdgcn_s_barrier();
-            if (kt + NS < nk) issue(I0{}, ILPS{}, kt + NS, slot);
-            slot = (slot + 1 == NS) ? 0 : slot + 1;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
-    }
-
-    // =====================================================================================================================
-    // compute waves
-    // =====================================================================================================================
+    // ---- fragment geometry ----------------------------------------------------------------------------------------------
     const int wm = wid / WGN, wn = wid % WGN;
     const int li = lane & 31, hi = lane >> 5;
-    const int fsw = wp_swz<BK_T>(li);
-    uint32_t xoff[S], woff[S];          // byte offsets inside a stage of this lane's fragment chunks, per k16 step
+    const int fsw = wp_swz(li);
+    uint32_t xoff[S], woff[S];          // byte offsets inside a ring slot of this lane's fragment chunks, per k16 step
     {
         const int rowx = wm * WROWS_M + li;
         const int roww = wn * WROWS_N + 16 * TN * ((li >> 2) & 1) + 4 * (li >> 3) + (li & 3);
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             xoff[s] = (uint32_t)(rowx * ROWB + (((2 * s + hi) ^ fsw) << 4));
-            woff[s] = (uint32_t)(XBYTES + roww * ROWB + (((2 * s + hi) ^ fsw) << 4));
+            woff[s] = (uint32_t)(WRING + roww * ROWB + (((2 * s + hi) ^ fsw) << 4));
         }
     }
     f32x16 acc[TM][TN];
@@ -180,33 +156,55 @@ __global__ __launch_bounds__((WGM * WGN + (LOADER ? 4 : 0)) * 64, (WGM * WGN + (
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    f16x8 xf[2][TM], wf[2][TN];
+    f16x8 xf[NB][TM], wf[NB][TN];
+    if constexpr (WP_DBG & 24) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) xf[b][t] = __builtin_bit_cast(f16x8, (u32x4){(uint32_t)lane, 1u, 2u, 3u});
+#pragma unroll
+            for (int t = 0; t < TN; ++t) wf[b][t] = __builtin_bit_cast(f16x8, (u32x4){(uint32_t)lane, 5u, 6u, 7u});
+        }
+    }
 
-    // fragment read q of a step (order: x0, w0 .. w(TN-1), x1 .. x(TM-1): the first MFMAs' operands first) into register set BUF
-    auto read_one = [&](auto BUF_, auto Q_, const char* stage, auto SS_) {
+    // fragment read q of a step (order: x0, w0 .. w(TN-1), x1 .. x(TM-1): the first MFMAs' operands first) into register set BUF;
+    // xs / ws = byte offsets of the X / W ring slot that holds the k tile
+    auto read_one = [&](auto BUF_, auto Q_, int xs, int ws, auto SS_) {
         constexpr int BUF = decltype(BUF_)::value, q = decltype(Q_)::value, ss = decltype(SS_)::value;
-        if constexpr (q == 0) xf[BUF][0] = ld8(reinterpret_cast<const f16*>(stage + xoff[ss]));
-        else if constexpr (q <= TN) wf[BUF][q - 1] = ld8(reinterpret_cast<const f16*>(stage + woff[ss] + (q - 1) * 16 * ROWB));
-        else xf[BUF][q - TN] = ld8(reinterpret_cast<const f16*>(stage + xoff[ss] + (q - TN) * 32 * ROWB));
+        if constexpr (WP_DBG & 8) return;
+        if constexpr (WP_DBG & 16) {
+            const uint32_t a = lds0 + (q == 0 ? (uint32_t)xs + xoff[ss] : (q <= TN ? (uint32_t)ws + woff[ss] + (q - 1) * 16 * ROWB : (uint32_t)xs + xoff[ss] + (q - TN) * 32 * ROWB));
+            u32x4 junk;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(junk) : "v"(a));
+            return;
+        }
+        if constexpr (q == 0) xf[BUF][0] = ld8(reinterpret_cast<const f16*>(smem + xs + xoff[ss]));
+        else if constexpr (q <= TN) wf[BUF][q - 1] = ld8(reinterpret_cast<const f16*>(smem + ws + woff[ss] + (q - 1) * 16 * ROWB));
+        else xf[BUF][q - TN] = ld8(reinterpret_cast<const f16*>(smem + xs + xoff[ss] + (q - TN) * 32 * ROWB));
     };
     auto mfma_one = [&](auto BUF_, auto K_) {
         constexpr int BUF = decltype(BUF_)::value, k = decltype(K_)::value, tm = k / TN, tn = k % TN;
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[BUF][tn], xf[BUF][tm], acc[tm][tn], 0, 0, 0);
+        if constexpr (WP_DBG & 1) { const f16x8 a_ = wf[BUF][tn], b_ = xf[BUF][tm]; asm volatile("" ::"v"(a_), "v"(b_)); }
+        else acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[BUF][tn], xf[BUF][tm], acc[tm][tn], 0, 0, 0);
     };
-    // One k16 step.  MODE 0: regular (reads of the next step spread over all MFMAs); 1: barrier step (PB MFMAs, counted wait,
-    // barrier, then the reads of the next tile's step 0 and -- for DMA-issuing compute waves -- pieces [G0, G1) of stage gkt);
-    // 2: last step of the last tile (no reads).  WAITN: vmcnt immediate of the barrier step (-1: none, loader builds).
-    auto step = [&](auto CUR_, auto MODE_, auto NEXTS_, auto WAITN_, auto G0_, auto G1_, const char* rstage, int gkt, int gslot, bool gdo) {
-        constexpr int CUR = decltype(CUR_)::value, MODE = decltype(MODE_)::value, NEXTS = decltype(NEXTS_)::value, WAITN = decltype(WAITN_)::value;
-        constexpr int G0 = decltype(G0_)::value, G1 = decltype(G1_)::value, NG = G1 - G0;
+    // One k16 step.  MODE 0: regular (reads of the next step spread over all MFMAs); 1: barrier step (PB MFMAs, counted wait, barrier,
+    // then the reads of the next tile's step 0); 2: last step of the last tile (no reads).  WX / WW: vmcnt immediates of the barrier
+    // step for X- / W-issuing waves (one wave issuing both: WX counts both).  GX / GW: DMA group (0 .. S-1) carried, -1 none.
+    auto step = [&](auto CUR_, auto DST_, auto MODE_, auto NEXTS_, auto WX_, auto WW_, auto GX_, auto GW_, int rxs, int rws, const WpDma& d) {
+        constexpr int CUR = decltype(CUR_)::value, MODE = decltype(MODE_)::value, WX = decltype(WX_)::value, WW = decltype(WW_)::value;
+        constexpr int GX = decltype(GX_)::value, GW = decltype(GW_)::value;
         constexpr int FIRST = (MODE == 1) ? PB : 0;          // first MFMA slot that may carry reads / DMA
         constexpr int SPAN = NM - FIRST;
+        // pieces of the groups: a burst ring issues everything in group 0
+        constexpr int X0 = GX < 0 ? 0 : (SPX ? GX * LPX / S : 0), X1 = GX < 0 ? 0 : (SPX ? (GX + 1) * LPX / S : (GX == 0 ? LPX : 0));
+        constexpr int W0 = GW < 0 ? 0 : (SPW ? GW * LPW / S : 0), W1 = GW < 0 ? 0 : (SPW ? (GW + 1) * LPW / S : (GW == 0 ? LPW : 0));
+        constexpr int NGX = X1 - X0, NGW = W1 - W0, NGB = NGX + NGW;
         static_for<0, NM>([&](auto K_) {
             constexpr int k = decltype(K_)::value;
             if constexpr (MODE == 1 && k == PB) {
                 WP_SCHED();
-                if constexpr (WAITN >= 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WAITN) : "memory");
-                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (ROLES && !xrole) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WX) : "memory");
                 __builtin_amdgcn_s_barrier();
                 WP_SCHED();
             }
@@ -214,133 +212,259 @@ __global__ __launch_bounds__((WGM * WGN + (LOADER ? 4 : 0)) * 64, (WGM * WGN + (
             if constexpr (MODE != 2 && k >= FIRST) {
                 static_for<0, NR>([&](auto Q_) {
                     constexpr int q = decltype(Q_)::value;
-                    // regular step: spread over the step; barrier step: one per MFMA right behind the barrier (the loop back edge waits
-                    // for all of them: lgkmcnt(0) at the loop head)
+                    // regular step: spread over the step; barrier step: one per MFMA right behind the barrier (the loop back edge
+                    // waits for all of them: lgkmcnt(0) at the loop head)
                     constexpr int rslot = (MODE == 1) ? ((FIRST + q < NM) ? FIRST + q : NM - 1) : (q * SPAN) / NR;
-                    if constexpr (rslot == k) read_one(std::integral_constant<int, CUR ^ 1>{}, Q_, rstage, NEXTS_);
+                    if constexpr (rslot == k) read_one(DST_, Q_, rxs, rws, NEXTS_);
                 });
             }
-            if constexpr (NG > 0 && k >= FIRST) {
-                static_for<0, NG>([&](auto G_) {
-                    constexpr int g = decltype(G_)::value;
-                    if constexpr (FIRST + (g * SPAN) / NG == k) {
-                        if (gdo) issue(std::integral_constant<int, G0 + g>{}, std::integral_constant<int, G0 + g + 1>{}, gkt, gslot);
+            if constexpr (k >= FIRST) {
+                if constexpr (ROLES) {
+                    if (xrole) {
+                        static_for<0, NGX>([&](auto G_) {
+                            constexpr int g = decltype(G_)::value;
+                            if constexpr (FIRST + (g * SPAN) / (NGX > 0 ? NGX : 1) == k) { if (d.dox) issue_x(IC<X0 + g>{}, IC<X0 + g + 1>{}, d.kx, d.sx); }
+                        });
+                    } else {
+                        static_for<0, NGW>([&](auto G_) {
+                            constexpr int g = decltype(G_)::value;
+                            if constexpr (FIRST + (g * SPAN) / (NGW > 0 ? NGW : 1) == k) { if (d.dow) issue_w(IC<W0 + g>{}, IC<W0 + g + 1>{}, d.kw, d.sw); }
+                        });
                     }
-                });
+                } else {
+                    static_for<0, NGB>([&](auto G_) {          // X pieces first, then W pieces, spread over the slots together
+                        constexpr int g = decltype(G_)::value;
+                        if constexpr (FIRST + (g * SPAN) / (NGB > 0 ? NGB : 1) == k) {
+                            if constexpr (g < NGX) { if (d.dox) issue_x(IC<X0 + g>{}, IC<X0 + g + 1>{}, d.kx, d.sx); }
+                            else { if (d.dow) issue_w(IC<W0 + g - NGX>{}, IC<W0 + g - NGX + 1>{}, d.kw, d.sw); }
+                        }
+                    });
+                }
             }
             WP_SCHED();
         });
     };
-    using IM1 = std::integral_constant<int, -1>;
-    constexpr bool CDMA = !LOADER;                 // compute waves issue the DMA
-    // spread issue: group g of a stage = pieces [g LPS / SPREAD, (g + 1) LPS / SPREAD); group 0 goes behind the barrier
 
-    // ---- prologue ---------------------------------------------------------------------------------------------------
-    if (CDMA) {
-        const int pre = min(NS, nk);
-        for (int st = 0; st < pre; ++st) issue(I0{}, ILPS{}, st, st);
-        if (nk >= NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * LPS) : "memory");
+    // ---- prologue: fill both rings, wait for stage 0 ------------------------------------------------------------------------
+    if constexpr (ROLES) {
+        if (xrole) { for (int st = 0; st < min(NSX, nk); ++st) issue_x(IC<0>{}, IC<LPX>{}, st, st); }
+        else { for (int st = 0; st < min(NSW, nk); ++st) issue_w(IC<0>{}, IC<LPW>{}, st, st); }
+        if (nk >= NSMAX) {
+            if (xrole) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSX - 1) * LPX) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSW - 1) * LPW) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    } else {
+        for (int st = 0; st < min(NSX, nk); ++st) { issue_x(IC<0>{}, IC<LPX>{}, st, st); issue_w(IC<0>{}, IC<LPW>{}, st, st); }   // stage by stage: the in-order count
+        if (nk >= NSMAX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSX - 1) * (LPX + LPW)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    static_for<0, NR>([&](auto Q_) { read_one(I0{}, Q_, smem, I0{}); });
+    static_for<0, LEAD>([&](auto L_) { static_for<0, NR>([&](auto Q_) { read_one(L_, Q_, 0, 0, L_); }); });
 
-    // One k tile (slot cs, next slot ns).  J = stages behind this tile that are (or will be) in the ring: min(NS-1, nk-1-kt);
-    // ISSUE: stage kt+NS exists and is issued at this tile's barrier.
-    auto tile = [&](auto J_, auto ISSUE_, int kt, int cs, int ns, bool prev_spread) {
+    // One k tile.  J = min(NSMAX, nk - 1 - kt): k tiles behind this one (NSMAX = "at least NSMAX": the main loop).
+    // csx / csw: ring slots of this tile; the spread groups 1 .. S-1 of the stages issued behind the PREVIOUS barrier ride on steps 0 .. S-2.
+    auto tile = [&](auto J_, int kt, int csx, int csw, bool prevx, bool prevw) {
         constexpr int J = decltype(J_)::value;
-        constexpr bool ISSUE = decltype(ISSUE_)::value;
-        const char* cstage = smem + cs * STAGE;
-        const char* nstage = smem + ns * STAGE;
-        const int pslot = __builtin_amdgcn_readfirstlane((cs == 0) ? NS - 1 : cs - 1);   // slot of tile kt-1: target of a spread issue still in progress
+        constexpr int OX = (J < NSX - 1) ? J : NSX - 1, OW = (J < NSW - 1) ? J : NSW - 1;       // stages of each ring behind this tile
+        constexpr bool ISX = J >= NSX, ISW = J >= NSW;                                          // stage kt + NSX / kt + NSW exists
+        // vmcnt at the barrier: everything but the (O - 1) youngest stages of the wave's stream(s) has landed
+        constexpr int WX = ROLES ? (OX > 0 ? (OX - 1) * LPX : 0) : (OX > 0 ? (OX - 1) * (LPX + LPW) : 0);
+        constexpr int WW = OW > 0 ? (OW - 1) * LPW : 0;
+        const int nsx = (csx + 1 == NSX) ? 0 : csx + 1, nsw = (csw + 1 == NSW) ? 0 : csw + 1;
+        const int psx = __builtin_amdgcn_readfirstlane((csx == 0) ? NSX - 1 : csx - 1), psw = __builtin_amdgcn_readfirstlane((csw == 0) ? NSW - 1 : csw - 1);
+        const WpDma dprev{kt - 1 + NSX, psx, kt - 1 + NSW, psw, prevx, prevw};
+        const WpDma dnew{kt + NSX, csx, kt + NSW, csw, ISX, ISW};
+        const WpDma dnone{0, 0, 0, 0, false, false};
+        const int cxo = csx * XBYTES, cwo = csw * WBYTES, nxo = nsx * XBYTES, nwo = nsw * WBYTES;
         static_for<0, S>([&](auto SS_) {
             constexpr int ss = decltype(SS_)::value;
-            using CUR = std::integral_constant<int, ss & 1>;
-            if constexpr (ss < S - 1) {
-                // regular step; with SPREAD = S it carries group ss+1 of the stage issued behind the previous barrier
-                if constexpr (CDMA && SPREAD > 1)
-                    step(CUR{}, I0{}, std::integral_constant<int, ss + 1>{}, IM1{}, std::integral_constant<int, (ss + 1) * LPS / SPREAD>{},
-                         std::integral_constant<int, (ss + 2) * LPS / SPREAD>{}, cstage, kt - 1 + NS, pslot, prev_spread);
-                else
-                    step(CUR{}, I0{}, std::integral_constant<int, ss + 1>{}, IM1{}, I0{}, I0{}, cstage, 0, 0, false);
+            using CUR = IC<(ss % NB)>;
+            using DST = IC<((ss + LEAD) % NB)>;
+            constexpr int BS = S - LEAD;                       // the barrier step
+            if constexpr (ss < BS) {
+                // regular step reading step ss + LEAD of this tile; with spread rings it carries group ss + LEAD of the stage issued
+                // behind the previous tile's barrier
+                step(CUR{}, DST{}, IC<0>{}, IC<ss + LEAD>{}, IC<0>{}, IC<0>{}, IC<(SPX ? ss + LEAD : -1)>{}, IC<(SPW ? ss + LEAD : -1)>{}, cxo, cwo, dprev);
             } else if constexpr (J == 0) {
-                step(CUR{}, std::integral_constant<int, 2>{}, I0{}, IM1{}, I0{}, I0{}, cstage, 0, 0, false);
+                step(CUR{}, DST{}, IC<2>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<-1>{}, IC<-1>{}, cxo, cwo, dnone);
+            } else if constexpr (ss == BS) {
+                step(CUR{}, DST{}, IC<1>{}, IC<0>{}, IC<WX>{}, IC<WW>{}, IC<(ISX ? 0 : -1)>{}, IC<(ISW ? 0 : -1)>{}, nxo, nwo, dnew);
             } else {
-                constexpr int WAITN = CDMA ? (J - 1) * LPS : -1;
-                if constexpr (CDMA && ISSUE)
-                    step(CUR{}, std::integral_constant<int, 1>{}, I0{}, std::integral_constant<int, WAITN>{}, I0{},
-                         std::integral_constant<int, LPS / SPREAD>{}, nstage, kt + NS, cs, true);
-                else
-                    step(CUR{}, std::integral_constant<int, 1>{}, I0{}, std::integral_constant<int, WAITN>{}, I0{}, I0{}, nstage, 0, 0, false);
+                // behind the barrier: reads of the next tile's step ss - BS, groups ss - BS of the stage issued at this tile's barrier
+                step(CUR{}, DST{}, IC<0>{}, IC<ss - BS>{}, IC<0>{}, IC<0>{}, IC<((ISX && SPX) ? ss - BS : -1)>{}, IC<((ISW && SPW) ? ss - BS : -1)>{}, nxo, nwo, dnew);
             }
         });
     };
-    int kt = 0, cs = 0;
-    bool prev_spread = false;
-    for (; kt + NS < nk; ++kt) {
-        const int ns = (cs + 1 == NS) ? 0 : cs + 1;
-        tile(std::integral_constant<int, NS - 1>{}, std::true_type{}, kt, cs, ns, prev_spread);
-        prev_spread = true;
-        cs = ns;
+    int kt = 0, csx = 0, csw = 0;
+    bool prevx = false, prevw = false;
+    for (; kt + NSMAX < nk; ++kt) {
+        tile(IC<NSMAX>{}, kt, csx, csw, prevx, prevw);
+        prevx = prevw = true;
+        csx = (csx + 1 == NSX) ? 0 : csx + 1;
+        csw = (csw + 1 == NSW) ? 0 : csw + 1;
     }
-    static_for<0, NS>([&](auto JJ_) {
-        constexpr int J = NS - 1 - decltype(JJ_)::value;
+    static_for<0, NSMAX>([&](auto JJ_) {
+        constexpr int J = NSMAX - 1 - decltype(JJ_)::value;
         if (nk - 1 - kt == J) {
-            const int ns = (cs + 1 == NS) ? 0 : cs + 1;
-            tile(std::integral_constant<int, J>{}, std::false_type{}, kt, cs, ns, prev_spread);
-            prev_spread = false;
-            cs = ns;
+            tile(IC<J>{}, kt, csx, csw, prevx, prevw);
+            prevx = J >= NSX;                 // a stage issued behind this tile's barrier continues on the next tile's steps
+            prevw = J >= NSW;
+            csx = (csx + 1 == NSX) ? 0 : csx + 1;
+            csw = (csw + 1 == NSW) ? 0 : csw + 1;
             ++kt;
         }
     });
 
-    // ---- epilogue: lane owns row m per m-tile and 16 TN consecutive n ---------------------------------------------------
-    const int nbase = n0 + wn * WROWS_N + 16 * TN * hi;
+    // ---- epilogue --------------------------------------------------------------------------------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();             // every wave is done with the stage buffers
+    if constexpr (WP_DBG & 4) { if (acc[0][0][0] != 12345.678f) return; }
+    constexpr int CW = 32 * TN;               // columns of the wave tile
+    constexpr int RS = CW * 4 + 16;           // padded row stride of the transpose buffer (bytes): conflict-free ds_write_b128 of 8 rows
+    constexpr int LPR = CW / 8, RPP = 64 / LPR, NPASS = 32 / RPP;
+    char* const ebuf = smem + wid * (32 * RS);
+    const int er = lane / LPR, ec = (lane % LPR) * 8;
+    const int nc = n0 + wn * WROWS_N + ec;    // this lane's 8 columns (the same for every row it handles)
+    const bool ncol_ok = nc < p.N;
+    float bias_v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bias_v[j] = 0.f;
+    if (p.bias && ncol_ok) {
+        if (nc + 8 <= p.N) {
+            const f16x8 b = ld8(p.bias + nc);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bias_v[j] = (float)b[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (nc + j < p.N) bias_v[j] = (float)p.bias[nc + j];
+        }
+    }
+    const bool ragged = (p.N & 7) && nc + 8 > p.N;      // last, partial vector of a row: pad columns are written as zero
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
-        const int m = m0 + wm * WROWS_M + 32 * tm + li;
-        if (m >= p.M) continue;
-        const uint32_t rkey = p.drop.thresh ? drop_rowkey(p.drop, (uint64_t)m) : 0u;
+        // accumulators -> transpose buffer (row li, columns 16 TN hi + 16 tn + r)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float v[8];
+            for (int q = 0; q < 4; ++q) {
+                f32x4 t;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = acc[tm][tn][8 * h + j] * p.alpha;
-                nt_epilogue8<SG, true>(p, m, nbase + 16 * tn + 8 * h, v, rkey);
+                for (int j = 0; j < 4; ++j) t[j] = acc[tm][tn][4 * q + j];
+                *reinterpret_cast<f32x4*>(ebuf + li * RS + (16 * TN * hi + 16 * tn + 4 * q) * 4) = t;
             }
+        const int mb = m0 + wm * WROWS_M + 32 * tm + er;       // row of pass 0
+        // batched operand loads (whole lines per row): the latency of all passes overlaps
+        f16x8 mulv[NPASS], resv[NPASS];
+        if constexpr (!SG) {
+            if (p.mulmode != VLP_MUL_NONE) {
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const int m = mb + ps * RPP;
+                    if (m < p.M && ncol_ok) mulv[ps] = ld8(p.mulsrc + (int64_t)m * p.ldm + nc);
+                }
+            }
+            if (p.residual) {
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const int m = mb + ps * RPP;
+                    if (m < p.M && ncol_ok) resv[ps] = ld8(p.residual + (int64_t)m * p.ldr + nc);
+                }
+            }
+        }
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int m = mb + ps * RPP;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ebuf + (er + ps * RPP) * RS + ec * 4);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(ebuf + (er + ps * RPP) * RS + ec * 4 + 16);
+            if (m >= p.M || !ncol_ok) continue;
+            float vv[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { vv[j] = a0[j] * p.alpha + bias_v[j]; vv[4 + j] = a1[j] * p.alpha + bias_v[4 + j]; }
+            if constexpr (SG) {
+                // z = fp16-rounded pre-activation; y = gelu(z); preact <- gelu'(z)   (same arithmetic as nt_epilogue8<true>)
+                f16x8 d, o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float gl, gp;
+                    gelu_and_grad_f((float)(f16)vv[j], gl, gp);
+                    o[j] = (f16)gl;
+                    d[j] = (f16)gp;
+                }
+                if (ragged) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (nc + j >= p.N) { o[j] = (f16)0.f; d[j] = (f16)0.f; }
+                }
+                st8(p.preact + (int64_t)m * p.ldp + nc, d);
+                st8(p.Y + (int64_t)m * p.ldy + nc, o);
+            } else {
+                // light epilogue, same order of operations as nt_epilogue8: pre-activation store, ReLU, multiplier, dropout, residual
+                if (p.preact) {
+                    f16x8 z;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) z[j] = (nc + j < p.N) ? (f16)vv[j] : (f16)0.f;
+                    st8(p.preact + (int64_t)m * p.ldp + nc, z);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) vv[j] = (float)z[j];
+                }
+                if (p.act == VLP_ACT_RELU) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) vv[j] = fmaxf(vv[j], 0.f);
+                }
+                if (p.mulmode == VLP_MUL_PLAIN) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) vv[j] *= (float)mulv[ps][j];
+                } else if (p.mulmode != VLP_MUL_NONE) {           // VLP_MUL_RELU_MASK (GELU_GRAD is refused by the launcher)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) vv[j] = ((float)mulv[ps][j] > 0.f) ? vv[j] : 0.f;
+                }
+                if (p.drop.thresh) drop_mult8(p.drop, drop_rowkey(p.drop, (uint64_t)m), (uint32_t)nc, vv);
+                if (p.residual) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) vv[j] += (float)resv[ps][j];
+                }
+                f16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (!ragged || nc + j < p.N) ? (f16)vv[j] : (f16)0.f;
+                st8(p.Y + (int64_t)m * p.ldy + nc, o);
+            }
+        }
     }
 }
 
-// cfg (vlp_gemm_nt variant 64 + cfg, + 8 = XCD-aware tile order):
-//   0: 256x256, 4 waves (128x128), BK 64, 2 slots, burst DMA          1: 256x256, 8 waves (128x64), BK 64, 2 slots, burst
-//   2: 256x256, 4 waves, BK 32, 4 slots, spread DMA                    3: 256x256, 8 waves, BK 32, 4 slots, spread
-//   4: 256x128, 4 waves (128x64), BK 64, 3 slots, spread               5: 256x128, 8 waves (64x64), BK 64, 3 slots, spread
-//   6: 256x128, 4 compute waves (128x64) + 4 DMA waves, BK 64, 3 slots 7: 256x128, 4 waves, BK 64, 3 slots, burst
+// cfg (vlp_gemm_nt variant 64 + cfg, + 8 = XCD-aware tile order; cfg 8.. = variant 192 + cfg - 8):
+//   0: 256x256, 4 waves (128x128), rings 2/2                1: 256x256, 8 waves (128x64), rings 2/2
+//   2: as 0, fragments read 2 steps ahead                   3: 256x256, 4 waves, X/W roles, rings 3/2 (160 KiB), 2 steps ahead
+//   4: 256x128, 4 waves (128x64), rings 3/3, spread         5: 256x128, 8 waves (64x64), rings 3/3, spread
+//   6: as 4, 2 steps ahead                                  7: as 5, 2 steps ahead
+//   8: 256x128, 8 waves, roles, rings 3/3 (control)         9: 256x128, 8 waves, roles, rings 4/2 (160 KiB)
 int vlp_gemm_nt_wp_launch(GemmNtParams& p, int cfg, bool sg, hipStream_t s) {
     VLP_CHECK_ARG(sg || nt_epilogue_is_light(p), "vlp_gemm_nt: the wave-pipelined variants carry bias / ReLU / multiplier / dropout / residual / save-grad GeLU epilogues only");
     VLP_CHECK_ARG((int64_t)p.M * p.ldx < (1ll << 31) && (int64_t)p.N * p.ldw < (1ll << 31), "vlp_gemm_nt: wave-pipelined variants need M*ldx, N*ldw < 2^31");
-#define LAUNCH_WP_(BNT, WGM, WGN, BKT, NSV, SPR, LDR, SGV, PBV)                                                                            \
+#define LAUNCH_WP_(BNT, WGM, WGN, NSXV, NSWV, RLS, SPR, SGV, PBV, LDV)                                                                       \
     do {                                                                                                                               \
-        const size_t smem = (size_t)(NSV) * (256 + (BNT)) * (BKT) * sizeof(f16);                                                       \
-        auto kfn = gemm_nt_wp_kernel<BNT, WGM, WGN, BKT, NSV, SPR, LDR, SGV, PBV>;                                                     \
+        const size_t smem = ((size_t)(NSXV) * 256 + (size_t)(NSWV) * (BNT)) * 64 * sizeof(f16);                                        \
+        auto kfn = gemm_nt_wp_kernel<BNT, WGM, WGN, NSXV, NSWV, RLS, SPR, SGV, PBV, LDV>;                                                   \
         static bool attr = false;                                                                                                      \
         if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; } \
         p.tiles_n = cdiv(p.N, (BNT));                                                                                                  \
-        hipLaunchKernelGGL(kfn, dim3(cdiv(p.M, 256) * p.tiles_n), dim3(((WGM) * (WGN) + ((LDR) ? 4 : 0)) * 64), smem, s, p);          \
+        hipLaunchKernelGGL(kfn, dim3(cdiv(p.M, 256) * p.tiles_n), dim3((WGM) * (WGN) * 64), smem, s, p);                               \
     } while (0)
-#define LAUNCH_WP(BNT, WGM, WGN, BKT, NSV, SPR, LDR, PBV) \
-    do { if (sg) LAUNCH_WP_(BNT, WGM, WGN, BKT, NSV, SPR, LDR, true, PBV); else LAUNCH_WP_(BNT, WGM, WGN, BKT, NSV, SPR, LDR, false, PBV); } while (0)
+#define LAUNCH_WP(BNT, WGM, WGN, NSXV, NSWV, RLS, SPR, PBV, LDV) \
+    do { if (sg) LAUNCH_WP_(BNT, WGM, WGN, NSXV, NSWV, RLS, SPR, true, PBV, LDV); else LAUNCH_WP_(BNT, WGM, WGN, NSXV, NSWV, RLS, SPR, false, PBV, LDV); } while (0)
     switch (cfg) {
-        case 0: LAUNCH_WP(256, 2, 2, 64, 2, 1, false, 4); break;
-        case 1: LAUNCH_WP(256, 2, 4, 64, 2, 1, false, 2); break;
-        case 2: LAUNCH_WP(256, 2, 2, 32, 4, 2, false, 4); break;
-        case 3: LAUNCH_WP(256, 2, 4, 32, 4, 2, false, 2); break;
-        case 4: LAUNCH_WP(128, 2, 2, 64, 3, 4, false, 2); break;
-        case 5: LAUNCH_WP(128, 4, 2, 64, 3, 4, false, 0); break;
-        case 6: LAUNCH_WP(128, 2, 2, 64, 3, 1, true, 2); break;
-        default: LAUNCH_WP(128, 2, 2, 64, 3, 1, false, 2); break;
+        case 0: LAUNCH_WP(256, 2, 2, 2, 2, false, false, 4, 1); break;
+        case 1: LAUNCH_WP(256, 2, 4, 2, 2, false, false, 2, 1); break;
+        case 2: LAUNCH_WP(256, 2, 2, 2, 2, false, false, 4, 2); break;
+        case 3: LAUNCH_WP(256, 2, 2, 3, 2, true, true, 4, 2); break;
+        case 4: LAUNCH_WP(128, 2, 2, 3, 3, false, true, 2, 1); break;
+        case 5: LAUNCH_WP(128, 4, 2, 3, 3, false, true, 0, 1); break;
+        case 6: LAUNCH_WP(128, 2, 2, 3, 3, false, true, 2, 2); break;
+        case 7: LAUNCH_WP(128, 4, 2, 3, 3, false, true, 0, 2); break;
+        case 8: LAUNCH_WP(128, 4, 2, 3, 3, true, true, 0, 1); break;
+        default: LAUNCH_WP(128, 4, 2, 4, 2, true, true, 0, 1); break;
     }
 #undef LAUNCH_WP
 #undef LAUNCH_WP_

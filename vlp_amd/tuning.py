@@ -65,12 +65,12 @@ def dump(path):
 
 # ---- heuristics ------------------------------------------------------------------------------------------------------
 def nt_heuristic(M, N, K):
-    """vlp_gemm_nt variant (include/vlp_hip.h): +8 = XCD-aware tile order, +16 = LDS-DMA ring (raw barrier, counted vmcnt).
+    """vlp_gemm_nt variant (include/vlp_hip.h): +8 = XCD-aware tile order, +16 = LDS-DMA ring (raw barrier, counted vmcnt), 64 + cfg = wave-pipelined family.
     Measured with cold operands (tools/nt_lab.py --rotate=12), which is what a training step sees: the rings win every shape."""
     if M <= 1024:
         return 1                      # few workgroups: 128x128 LDS-DMA double buffer
     if N <= 1024:
-        return 27                     # 256x128 tiles, 3-stage ring: narrow outputs (252 workgroups at M = 10 688, N = 768)
+        return 77                     # 256x128 tiles, wave-pipelined 3-slot ring (gemm_nt_wp.hip): narrow outputs (252 workgroups at M = 10 688, N = 768)
     return 29                         # 256x256 tiles, 2-stage ring
 
 
