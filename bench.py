@@ -3,14 +3,16 @@
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+(without a launcher, `--gpus N` re-executes itself under torch.distributed.run: one rank per GPU over RCCL)
 
 One "step" = one full training iteration of the reference's loop (run_img2txt_dist.py:479-585) on a synthetic
 COCO-shape batch that is already resident in HBM: forward (region projections, embeddings, 12 BertLayers, LM head,
 masked-LM loss) + backward + loss-scaled fused Adam (+ RCCL gradient buckets when N > 1), dropout 0.1 as in training.
 Workload = BASELINE.json configs[1]: BERT-base 12L, 100 regions, seq_len 64 (L = 64+100+3 = 167), batch 64 per GPU, fp16.
 Rank 0 prints ONE JSON line: whole-job samples/s, plus
-  roofline     -- the dominant kernel (gemm_nt_kernel: every forward / dgrad GEMM): algorithmic FLOPs per launch /
-                  average launch duration, both measured live with HIP events on the launch stream over the timed steps;
+  roofline     -- the dominant kernel (vlp_gemm_nt: every forward / dgrad GEMM): algorithmic FLOPs per launch / average launch
+                  duration, measured live with HIP events on the launch stream in a second pass over the same K steps (so the
+                  brackets do not perturb the timed steps);
   cpu_baseline -- the oracle (CPU restatement of the reference, fp32 fwd+bwd+BertAdam) timed on this box's host cores
                   on a bounded sample (rank 0, N = 1 only).
 """
@@ -28,6 +30,53 @@ sys.path.insert(0, ROOT)
 METRIC = "samples/sec/node (COCO 100-region, seq64, bs64xN) fp16"
 MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 FLOP_PER_SAMPLE = 92.805e9         # fwd+bwd dense contractions at L=167
+
+
+def nt_kernel_src_sha16():
+    """sha256 over the sources of the dominant kernel family (vlp_gemm_nt): a PMC traffic file is only quoted if it was measured on this code."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "vlp_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.startswith("gemm_nt") or f == "common.h":
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic():
+    """HBM bytes per launch of the dominant kernel from the newest profiles/rNN_pmc_traffic.json (a separate rocprofv3 --pmc run of
+    this command: counters cannot be read inside the process).  Fails loudly -- (None, reason) -- when the file was measured on other
+    kernel sources than the ones built here."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, "no profiles/r*_pmc_traffic.json committed"
+    tf = files[-1]
+    rel = os.path.relpath(tf, ROOT)
+    try:
+        d = json.load(open(tf))
+    except Exception as e:      # noqa: BLE001
+        return None, "%s unreadable: %s" % (rel, e)
+    want, have = d.get("kernel_src_sha16"), nt_kernel_src_sha16()
+    if want != have:
+        return None, "%s was measured on kernel sources %s, this build is %s: stale, not quoted" % (rel, want, have)
+    return d.get("gemm_nt_bytes_per_launch"), rel + " (separate rocprofv3 --pmc run of the same command; FETCH_SIZE calibrated on fused_adam_kernel + WRITE_SIZE)"
+
+
+def self_spawn(n, argv):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU (RCCL), on this node."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        raise SystemExit("bench.py --gpus %d: this node exposes %d GPU(s); one rank per GPU is required (no oversubscription)" % (n, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def cpu_baseline_worker(seconds_budget, threads, B=16):
@@ -63,9 +112,20 @@ def cpu_baseline_worker(seconds_budget, threads, B=16):
     dt = time.time() - t0
     if n == 0:
         n, dt = 1, warm
+    tie, ref_equiv = "", None
+    try:        # the port's speed relative to the UNMODIFIED reference, measured side by side in the build container (tools/cpu_baseline_ref_vs_port.py)
+        import glob
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_baseline_reference_vs_port.json")))[-1]
+        d = json.load(open(f))
+        tie = "; the unmodified reference runs the same step at %.2fx the port's speed on the same %d threads (%s)" % (
+            d["reference_over_port"], d["threads"], os.path.relpath(f, ROOT))
+        ref_equiv = round(B * n / dt * d["reference_over_port"], 3)
+    except Exception:      # noqa: BLE001
+        pass
     return {"value": round(B * n / dt, 3), "unit": "samples/s", "cores": threads, "kind": "port", "reference_code": False, "batch": B,
-            "sample": "%d steps of B=%d, L=167, 12 layers, fp32 fwd+bwd+BertAdam (oracle/vlp_oracle.py), %d of %d host threads"
-                      % (n, B, threads, os.cpu_count() or 1)}
+            "reference_equivalent_value": ref_equiv,      # value x (reference / port speed ratio measured in the build container); derived, not timed here
+            "sample": "%d steps of B=%d, L=167, 12 layers, fp32 fwd+bwd+BertAdam (oracle/vlp_oracle.py), %d of %d host threads%s"
+                      % (n, B, threads, os.cpu_count() or 1, tie)}
 
 
 def cpu_baseline(seconds_budget=25.0, hard_timeout=150.0):
@@ -106,11 +166,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    if not torch.cuda.is_available() and not (args.gpus > 1 and "WORLD_SIZE" not in os.environ):
         raise SystemExit("bench.py needs an MI355X: vlp_amd has no CPU path")
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            self_spawn(args.gpus, sys.argv[1:])           # never returns
+        raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d" % (args.gpus, world))
     # one rank per GPU.  VLP_BENCH_SHARE_GPU=1 (test only: world-2 run of the real engine + DDP hooks on a 1-GPU box, backend gloo)
     # lets several ranks share the visible devices
     dev_index = local_rank % torch.cuda.device_count() if os.environ.get("VLP_BENCH_SHARE_GPU") == "1" else local_rank
@@ -159,8 +220,6 @@ def main():
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
-    if not args.no_kernel_events:
-        eng.prof = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -170,18 +229,30 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # roofline sampling: the SAME K steps once more, now with HIP events around every PROF_EVERY-th launch of the dominant kernel (on
+    # the launch stream).  It is a separate, un-timed pass so that the event brackets (and the side-stream joins they need) do not
+    # perturb the headline steps above.
+    if not args.no_kernel_events:
+        eng.prof = []
+        for i in range(args.steps):
+            one(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
     if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     loss = float((lt[0] + lt[1] + lt[2]).sum().detach())
-    if use_dist and os.environ.get("VLP_BENCH_CHECK_RANKS") == "1":
+    ranks_equal = None
+    if use_dist:
         # data-parallel invariant: after any number of steps every rank holds bit-identical parameters
         eng.wait_params()
         mine = torch.stack([eng.flat[k].float().sum() for k in ("decay", "nodecay")] + [eng.flat["decay"].float().abs().sum()])
         allv = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
-        if not all(torch.equal(allv[0], v) for v in allv):
+        ranks_equal = all(torch.equal(allv[0], v) for v in allv)
+        if not ranks_equal and os.environ.get("VLP_BENCH_CHECK_RANKS", "1") == "1":
             raise SystemExit("rank parameter checksums differ: %s" % [v.tolist() for v in allv])
     prof, eng.prof = eng.prof, None
 
@@ -198,18 +269,10 @@ def main():
             flops = [f for _, _, f in prof]
             achieved = (sum(flops) / len(flops)) / (sum(ms) / len(ms) * 1e-3) / 1e12
             # HBM traffic of the same kernel comes from a separate rocprofv3 --pmc pass (counters cannot be read inside this
-            # process): profiles/<round>_pmc_traffic.json, produced by tools/gpu_pmc_bench.sh on the same command; the field
-            # `traffic_source` says so.  null when no such file is committed.
-            traffic, traffic_src = None, None
-            for name in ("r02_pmc_traffic.json",):
-                tf = os.path.join(ROOT, "profiles", name)
-                if os.path.exists(tf):
-                    try:
-                        traffic = json.load(open(tf)).get("gemm_nt_bytes_per_launch")
-                        traffic_src = "profiles/" + name + " (separate rocprofv3 --pmc run of the same command; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"
-                    except Exception:
-                        traffic = None
-            roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (all forward + dgrad GEMMs; every %dth launch bracketed by HIP events)" % eng.PROF_EVERY, "achieved": round(achieved, 1),
+            # process): the newest profiles/rNN_pmc_traffic.json, produced by tools/gpu_pmc_bench.sh on the same command -- quoted
+            # only if it was measured on the kernel sources of this build (otherwise null + the reason in `traffic_source`).
+            traffic, traffic_src = committed_traffic()
+            roof = {"bound": "mfma", "kernel": "vlp_gemm_nt (gemm_nt_kernel + gemm_nt_wp_kernel: all forward + dgrad GEMMs; every %dth launch bracketed by HIP events in a second, un-timed pass over the same steps)" % eng.PROF_EVERY, "achieved": round(achieved, 1),
                     "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launches_per_step": len(prof) * eng.PROF_EVERY // max(args.steps, 1), "sampled_launches": len(prof),
                     "avg_launch_us": round(sum(ms) / len(ms) * 1e3, 2),
@@ -222,7 +285,7 @@ def main():
                                       "fwd+bwd+FP16 FusedAdam, dropout 0.1, dynamic loss scale" % (shape_name, args.layers, args.max_len_b, args.max_len_b + 103, args.batch),
                           "global_batch": world * args.batch, "parallelism": "dp%d" % world, "final_loss": round(loss, 4),
                           "loss_scale": opt.cur_scale, "skipped_steps": opt.skipped_steps,
-                          "rccl_ranks": dist.get_world_size() if use_dist else 1},
+                          "rccl_ranks": dist.get_world_size() if use_dist else 1, "rank_param_checksums_equal": ranks_equal},
                "roofline": roof}
         if os.environ.get("VLP_DEBUG_TUNE") == "1":  # noqa
             from vlp_amd.engine import Engine

@@ -135,7 +135,8 @@ def test_reference_fp16_self_spread(name):
     against the unmodified reference) is run in fp16 twice -- torch on the host CPU and torch on the MI355X (different GEMM summation
     orders, different erf / exp / softmax kernels) -- on the fixture inputs.  The north-star "logits within 1e-3 of the reference at
     fp16" can only mean "as close as the reference is to itself": the measured spread is the yardstick for criterion (i), and the
-    HIP path must be no farther from EITHER fp16 evaluation than they are from each other (+1e-3)."""
+    HIP path must be no farther from EITHER fp16 evaluation than they are from each other (+1e-3; the full-size decomposition in
+    tests/test_20_fullsize_gpu.py::test_full_size_rounding_point_decomposition attributes the difference to rounding-point placement)."""
     try:
         g, p, batch, mk = load_case(name)
     except RuntimeError as e:
@@ -156,7 +157,7 @@ def test_reference_fp16_self_spread(name):
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/parity_report.json", "w") as f:
         json.dump(REPORT, f, indent=1)
-    assert max(d_cpu, d_gpu) <= 1.5 * spread + 1e-3, REPORT[name]
+    assert max(d_cpu, d_gpu) <= spread + 1e-3, REPORT[name]
 
 
 def test_plumbing_config_8_regions():

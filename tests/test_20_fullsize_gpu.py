@@ -149,11 +149,14 @@ def test_full_size_parity_vs_device_oracle(case):
     losses = _hip(m, batch, scale=GSCALE)
     truth, gt = _oracle(p, batch, tasks, torch.float32, scale=1.0)
     ref16, g16 = _oracle(p, batch, tasks, torch.float16, scale=GSCALE)
+    with O.rounding("sum_order"):            # the reference's arithmetic once more, every contraction summed in another order
+        ref16b, _ = _oracle(p, batch, tasks, torch.float16)
     key = "vqa_logits" if tasks == "vqa2" else "mlm_logits"
     t = truth[key].float()
     ours = (m.last_vqa_logits if tasks == "vqa2" else m.last_mlm_logits).float().reshape(t.shape)
     r16 = ref16[key].float().reshape(t.shape)
     rep = {"logits_hip_vs_fp32": _relmax(ours, t), "logits_ref16_vs_fp32": _relmax(r16, t), "logits_hip_vs_ref16": _relmax(ours, r16),
+           "logits_ref16_vs_ref16_other_summation_order": _relmax(ref16b[key].float().reshape(t.shape), r16),
            "logits_relL2_hip_vs_fp32": _relL2(ours, t), "logits_relL2_ref16_vs_fp32": _relL2(r16, t)}
     lt = float(truth["loss"].sum())
     lh = float((losses[0] + losses[1] + losses[2]).sum())
@@ -197,7 +200,10 @@ def test_full_size_parity_vs_device_oracle(case):
         json.dump(per_tensor, f, indent=0)
     # ---- assertions ------------------------------------------------------------------------------------------------
     assert rep["logits_hip_vs_fp32"] <= rep["logits_ref16_vs_fp32"] + 1e-3, rep          # criterion (ii)
-    assert rep["logits_hip_vs_ref16"] <= 4e-3, rep                                          # criterion (i), two fp16 evaluations
+    # criterion (i): no farther from the reference-fp16 logits than the reference's own arithmetic is from itself under another
+    # summation order, + the north-star 1e-3 (measured 2.75e-3 vs 2.20e-3 COCO, 3.49e-3 vs 2.86e-3 VQA; the decomposition test
+    # below attributes the difference to rounding-point placement)
+    assert rep["logits_hip_vs_ref16"] <= rep["logits_ref16_vs_ref16_other_summation_order"] + 1e-3, rep
     assert abs(lh - lt) <= 2e-3 * abs(lt), rep
     assert n_checked >= (208 if tasks == "img2txt" else 206), n_checked
     for n, (rel_h, rel_r) in per_tensor.items():
@@ -209,6 +215,63 @@ def test_full_size_parity_vs_device_oracle(case):
         # 1.9e-3 (vqa2, back-propagated with a x4 scale only) above the reference-fp16 error of the same tensor
         assert rel_h <= max(1.25 * rel_r, rel_r + (1e-3 if tasks == "img2txt" else 2.5e-3)), (n, rel_h, rel_r)
         assert rel_h <= 2e-2, (n, rel_h, rel_r)
+
+
+@pytest.mark.parametrize("case", ["coco_s2s", "vqa2"])
+def test_full_size_rounding_point_decomposition(case):
+    """Where does the distance between the HIP path and the reference's fp16 arithmetic come from?  The oracle is
+    evaluated in fp16 with the reference's op-by-op rounding, with ONE group of rounding points at a time moved to where the HIP
+    kernels round (oracle.rounding flags), and with all of them moved.  The yardstick is the NOISE FLOOR of
+    fp16 arithmetic on this network: the same evaluation with every Linear's contraction summed in another order (what a different
+    GEMM tiling does; no rounding point moves) lands 1.7e-3 - 2.9e-3 max-rel (1.5e-3 - 1.9e-3 rel-L2) away from itself at 12
+    layers -- no fp16 evaluation can be closer to another than that, in any norm.  Asserted: against the evaluation that rounds
+    exactly where the HIP path rounds, the HIP logits sit AT that floor (measured 1.65e-3 vs 1.65e-3, 1.97e-3 vs 2.22e-3): nothing
+    is left to explain beyond summation order; the whole extra distance to the reference-rounding logits (2.75e-3 / 3.49e-3) is
+    rounding-point placement; and the placement costs no accuracy against the fp32 truth."""
+    c = FULL_CASES[case]
+    tasks = c["tasks"]
+    p = O.init_params(vocab_size=V, layers=12, tasks=tasks, seed=c["seed"])
+    batch = S.make_batch(B, max_len_b=64, vocab_size=V, max_pred=c["max_pred"], s2s_prob=c["s2s_prob"], tasks=tasks, seed=c["seed"] + 7)
+    key = "vqa_logits" if tasks == "vqa2" else "mlm_logits"
+    m = _build(p, tasks)
+    with torch.no_grad():
+        _hip(m, batch)
+    truth, _ = _oracle(p, batch, tasks, torch.float32)
+    t = truth[key].float()
+    ours = (m.last_vqa_logits if tasks == "vqa2" else m.last_mlm_logits).float().reshape(t.shape)
+    allk = "all flags = HIP rounding points"
+    evals = [("reference rounding", ())] + [(f, (f,)) for f in O.ROUNDING_FLAGS] + [(allk, O.ROUNDING_FLAGS),
+             ("reference rounding, other summation order", ("sum_order",)), (allk + ", other summation order", O.ROUNDING_FLAGS + ("sum_order",))]
+    table, logits = {}, {}
+    for name, flags in evals:
+        with O.rounding(*flags):
+            out, _ = _oracle(p, batch, tasks, torch.float16)
+        logits[name] = out[key].float().reshape(t.shape)
+    ref, hipr = logits["reference rounding"], logits[allk]
+    for name, l in logits.items():
+        table[name] = {"vs_fp32_truth": _relmax(l, t), "vs_hip": _relmax(l, ours), "vs_reference_rounding": _relmax(l, ref),
+                       "relL2_vs_hip": _relL2(l, ours), "relL2_vs_fp32_truth": _relL2(l, t)}
+    table["hip"] = {"vs_fp32_truth": _relmax(ours, t), "vs_reference_rounding": _relmax(ours, ref), "relL2_vs_fp32_truth": _relL2(ours, t)}
+    # noise floor: the same rounding points, another fp32 summation order
+    table["noise_floor_reference_rounding"] = {"maxrel": _relmax(logits["reference rounding, other summation order"], ref),
+                                               "relL2": _relL2(logits["reference rounding, other summation order"], ref)}
+    table["noise_floor_hip_rounding"] = {"maxrel": _relmax(logits[allk + ", other summation order"], hipr),
+                                         "relL2": _relL2(logits[allk + ", other summation order"], hipr)}
+    os.makedirs("gpurun_out", exist_ok=True)
+    path = "gpurun_out/parity_rounding_decomposition.json"
+    rep = json.load(open(path)) if os.path.exists(path) else {}
+    rep[case] = table
+    with open(path, "w") as f:
+        json.dump(rep, f, indent=1)
+    floor = table["noise_floor_hip_rounding"]
+    # (a) same rounding points: the HIP logits are as close to that evaluation as it is to its own re-ordered twin (margin: half the
+    #     north-star tolerance in max-rel, a fifth of it in rel-L2)
+    assert table[allk]["vs_hip"] <= floor["maxrel"] + 5e-4, table
+    assert table[allk]["relL2_vs_hip"] <= floor["relL2"] + 2e-4, table
+    # (b) moving the rounding points to the HIP path's places explains the gap to the reference-fp16 logits ...
+    assert table[allk]["vs_hip"] < table["reference rounding"]["vs_hip"], table
+    # (c) ... and does not cost accuracy: against the fp32 truth the HIP path is no worse than the reference's own rounding
+    assert table["hip"]["vs_fp32_truth"] <= table["reference rounding"]["vs_fp32_truth"] + 1e-3, table
 
 
 def test_full_size_logits_under_every_nt_variant():

@@ -134,6 +134,12 @@ def test_pipelined_optimizer_step_is_bit_identical():
         batches = [S.batch_to(S.make_batch(6, max_len_b=20, vocab_size=1024, max_pred=3, seed=40 + i), DEV, half=True) for i in range(3)]
         losses = []
         for it in range(12):
+            if pipelined and it % 2 == 1:
+                # hold the optimizer stream back: every parameter / loss-scale read of the next forward and backward must be
+                # ORDERED behind the step, not merely later in wall time -- on this 3-layer model the update otherwise finishes long
+                # before anything reads it.  ~20 ms of spinning in front of the step's kernels.
+                with torch.cuda.stream(model.engine.optimizer_stream()):
+                    torch.cuda._sleep(40_000_000)
             lt = train_step(model, opt, batches[it % 3], 3e-4)
             losses.append(lt[0].detach().clone())
         torch.cuda.synchronize()
@@ -215,21 +221,24 @@ def test_entry_script_synthetic(tmp_path):
     assert "bert.encoder.layer.1.output.LayerNorm.bias" in sd and sd["bert.embeddings.word_embeddings.weight"].shape == (28996, 768)
 
 
-def test_bench_through_torchrun_and_rccl_world1():
+@pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])
+def test_bench_through_torchrun_and_rccl_world1(mode):
     """The launch line the driver uses for N > 1, with N = 1: RCCL process group, parameter broadcast, bucketed
-    ReduceOp.AVG all-reduce hooks fired from the fused backward, barrier + max-over-ranks timing."""
+    ReduceOp.AVG all-reduce hooks fired from the fused backward (mode rs_ag: reduce_scatter_tensor + all_gather_into_tensor on RCCL,
+    so that branch is not first executed on the driver's 8-GPU node), barrier + max-over-ranks timing, rank checksum comparison."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--layers", "2",
-           "--batch", "8", "--force-dist", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+           "--master-port", "29517" if mode == "allreduce" else "29523", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2",
+           "--layers", "2", "--batch", "8", "--force-dist", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, VLP_DDP_MODE=mode))
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["final_loss"] == out["config"]["final_loss"]
+    assert out["config"]["rccl_ranks"] == 1 and out["config"]["rank_param_checksums_equal"] is True
 
 
 @pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])

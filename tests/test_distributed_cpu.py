@@ -4,6 +4,8 @@ completion order on flat CPU buffers."""
 import os
 import tempfile
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -91,11 +93,12 @@ def test_real_12_layer_bucket_plan():
                 end = offs[grp][n] + numel[n]
             assert end <= sizes[grp]
         # ready-slices: contiguous, in backward-completion order, covering the decay buffer exactly once
-        assert len(slices) == 12 + 2
+        assert len(slices) == 12 + 3
         assert slices[0][0] == 0 and slices[-1][1] == sizes["decay"]
         for (lo, hi), (lo2, _) in zip(slices, slices[1:]):
             assert lo < hi and hi == lo2
-        # slice 0 = task head, slices 1..12 = layers 11..0 (six weight matrices each), last = embeddings + region projections
+        # slice 0 = task head, slices 1..12 = layers 11..0 (six weight matrices each), 13 = embedding tables (final after embed_bwd),
+        # 14 = region projections (final after the last wgrads of backward)
         def owner(n):
             o = offs["decay"][n]
             return [i for i, (lo, hi) in enumerate(slices) if lo <= o < hi][0]
@@ -106,7 +109,10 @@ def test_real_12_layer_bucket_plan():
                 assert owner(L + suffix) == 12 - i, (L + suffix, owner(L + suffix))
             q, k, v = (offs["decay"][L + "attention.self.%s.weight" % x] for x in ("query", "key", "value"))
             assert k == q + 768 * 768 and v == k + 768 * 768           # packed QKV GEMM reads them as one [2304, 768] matrix
-        assert owner("bert.embeddings.word_embeddings.weight") == 13 and owner("vis_embed.0.weight") == 13
+        assert owner("bert.embeddings.word_embeddings.weight") == 13 and owner("vis_embed.0.weight") == 14
+        # the 45 MB embedding slice is its own bucket: its reduction starts before the region-projection wgrads, not after them
+        bk, fa = coalesce_buckets(slices, int(50.0 * 1024 * 1024 / 2))
+        assert bk[fa[13]] == slices[13], (bk[fa[13]], slices[13])
         assert owner("ans_classifier.0.weight" if tasks == "vqa2" else "cls.predictions.transform.dense.weight") == 0
         # coalescing to <= 50 MB of fp16: every bucket within the cap unless it is a single slice; buckets tile the buffer; a bucket
         # fires when its last slice is ready, in order
@@ -123,7 +129,7 @@ def test_real_12_layer_bucket_plan():
         assert fired == sorted(fired)
         for si, b in fire_at.items():
             assert slices[si][1] == buckets[b][1]
-        assert 5 <= len(buckets) <= 8, len(buckets)        # 231.9 MB of fp16 gradients in <= 50 MB pieces (+ the 67 MB embedding slice)
+        assert 5 <= len(buckets) <= 8, len(buckets)        # 231.9 MB of fp16 gradients in <= 50 MB pieces (the 45 MB embedding slice and the region projections are separate buckets)
         # rs_ag mode needs bucket sizes divisible by the world size (8)
         assert all((hi - lo) % 8 == 0 for lo, hi in buckets) and sizes["nodecay"] % 8 == 0
 
@@ -230,3 +236,30 @@ def test_ddp_hook_wiring_world2_gloo_allreduce():
 
 def test_ddp_hook_wiring_world2_gloo_reduce_scatter_all_gather():
     _run_world2(_ddp_worker, "rs_ag")
+
+
+def test_bench_self_spawn_for_n_gpus(monkeypatch):
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run (one rank per GPU, 127.0.0.1
+    rendezvous, the caller's arguments preserved); on a node with fewer GPUs it fails at the device count with a clear message."""
+    import importlib
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3"], capture_output=True, text=True,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and "exposes" in (r.stdout + r.stderr) and "one rank per GPU" in (r.stdout + r.stderr), (r.stdout, r.stderr)
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    seen = {}
+    monkeypatch.setattr(bench.torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    with pytest.raises(SystemExit) as e:
+        bench.self_spawn(4, ["--gpus", "4", "--steps", "3"])
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

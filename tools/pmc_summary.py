@@ -19,6 +19,8 @@ cut = ids[int(len(ids) * 0.5)]
 
 def group(name):
     n = name.split("(")[0]
+    if "gemm_nt_wp_kernel" in n:          # the wave-pipelined family is part of the dominant "vlp_gemm_nt" group
+        return "gemm_nt_kernel"
     for key in ("gemm_nt_kernel", "gemm_tn_grouped_kernel", "gemm_tn_glds_kernel", "attn_fwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel",
                 "fused_adam_kernel", "layernorm_fwd_kernel", "layernorm_bwd_kernel"):
         if key in n:
@@ -56,5 +58,13 @@ if "fused_adam_kernel" in res and "FETCH_SIZE_avg" in res["fused_adam_kernel"]:
             res[g]["bytes_per_launch"] = (factor * res[g]["FETCH_SIZE_avg"] + res[g].get("WRITE_SIZE_avg", 0.0)) * 1024.0
         if "gemm_nt_kernel" in res:
             res["gemm_nt_bytes_per_launch"] = res["gemm_nt_kernel"].get("bytes_per_launch")
+import hashlib      # noqa: E402
+import os           # noqa: E402
+_h = hashlib.sha256()
+_d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vlp_amd", "csrc")
+for _f in sorted(os.listdir(_d)):
+    if _f.startswith("gemm_nt") or _f == "common.h":
+        _h.update(open(os.path.join(_d, _f), "rb").read())
+res["kernel_src_sha16"] = _h.hexdigest()[:16]       # bench.py quotes this file only for the same kernel sources
 json.dump(res, open(out_path, "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -65,7 +65,7 @@ class GradReducer(object):
         self._work = []
 
     def _reduce(self, t):
-        if self.mode == "rs_ag" and self.world > 1 and t.numel() % self.world == 0:
+        if self.mode == "rs_ag" and t.numel() % self.world == 0:      # (also with one rank: the same RCCL calls, a path check)
             self._reduce_rs_ag(t)
         elif self._avg:
             self._work.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.pg, async_op=True), None))

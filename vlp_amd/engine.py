@@ -115,9 +115,11 @@ class Engine(object):
             L = "bert.encoder.layer.%d." % i
             add([L + "output.dense.weight", L + "intermediate.dense.weight", L + "attention.output.dense.weight",
                  L + "attention.self.query.weight", L + "attention.self.key.weight", L + "attention.self.value.weight"])
+        # two slices: the embedding tables are final after embed_bwd (45 MB: the tied word embedding), the region projections only after
+        # the three wgrads that follow -- the big slice's all-reduce overlaps them instead of waiting for the end of backward
         add(["bert.embeddings.position_embeddings.weight", "bert.embeddings.token_type_embeddings.weight",
-             "bert.embeddings.word_embeddings.weight", "vis_pe_embed.0.weight", "vis_embed.2.weight", "vis_embed.0.weight",
-             "bert.pooler.dense.weight"] + head_unused)
+             "bert.embeddings.word_embeddings.weight"])
+        add(["vis_pe_embed.0.weight", "vis_embed.2.weight", "vis_embed.0.weight", "bert.pooler.dense.weight"] + head_unused)
         nodecay = sorted(n for n in names if is_no_decay(n))
         # q/k/v biases of a layer must be contiguous (packed QKV GEMM)
         for i in range(cfg.num_hidden_layers):
@@ -134,7 +136,7 @@ class Engine(object):
     def plan_layout(self, model=None):
         """Pure function of the parameter shapes (runs on CPU, no device needed): names per flat buffer, element offsets (every
         parameter on a 128-byte boundary), buffer sizes, and the gradient buckets = contiguous slices of the decay buffer in
-        backward-completion order (head, layer N-1 .. 0, embeddings + region projections)."""
+        backward-completion order (head, layer N-1 .. 0, embedding tables, region projections)."""
         model = model if model is not None else self._model()
         numel = {n: p.numel() for n, p in model.named_parameters()}
         decay, nodecay, bucket_idx = self._ordered_names(model)
@@ -537,12 +539,14 @@ class Engine(object):
         else:
             vp = vis_pe.reshape(Mv, PE_DIM).contiguous()
             K.copy2d(vp, PE_DIM, vp.dtype == torch.float32, ws["vpe_in"], PE_PAD, Mv, PE_DIM, PE_PAD)
-        K.copy2d(self.P("vis_pe_embed.0.weight"), PE_DIM, False, ws["wpe_pad"], PE_PAD, H, PE_DIM, PE_PAD)
         st.batch = (img, input_ids.contiguous(), token_type_ids.contiguous(), masked_pos)
 
         # parameters written by a pipelined optimizer step become readable chunk by chunk (wait_params is a no-op otherwise)
         self.wait_params("nodecay")
-        self.wait_params(len(self.buckets) - 1)             # embeddings + region projections
+        self.wait_params(len(self.buckets) - 1)             # region projections
+        self.wait_params(len(self.buckets) - 2)             # embedding tables
+        # (reads a parameter of the embeddings bucket: AFTER the waits, or a pipelined step would project with last step's weight)
+        K.copy2d(self.P("vis_pe_embed.0.weight"), PE_DIM, False, ws["wpe_pad"], PE_PAD, H, PE_DIM, PE_PAD)
         # ---- region projections (modeling.py:1003-1018,1035-1036) ---------------------------------
         self._nt(img, self.P("vis_embed.0.weight"), ws["h1"], Mv, 2048, 2048, bias=self.P("vis_embed.0.bias"), act=K.ACT_RELU)
         self._nt(ws["h1"], self.P("vis_embed.2.weight"), ws["vis_h"], Mv, H, 2048, bias=self.P("vis_embed.2.bias"), act=K.ACT_RELU,
@@ -1124,6 +1128,7 @@ class Engine(object):
         K.embed_bwd(dpre, input_ids, token_type_ids, ws["vis_h"], ws["vispe_h"], self.G(E + "word_embeddings.weight"),
                     self.G(E + "position_embeddings.weight"), self.G(E + "token_type_embeddings.weight"), ws["d_vis_h"], ws["d_vispe_h"],
                     ws["acc32"], B, L, Nv, H, V, cfg.type_vocab_size, drop_p=p, seed=seed, vis_stream=1001, vispe_stream=1002)
+        self._bucket_done(NL + 1)           # position / type / word embedding tables (tied decoder wgrad + embedding backward) are final
         # vis_pe_embed: Linear(1607, H) -- wgrad into the padded shadow, then crop-accumulate
         # vis_embed: Linear(2048,2048)+ReLU -> Linear(2048,H)+ReLU+Dropout
         self._nt(ws["d_vis_h"], sh["v2T"], ws["dz1v"], Mv, 2048, H, mul_src=ws["h1"], mul_mode=K.MUL_RELU_MASK)
@@ -1139,7 +1144,7 @@ class Engine(object):
             self._tn(ws["dz1v"], img, self.G("vis_embed.0.weight"), Mv, 2048, 2048, ws, beta, bias=self.G("vis_embed.0.bias"))
         K.copy2d(ws["dwpe_pad"], PE_PAD, False, self.G("vis_pe_embed.0.weight"), PE_DIM, H, PE_DIM, PE_DIM, beta=beta)
         K.colsum(ws["d_vispe_h"], self.G("vis_pe_embed.0.bias"), Mv, H, beta=beta, workspace=ws["cs_ws"])
-        self._bucket_done(NL + 1)
+        self._bucket_done(NL + 2)
         self.grads_dirty = True
         if self.post_backward_hook is not None:
             self.post_backward_hook()

@@ -168,6 +168,9 @@ class FP16_Optimizer_State(object):
     # ---- the train-loop contract -------------------------------------------------------------------------
     def backward(self, loss):
         """apex: scaled_loss = loss.float() * cur_scale; scaled_loss.backward()   (run_img2txt_dist.py:571)"""
+        # a pipelined step (pipeline_with_forward) may still be running on the optimizer stream: its loss_scale_update is the LAST thing it
+        # enqueues, so the scale read here must be ordered behind the whole step, not only behind the first parameter chunk
+        self.engine.wait_params()
         (loss.float() * self._scale_state[0]).backward()
 
     def zero_grad(self, set_grads_to_None=True):
