@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VLP_ABI_VERSION 1
+#define VLP_ABI_VERSION 2
 
 typedef enum {
     VLP_OK = 0,
@@ -442,8 +442,12 @@ int vlp_loss_scale_update(float* scale_state, const float* overflow, void* strea
 /* BertAdam (optimization.py:112-182) over a flat fp32 master buffer made of `ntensors` tensors:
  * per-tensor L2 clip to max_grad_norm (:146-147), no bias correction, decoupled decay, lr already
  * scheduled by the host (warmup_linear :45-48).  seg_off[ntensors+1] (int64, device) are the tensor
- * boundaries inside the flat buffers, norms is f32 scratch [ntensors].  g may be fp16 or fp32.
+ * boundaries inside the flat buffers.  g may be fp16 or fp32.
+ * norms: f32 scratch of vlp_bert_adam_norms_floats(n, ntensors) floats (ABI 2; it was [ntensors] in ABI 1): [0, ntensors) receive the
+ * per-tensor squared gradient norms, the rest holds one partial sum per (4096-element chunk, tensor) pair, which a second kernel adds
+ * up in a fixed order -- no atomics: the clip factors, hence the update, are bitwise reproducible.
  */
+int64_t vlp_bert_adam_norms_floats(int64_t n, int32_t ntensors);
 typedef struct {
     float* p32; float* m; float* v;
     const void* g; int32_t g_is_f32;

@@ -199,6 +199,26 @@ def test_gemm_nt_epilogues(variant, gen):
     assert rel(y.float(), (x.float() @ w.float().t()) * gp.float()) < 1.5e-3
 
 
+def test_c_only_consumer_two_host_threads(tmp_path):
+    """tests/c_abi_smoke.c: a C program (no Python, no torch) links libvlp_hip.so through include/vlp_hip.h and drives vlp_gemm_nt +
+    vlp_layernorm_fwd from TWO host threads, each on its own stream, checking the results against plain C arithmetic (SURVEY.md 8b
+    threading contract; first calls race on the launchers' once-per-device state)."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None:
+        pytest.skip("needs gcc")
+    exe = os.path.join(str(tmp_path), "c_abi_smoke")
+    libdir = os.path.join(root, "vlp_amd")
+    r = subprocess.run(["gcc", "-O2", "-std=c11", "-D__HIP_PLATFORM_AMD__", "-D_GNU_SOURCE", "-I", os.path.join(root, "include"), "-I", "/opt/rocm/include",
+                        os.path.join(root, "tests", "c_abi_smoke.c"), "-o", exe, "-L", libdir, "-lvlp_hip", "-L", "/opt/rocm/lib", "-lamdhip64", "-lpthread",
+                        "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "c_abi_smoke ok" in r.stdout, (r.stdout, r.stderr)
+
+
 def test_gemm_nt_rejects_bad_args():
     x = torch.zeros(8, 100, device=DEV, dtype=torch.half)
     with pytest.raises(RuntimeError, match="multiple of 64"):
@@ -715,10 +735,13 @@ def test_bert_adam(g_is_f32, gen):
     g[offs[1]:offs[2]] *= 100          # one tensor far above the clip threshold
     gk = g if g_is_f32 else g.half()
     m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
-    norms = torch.zeros(len(sizes), device=DEV)
+    norms = torch.full((K.bert_adam_norms_floats(n, len(sizes)),), float("nan"), device=DEV)     # stale scratch must not matter
+    with pytest.raises(RuntimeError, match="norms"):
+        K.bert_adam(p32, m, v, gk, g_is_f32, None, seg, len(sizes), n, norms[:len(sizes)], lr=1e-3)          # ABI-1 sized scratch is refused
     p16 = torch.empty(n, device=DEV, dtype=torch.half)
     rp = p32.cpu().clone()
     rm, rv = torch.zeros(n), torch.zeros(n)
+    p0, m0, v0 = p32.clone(), m.clone(), v.clone()
     for step in range(2):
         lr = 1e-3 * O.warmup_linear((step + 1) / 20, 0.1)
         K.bert_adam(p32, m, v, gk, g_is_f32, p16, seg, len(sizes), n, norms, lr=lr, decay=0.01)
@@ -727,3 +750,15 @@ def test_bert_adam(g_is_f32, gen):
             O.bert_adam_step(rp[sl], gk.float().cpu()[sl], rm[sl], rv[sl], 0, lr=lr, weight_decay=0.01)
     assert rel(p32.cpu(), rp) < 1e-5 and rel(m.cpu(), rm) < 1e-4
     assert rel(p16.float().cpu(), p32.cpu()) < 1e-3
+    # per-tensor squared norms (clip decisions) against torch, and bitwise repeatability of the whole update (no atomics)
+    want = torch.stack([gk.float()[offs[i]:offs[i + 1]].double().pow(2).sum() for i in range(len(sizes))]).float()
+    assert rel(norms[:len(sizes)].cpu(), want.cpu()) < 1e-5
+    runs = []
+    for rep in range(3):
+        a, b, c = p0.clone(), m0.clone(), v0.clone()
+        nn_ = torch.zeros_like(norms)
+        for step in range(2):
+            K.bert_adam(a, b, c, gk, g_is_f32, None, seg, len(sizes), n, nn_, lr=1e-3, decay=0.01)
+        runs.append((a, b, c, nn_[:len(sizes)].clone()))
+    for r in runs[1:]:
+        assert all(torch.equal(x, y) for x, y in zip(runs[0], r))

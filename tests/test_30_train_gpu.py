@@ -156,6 +156,53 @@ def test_pipelined_optimizer_step_is_bit_identical():
             assert torch.equal(x, y)
 
 
+def test_apex_layout_optimizer_checkpoint_round_trip(tmp_path):
+    """Checkpoint interchange with the reference stack (optimization_fp16.py:17-80 on apex FP16_Optimizer + FusedAdam): apex_state_dict()
+    emits `optimizer_state_dict = {state: {gid: {step, exp_avg, exp_avg_sq}}, param_groups: [{..., params: [gid]}]}` + dense
+    `fp32_groups_flat` in the caller's parameter order; a torch Optimizer built the way apex builds its inner optimizer (one flat fp32
+    parameter per group) loads it; load_state_dict() of a fresh vlp_amd optimizer recognises the layout and continues bit for bit."""
+    model, p0 = small_model(drop=0.0)
+    model.train()
+    opt = FP16_Optimizer_State(FusedAdam(groups_of(model), lr=3e-4, bias_correction=False, max_grad_norm=1.0), dynamic_loss_scale=True)
+    batches = [S.batch_to(S.make_batch(4, max_len_b=20, vocab_size=1024, max_pred=3, seed=60 + i), DEV, half=True) for i in range(2)]
+    for it in range(3):
+        train_step(model, opt, batches[it % 2], 3e-4)
+    sd = opt.apex_state_dict()
+    inner = sd["optimizer_state_dict"]
+    assert set(inner) == {"state", "param_groups"} and [g["params"] for g in inner["param_groups"]] == [[0], [1]]
+    assert all(set(inner["state"][i]) == {"step", "exp_avg", "exp_avg_sq"} and inner["state"][i]["step"] == 3 for i in (0, 1))
+    # dense, caller's order: the flat master of a group == its parameters concatenated in named_parameters order
+    for i, g in enumerate(groups_of(model)):
+        want = torch.cat([q.detach().reshape(-1) for q in g["params"]])
+        assert sd["fp32_groups_flat"][i].numel() == want.numel() == inner["state"][i]["exp_avg"].numel()
+        assert torch.equal(sd["fp32_groups_flat"][i].half(), want)
+    # what apex's inner optimizer looks like to torch: one flat fp32 parameter per group
+    flats = [torch.nn.Parameter(t.clone()) for t in sd["fp32_groups_flat"]]
+    ref_inner = torch.optim.Adam([{"params": [flats[0]], "weight_decay": 0.01}, {"params": [flats[1]], "weight_decay": 0.0}], lr=3e-4)
+    ref_inner.load_state_dict({"state": {k: {kk: (torch.tensor(float(vv)) if kk == "step" else vv) for kk, vv in v.items()} for k, v in inner["state"].items()},
+                               "param_groups": [dict(g, betas=tuple(g["betas"]), amsgrad=False, maximize=False, foreach=None, capturable=False,
+                                                     differentiable=False, fused=None) for g in inner["param_groups"]]})
+    assert torch.equal(ref_inner.state[flats[0]]["exp_avg"], inner["state"][0]["exp_avg"])
+    path = os.path.join(tmp_path, "optim.1.bin")
+    torch.save({k: (v if not torch.is_tensor(v) else v.cpu()) for k, v in sd.items()}, path)
+    # resume in a fresh model + optimizer from the apex-layout file
+    m2, _ = small_model(drop=0.0)
+    m2.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()}, strict=True)
+    m2 = m2.half().to(DEV)
+    m2.train()
+    opt2 = FP16_Optimizer_State(FusedAdam(groups_of(m2), lr=3e-4, bias_correction=False, max_grad_norm=1.0), dynamic_loss_scale=True)
+    opt2.load_state_dict(torch.load(path, map_location=DEV))
+    for a, b in zip(opt._m + opt._v + opt.fp32_groups_flat, opt2._m + opt2._v + opt2.fp32_groups_flat):
+        assert torch.equal(a, b)
+    assert opt2.cur_scale == opt.cur_scale and opt2.cur_iter == opt.cur_iter and opt2.applied_steps == opt.applied_steps
+    la = train_step(model, opt, batches[1], 3e-4)
+    lb = train_step(m2, opt2, batches[1], 3e-4)
+    torch.cuda.synchronize()
+    assert torch.equal(la[0], lb[0])
+    for k in model.engine.flat:
+        assert torch.equal(model.engine.flat[k], m2.engine.flat[k]), k
+
+
 def test_exact_resume_from_model_and_optimizer_checkpoint(tmp_path):
     """N4: the optimizer checkpoint the reference left disabled (run_img2txt_dist.py:599) and the resume path (:310,:428-437):
     2 epochs in one go == 1 epoch, process "restart", resume for epoch 2 -- bit for bit, with dropout on (the engine's mask-stream

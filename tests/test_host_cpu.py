@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libvlp_hip.so does not export %s" % name
     assert declared == set(_lib.SYMBOLS.keys()), declared ^ set(_lib.SYMBOLS.keys())
-    assert lib.vlp_version() == 1
+    assert lib.vlp_version() == 2
     # exported symbols visible to a plain dynamic loader (what a cgo/JNI/ctypes binding would see)
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (vlp_[a-z0-9_]+)", out))
@@ -224,3 +224,16 @@ def test_launch_plan_record_and_replay(monkeypatch):
         _lib.load().vlp_b(13)
     with pytest.raises(RuntimeError, match="boom"):
         _lib.replay(bad)
+
+
+def test_header_is_plain_c_and_the_c_consumer_compiles():
+    """include/vlp_hip.h stands alone: a C (not C++) translation unit that includes it and calls the entry points compiles with gcc
+    (tests/c_abi_smoke.c; it is linked against libvlp_hip.so and run on the GPU box by tests/test_00_kernels_gpu.py)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("needs gcc and the ROCm headers")
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-D_GNU_SOURCE", "-I", os.path.join(root, "include"), "-I", "/opt/rocm/include",
+                        "-fsyntax-only", os.path.join(root, "tests", "c_abi_smoke.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

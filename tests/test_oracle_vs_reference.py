@@ -186,3 +186,48 @@ def test_text_preprocessor_reproduces_reference_sample_stream(mode, n_tokens, se
     assert t["task_idx"] == task_idx and t["len_b"] == nb
     spec = MaskSpec.from_lengths(t["len_a"], [t["len_b"]], [t["is_s2s"]])
     assert torch.equal(spec.dense(123)[0], input_mask)
+
+
+def test_h5_to_packed_store_against_the_reference_loader(tmp_path, monkeypatch):
+    """N3 converter on the reference's own file layout (seq2seq_loader.py:325-330: `<prefix>_feat<id[-3:]>.h5`, `<prefix>_cls<id[-3:]>.h5`,
+    one bbox file, datasets keyed by image id): vlp_amd.data.pack_from_h5 reads the SAME (in-memory) h5 files the UNMODIFIED
+    Preprocess4Seq2seq.__call__ reads, and a batch gathered from the packed store equals what the reference loader hands to the model:
+    `img` bit for bit, `vis_pe` through the restated box / class encoding."""
+    import sys
+    import types
+    from oracle import loader_oracle as LO
+    from oracle.make_golden import loader_raw_inputs
+    from vlp_amd.data import PackedRegionStore, pack_from_h5
+    L = ref_loader.load_reference_loader()
+    seeds = [11, 12, 13]
+    ids, raw = [], {}
+    for sd in seeds:
+        bbox, cls, feat, tokens = loader_raw_inputs(sd)
+        img_id = "COCO_%06d" % (1000 + 37 * sd)                      # distinct 3-character suffixes -> distinct shard files
+        ids.append(img_id)
+        raw[img_id] = (bbox, cls, feat, tokens)
+        ref_loader.H5_REGISTRY["det_feat" + img_id[-3:] + ".h5"] = {img_id: feat}
+        ref_loader.H5_REGISTRY["det_cls" + img_id[-3:] + ".h5"] = {img_id: cls}
+    ref_loader.H5_REGISTRY["bbox.h5"] = {i: raw[i][0].copy() for i in ids}
+    monkeypatch.setitem(sys.modules, "h5py", types.SimpleNamespace(File=ref_loader._FakeH5File))
+    pack_from_h5("det", "bbox.h5", ids, str(tmp_path))
+    st = PackedRegionStore(str(tmp_path))
+    assert len(st) == 3 and st.nv == 100
+    order = [ids[2], ids[0], ids[1]]
+    f = np.empty((3, 100, 2048), np.float16)
+    c = np.empty((3, 100, 1601), np.float16)
+    b = np.empty((3, 100, 6), np.float32)
+    st.gather(st.rows(order), f, c, b)
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + ["w%d" % i for i in range(200)]
+    idx = {w: i for i, w in enumerate(vocab)}
+    proc = L.Preprocess4Seq2seq(3, 0.15, vocab, lambda toks: [idx[t] for t in toks], max_len=123, new_segment_ids=True,
+                                truncate_config={"max_len_b": 20, "trunc_seg": "b", "always_truncate_tail": True}, mode="s2s",
+                                len_vis_input=100, enable_butd=True, region_bbox_file="bbox.h5", region_det_file_prefix="det")
+    import random
+    for j, img_id in enumerate(order):
+        random.seed(5 + j)
+        out = proc(("/data/" + img_id + ".jpg", ["w%d" % int(t) for t in raw[img_id][3][:12]]))
+        img, vis_pe = out[8], out[10]
+        assert np.array_equal(img.numpy(), f[j].astype(np.float32))                       # features: the same fp16 values
+        mine = LO.vis_pe_prepare(b[j], c[j].astype(np.float32))
+        assert vis_pe.shape == (100, 1607) and np.abs(vis_pe.numpy() - mine).max() < 2e-4   # box / class encoding from the store's rows

@@ -173,6 +173,7 @@ SYMBOLS = {
     "vlp_adam_hyper": (C.c_int, [vp, vp, vp, f32, f32, vp, vp]),
     "vlp_loss_scale_update": (C.c_int, [vp, vp, vp]),
     "vlp_bert_adam": (C.c_int, [C.POINTER(BertAdamArgs), vp]),
+    "vlp_bert_adam_norms_floats": (i64, [i64, i32]),
 }
 
 _lib = None
@@ -240,7 +241,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.vlp_version() != 1:
+    if lib.vlp_version() != 2:      # include/vlp_hip.h VLP_ABI_VERSION
         raise RuntimeError("libvlp_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -569,9 +570,16 @@ def fused_adam(p32, m, v, g16, p16, n, hyper, b1=0.9, b2=0.999, eps=1e-8, decay=
     _check(load().vlp_fused_adam(C.byref(a), stream_ptr()))
 
 
+def bert_adam_norms_floats(n, ntensors):
+    return int(load().vlp_bert_adam_norms_floats(n, ntensors))
+
+
 def bert_adam(p32, m, v, g, g_is_f32, p16, seg_off, ntensors, n, norms, lr, b1=0.9, b2=0.999, eps=1e-6, decay=0.01,
               max_grad_norm=1.0, grad_scale=1.0, active=None):
     _req_cuda(p32, m, v, g, seg_off, norms)
+    if norms.numel() < bert_adam_norms_floats(n, ntensors):
+        raise RuntimeError("vlp_bert_adam: `norms` needs vlp_bert_adam_norms_floats(n, ntensors) = %d floats, got %d"
+                           % (bert_adam_norms_floats(n, ntensors), norms.numel()))
     a = BertAdamArgs(ptr(p32), ptr(m), ptr(v), ptr(g), int(g_is_f32), ptr(p16), ptr(seg_off), ntensors, n, ptr(norms),
                      lr, b1, b2, eps, decay, max_grad_norm, grad_scale, ptr(active))
     _check(load().vlp_bert_adam(C.byref(a), stream_ptr()))

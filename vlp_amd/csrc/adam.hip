@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* __restri
 }
 extern "C" int vlp_sumsq(const void* g, int64_t n, float* out2, float* partial, void* stream) {
     VLP_CHECK_ARG(g && out2 && partial && n > 0 && (uintptr_t)g % 16 == 0, "vlp_sumsq: bad args (partial must hold 2048 floats)");
+    VLP_ENTER(g, "vlp_sumsq");
     int blocks = (int)((n / 8 + 255) / 256);
     if (blocks > SQ_BLOCKS) blocks = SQ_BLOCKS;
     if (blocks < 1) blocks = 1;
@@ -89,6 +90,7 @@ __global__ void adam_hyper_kernel(const float* sumsq2, const float* any_overflow
 extern "C" int vlp_adam_hyper(const float* sumsq2, const float* any_overflow, const float* scale_state, float max_grad_norm, float step_size,
                               float* hyper3, void* stream) {
     VLP_CHECK_ARG(sumsq2 && hyper3 && scale_state, "vlp_adam_hyper: bad args");
+    VLP_ENTER(sumsq2, "vlp_adam_hyper");
     hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sumsq2, any_overflow, scale_state, max_grad_norm, step_size, hyper3);
     VLP_CHECK_LAUNCH("vlp_adam_hyper");
     return VLP_OK;
@@ -112,6 +114,7 @@ __global__ void loss_scale_update_kernel(float* st, const float* overflow) {
 }
 extern "C" int vlp_loss_scale_update(float* scale_state, const float* overflow, void* stream) {
     VLP_CHECK_ARG(scale_state && overflow, "vlp_loss_scale_update: bad args");
+    VLP_ENTER(scale_state, "vlp_loss_scale_update");
     hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scale_state, overflow);
     VLP_CHECK_LAUNCH("vlp_loss_scale_update");
     return VLP_OK;
@@ -173,6 +176,7 @@ __global__ __launch_bounds__(256) void fused_adam_kernel(vlp_fused_adam_args a) 
 }
 extern "C" int vlp_fused_adam(const vlp_fused_adam_args* a, void* stream) {
     VLP_CHECK_ARG(a && a->p32 && a->m && a->v && a->g16 && a->p16 && a->hyper, "vlp_fused_adam: null operand");
+    VLP_ENTER(a->p32, "vlp_fused_adam");
     VLP_CHECK_ARG(a->n > 0 && a->n % 8 == 0, "vlp_fused_adam: n must be a positive multiple of 8 (pad the flat buffer)");
     VLP_CHECK_ARG(((uintptr_t)a->p32 | (uintptr_t)a->m | (uintptr_t)a->v | (uintptr_t)a->g16 | (uintptr_t)a->p16) % 16 == 0, "vlp_fused_adam: alignment");
     int blocks = (int)((a->n / 8 + 255) / 256);
@@ -183,7 +187,9 @@ extern "C" int vlp_fused_adam(const vlp_fused_adam_args* a, void* stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// BertAdam: pass 1 = per-tensor sum of squares (one block per (tensor, slice), atomics into norms[]),
+// BertAdam: pass 1a = partial sums of squares per (4096-element chunk, tensor) pair into norms[ntensors + chunk + tensor] (the slots of
+// successive pairs are strictly increasing: a tensor's chunks are consecutive and the next tensor starts in the chunk the previous one
+// ended in or later), pass 1b = one wave per tensor adds its partials in chunk order into norms[tensor] -- deterministic, no atomics;
 // pass 2 = update with the per-tensor clip coefficient.
 // ---------------------------------------------------------------------------------------------
 #define BA_CHUNK 4096   // elements per block in both passes
@@ -220,10 +226,25 @@ __global__ __launch_bounds__(256) void bert_adam_norm_kernel(vlp_bert_adam_args 
         __syncthreads();
         if (l == 0) sh[w] = s;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(a.norms + t, sh[0] + sh[1] + sh[2] + sh[3]);
+        if (threadIdx.x == 0) a.norms[a.ntensors + (int64_t)blockIdx.x + t] = sh[0] + sh[1] + sh[2] + sh[3];
         pos = tend;
         ++t;
     }
+}
+__global__ __launch_bounds__(64) void bert_adam_norm_finish_kernel(vlp_bert_adam_args a) {
+    const int t = blockIdx.x;
+    if (a.active && !a.active[t]) { if (threadIdx.x == 0) a.norms[t] = 0.f; return; }
+    const int64_t lo = a.seg_off[t], hi = a.seg_off[t + 1];
+    if (hi <= lo) { if (threadIdx.x == 0) a.norms[t] = 0.f; return; }
+    const int64_t c0 = lo / BA_CHUNK, c1 = (hi - 1) / BA_CHUNK;
+    const float* part = a.norms + a.ntensors + t;
+    float s = 0.f;
+    for (int64_t c = c0 + threadIdx.x; c <= c1; c += 64) s += part[c];       // lane l: chunks c0 + l, c0 + l + 64, ... (fixed order)
+    s = wave_sum(s);
+    if (threadIdx.x == 0) a.norms[t] = s;
+}
+extern "C" int64_t vlp_bert_adam_norms_floats(int64_t n, int32_t ntensors) {
+    return (int64_t)ntensors + (n + BA_CHUNK - 1) / BA_CHUNK + (int64_t)ntensors;
 }
 __global__ __launch_bounds__(256) void bert_adam_update_kernel(vlp_bert_adam_args a) {
     const int64_t start = (int64_t)blockIdx.x * BA_CHUNK;
@@ -258,13 +279,13 @@ __global__ __launch_bounds__(256) void bert_adam_update_kernel(vlp_bert_adam_arg
 }
 extern "C" int vlp_bert_adam(const vlp_bert_adam_args* a, void* stream) {
     VLP_CHECK_ARG(a && a->p32 && a->m && a->v && a->g && a->seg_off && a->norms, "vlp_bert_adam: null operand");
+    VLP_ENTER(a->p32, "vlp_bert_adam");
     VLP_CHECK_ARG(a->n > 0 && a->ntensors > 0 && a->grad_scale > 0.f, "vlp_bert_adam: bad sizes");
     hipStream_t s = (hipStream_t)stream;
     const int blocks = (int)((a->n + BA_CHUNK - 1) / BA_CHUNK);
     if (a->max_grad_norm > 0.f) {
-        hipError_t e = hipMemsetAsync(a->norms, 0, sizeof(float) * a->ntensors, s);
-        if (e != hipSuccess) return vlp_set_error(VLP_ERR_HIP, "vlp_bert_adam: memset: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(bert_adam_norm_kernel, dim3(blocks), dim3(256), 0, s, *a);
+        hipLaunchKernelGGL(bert_adam_norm_finish_kernel, dim3(a->ntensors), dim3(64), 0, s, *a);
         VLP_CHECK_LAUNCH("vlp_bert_adam(norm)");
     }
     hipLaunchKernelGGL(bert_adam_update_kernel, dim3(blocks), dim3(256), 0, s, *a);

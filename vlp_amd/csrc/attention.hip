@@ -622,8 +622,7 @@ static int launch_attn_fwd(AttnParams& p, hipStream_t s) {
     static const int nw12 = attn_waves_nt12();
 #define LAUNCH_FWD(NT_, NW_)                                                                                         \
     do {                                                                                                             \
-        static bool attr = false;                                                                                    \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NT_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; } \
+        VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NT_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                                                            \
         hipLaunchKernelGGL((attn_fwd_kernel<NT_, NW_>), grid, dim3((NW_) * 64), smem, s, p);                           \
     } while (0)
     if (LP == 64) LAUNCH_FWD(4, 8); else if (LP == 128) LAUNCH_FWD(8, 8);
@@ -636,6 +635,7 @@ static int launch_attn_fwd(AttnParams& p, hipStream_t s) {
 
 extern "C" int vlp_attn_fwd(const vlp_attn_fwd_args* a, void* stream) {
     VLP_CHECK_ARG(a != nullptr, "vlp_attn_fwd: null args");
+    VLP_ENTER(a->qkv, "vlp_attn_fwd");
     int rc = attn_common_check("vlp_attn_fwd", a->qkv, a->ld_qkv, a->mask, a->B, a->L, a->heads);
     if (rc) return rc;
     VLP_CHECK_ARG(a->ctx && a->lse && a->ld_ctx % 4 == 0 && (uintptr_t)a->ctx % 8 == 0, "vlp_attn_fwd: ctx/lse");
@@ -653,6 +653,7 @@ extern "C" int vlp_attn_fwd(const vlp_attn_fwd_args* a, void* stream) {
 
 extern "C" int vlp_attn_decode(const vlp_attn_decode_args* a, void* stream) {
     VLP_CHECK_ARG(a != nullptr && a->q && a->k && a->v && a->mask && a->ctx, "vlp_attn_decode: null operand");
+    VLP_ENTER(a->q, "vlp_attn_decode");
     VLP_CHECK_ARG(a->B > 0 && a->heads > 0 && a->Lq > 0 && a->Lk > 0 && a->Lk <= 256, "vlp_attn_decode: bad shape (Lk <= 256)");
     VLP_CHECK_ARG(a->ld_q % 8 == 0 && a->ld_kv % 8 == 0 && a->ld_ctx % 4 == 0, "vlp_attn_decode: leading dims");
     VLP_CHECK_ARG(((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) % 16 == 0 && (uintptr_t)a->ctx % 8 == 0 && (uintptr_t)a->mask % 4 == 0,
@@ -680,6 +681,7 @@ extern "C" int vlp_attn_decode(const vlp_attn_decode_args* a, void* stream) {
 
 extern "C" int vlp_attn_bwd(const vlp_attn_bwd_args* a, void* stream) {
     VLP_CHECK_ARG(a != nullptr, "vlp_attn_bwd: null args");
+    VLP_ENTER(a->qkv, "vlp_attn_bwd");
     int rc = attn_common_check("vlp_attn_bwd", a->qkv, a->ld_qkv, a->mask, a->B, a->L, a->heads);
     if (rc) return rc;
     VLP_CHECK_ARG(a->ctx && a->dctx && a->lse && a->dqkv && a->delta && a->mask_t, "vlp_attn_bwd: null operand");
@@ -704,12 +706,8 @@ extern "C" int vlp_attn_bwd(const vlp_attn_bwd_args* a, void* stream) {
     static const int nw12 = attn_waves_nt12();
 #define LAUNCH_BWD(NT_, NW_)                                                                                         \
     do {                                                                                                             \
-        static bool attr = false;                                                                                    \
-        if (!attr) {                                                                                                 \
-            hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dq);   \
-            hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<NT_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dkv); \
-            attr = true;                                                                                             \
-        }                                                                                                            \
+        VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dq)); \
+        VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<NT_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dkv)); \
         hipLaunchKernelGGL(attn_bwd_dq_kernel<NT_>, grid, block, smem_dq, s, p);                                     \
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<NT_, NW_>), grid, dim3((NW_) * 64), smem_dkv, s, p);                   \
     } while (0)
@@ -741,6 +739,7 @@ __global__ void mask_pack_kernel(const int64_t* mask, uint8_t* out, uint8_t* out
 }
 extern "C" int vlp_mask_pack(const int64_t* mask, uint8_t* out, uint8_t* out_t, int32_t B, int32_t L, int32_t Lp, void* stream) {
     VLP_CHECK_ARG(mask && out && B > 0 && L > 0, "vlp_mask_pack: bad args");
+    VLP_ENTER(mask, "vlp_mask_pack");
     VLP_CHECK_ARG(Lp == (L + 31) / 32 * 32, "vlp_mask_pack: Lp must be roundup32(L)");
     const int64_t total = (int64_t)B * L * Lp + (out_t ? (int64_t)B * Lp * Lp : 0);
     int blocks = (int)((total + 255) / 256);
@@ -764,6 +763,7 @@ __global__ void mask_pack_rect_kernel(const int64_t* mask, int64_t bs, int64_t r
 extern "C" int vlp_mask_pack_rect(const int64_t* mask, int64_t batch_stride, int64_t row_stride, uint8_t* out, int32_t B, int32_t Lq, int32_t Lk,
                                   int32_t Lkp, void* stream) {
     VLP_CHECK_ARG(mask && out && B > 0 && Lq > 0 && Lk > 0 && Lkp == (Lk + 31) / 32 * 32, "vlp_mask_pack_rect: bad args");
+    VLP_ENTER(mask, "vlp_mask_pack_rect");
     const int64_t total = (int64_t)B * Lq * Lkp;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
@@ -805,6 +805,7 @@ __global__ void mask_build_kernel(const int32_t* st, const int32_t* en, const in
 extern "C" int vlp_mask_build(const int32_t* second_st, const int32_t* second_end, const int32_t* is_s2s, uint8_t* out, uint8_t* out_t, int32_t B,
                               int32_t L, int32_t Lp, void* stream) {
     VLP_CHECK_ARG(second_st && second_end && is_s2s && out && B > 0 && L > 0, "vlp_mask_build: bad args");
+    VLP_ENTER(second_st, "vlp_mask_build");
     VLP_CHECK_ARG(Lp == (L + 31) / 32 * 32, "vlp_mask_build: Lp must be roundup32(L)");
     const int64_t total = (int64_t)B * L * Lp + (out_t ? (int64_t)B * Lp * Lp : 0);
     int blocks = (int)((total + 255) / 256);

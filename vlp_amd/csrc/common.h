@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "vlp_hip.h"
 
 typedef _Float16 f16;
@@ -31,6 +33,30 @@ int vlp_set_error(int code, const char* fmt, ...);
     } while (0)
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------------
+// device selection on entry (SURVEY.md 8b threading contract): every entry point makes the device that owns its first operand current
+// for the calling thread (hipPointerGetAttributes; skipped on single-GPU processes), so the library can be driven from any host thread
+// and for several devices of one process.  A host pointer is refused here with a clear message instead of faulting in a kernel.
+// ---------------------------------------------------------------------------------------------
+int vlp_enter_device(const void* device_ptr, const char* who);      // api.cpp; returns VLP_OK or VLP_ERR_BAD_ARG / VLP_ERR_HIP
+int vlp_current_device(void);                                       // the device vlp_enter_device selected for this thread (hipGetDevice otherwise)
+#define VLP_ENTER(ptr, who)                                 \
+    do {                                                    \
+        const int erc_ = vlp_enter_device((ptr), (who));    \
+        if (erc_ != VLP_OK) return erc_;                    \
+    } while (0)
+// launcher state that HIP keeps per device (hipFuncSetAttribute: dynamic LDS limit): set once per (kernel instantiation, device), race-free --
+// two threads may both run `stmt` (idempotent), nobody launches before it has run on his device
+#define VLP_ONCE_PER_DEVICE(stmt)                                                      \
+    do {                                                                               \
+        static std::atomic<uint64_t> once_mask_{0};                                    \
+        const uint64_t once_bit_ = 1ull << (vlp_current_device() & 63);                \
+        if (!(once_mask_.load(std::memory_order_acquire) & once_bit_)) {               \
+            stmt;                                                                      \
+            once_mask_.fetch_or(once_bit_, std::memory_order_release);                 \
+        }                                                                              \
+    } while (0)
 
 // ---------------------------------------------------------------------------------------------
 // counter-based dropout RNG.  keep(seed, stream, idx) is a pure function, so backward recomputes the

@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(vlp_embed_fwd_args a) {
 }
 extern "C" int vlp_embed_fwd(const vlp_embed_fwd_args* a, void* stream) {
     VLP_CHECK_ARG(a && a->input_ids && a->segment_ids && a->word_emb && a->pos_emb && a->type_emb && a->pre, "vlp_embed_fwd: null operand");
+    VLP_ENTER(a->pre, "vlp_embed_fwd");
     VLP_CHECK_ARG(a->H % 8 == 0 && a->B > 0 && a->L > 0 && a->Nv >= 0 && a->Nv + 1 < a->L + 1, "vlp_embed_fwd: bad shape");
     VLP_CHECK_ARG(a->Nv == 0 || (a->vis_h && a->vispe_h), "vlp_embed_fwd: region rows need vis_h / vispe_h");
     const int64_t total = (int64_t)a->B * a->L * (a->H / 8);
@@ -275,6 +276,7 @@ extern "C" int64_t vlp_embed_bwd_workspace_floats(int32_t B, int32_t L, int32_t 
 }
 extern "C" int vlp_embed_bwd(const vlp_embed_bwd_args* a, void* stream) {
     VLP_CHECK_ARG(a && a->dpre && a->input_ids && a->segment_ids && a->d_word_emb && a->d_pos_emb && a->d_type_emb && a->acc32, "vlp_embed_bwd: null operand");
+    VLP_ENTER(a->dpre, "vlp_embed_bwd");
     VLP_CHECK_ARG(a->H % 8 == 0 && a->H <= 2048 && a->B > 0 && a->L > a->Nv && a->type_vocab >= 1 && a->type_vocab <= EMB_MAXT,
                   "vlp_embed_bwd: bad shape (H % 8 == 0, H <= 2048, L > Nv, type_vocab <= 8)");
     VLP_CHECK_ARG(a->Nv == 0 || (a->vis_h && a->vispe_h && a->d_vis_h && a->d_vispe_h), "vlp_embed_bwd: region buffers");
@@ -326,6 +328,7 @@ __global__ void copy2d_kernel(const void* src, int64_t lds, int src_f32, f16* ds
 extern "C" int vlp_copy2d(const void* src, int64_t lds, int32_t src_f32, void* dst, int64_t ldd, int32_t rows, int32_t cols_src,
                           int32_t cols_dst, int32_t beta, void* stream) {
     VLP_CHECK_ARG(src && dst && rows > 0 && cols_src > 0 && cols_dst > 0, "vlp_copy2d: bad args");
+    VLP_ENTER(src, "vlp_copy2d");
     VLP_CHECK_ARG(lds >= (cols_src < cols_dst ? cols_src : cols_dst) && ldd >= cols_dst, "vlp_copy2d: leading dims");
     const int64_t total = (int64_t)rows * cols_dst;
     int blocks = (int)((total + 255) / 256);
@@ -353,6 +356,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const f16* __restrict__ 
 }
 extern "C" int vlp_transpose(const void* src, int64_t lds, void* dst, int64_t ldd, int32_t rows, int32_t cols, int32_t rows_pad, void* stream) {
     VLP_CHECK_ARG(src && dst && rows > 0 && cols > 0 && rows_pad >= rows && ldd >= rows_pad && lds >= cols, "vlp_transpose: bad args");
+    VLP_ENTER(src, "vlp_transpose");
     dim3 grid(cdiv(cols, 64), cdiv(rows_pad, 64));
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)src, lds, (f16*)dst, ldd, rows, cols, rows_pad);
     VLP_CHECK_LAUNCH("vlp_transpose");
@@ -376,6 +380,7 @@ __global__ void gather_rows_kernel(const f16* src, int64_t lds, const int64_t* p
 extern "C" int vlp_gather_rows(const void* src, int64_t lds, const int64_t* pos, void* out, int64_t ldo, int32_t B, int32_t P, int32_t L,
                                int32_t H, void* stream) {
     VLP_CHECK_ARG(src && pos && out && B > 0 && P > 0 && L > 0 && H % 8 == 0 && lds % 8 == 0 && ldo % 8 == 0, "vlp_gather_rows: bad args");
+    VLP_ENTER(src, "vlp_gather_rows");
     const int64_t total = (int64_t)B * P * (H / 8);
     hipLaunchKernelGGL(gather_rows_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)src, lds, pos,
                        (f16*)out, ldo, B, P, L, H);
@@ -399,6 +404,7 @@ __global__ void scatter_add_rows_kernel(const f16* src, int64_t lds, const int64
 extern "C" int vlp_scatter_add_rows(const void* src, int64_t lds, const int64_t* pos, void* dst, int64_t ldd, int32_t B, int32_t P, int32_t L,
                                     int32_t H, void* stream) {
     VLP_CHECK_ARG(src && pos && dst && B > 0 && P > 0 && L > 0 && H % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0, "vlp_scatter_add_rows: bad args");
+    VLP_ENTER(src, "vlp_scatter_add_rows");
     const int64_t total = (int64_t)B * P * (H / 8);
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)src, lds,
                        pos, (f16*)dst, ldd, B, P, L, H);
@@ -417,6 +423,7 @@ __global__ void vqa_mul_fwd_kernel(const f16* h, f16* out, int B, int L, int Nv,
 }
 extern "C" int vlp_vqa_mul_fwd(const void* h, void* out, int32_t B, int32_t L, int32_t Nv, int32_t H, void* stream) {
     VLP_CHECK_ARG(h && out && B > 0 && Nv + 1 < L, "vlp_vqa_mul_fwd: bad args");
+    VLP_ENTER(h, "vlp_vqa_mul_fwd");
     hipLaunchKernelGGL(vqa_mul_fwd_kernel, dim3(cdiv((int64_t)B * H, 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)h, (f16*)out, B, L, Nv, H);
     VLP_CHECK_LAUNCH("vlp_vqa_mul_fwd");
     return VLP_OK;
@@ -435,6 +442,7 @@ __global__ void vqa_mul_bwd_kernel(const f16* h, const f16* dout, f16* dh, int B
 }
 extern "C" int vlp_vqa_mul_bwd(const void* h, const void* dout, void* dh, int32_t B, int32_t L, int32_t Nv, int32_t H, void* stream) {
     VLP_CHECK_ARG(h && dout && dh && B > 0 && Nv + 1 < L, "vlp_vqa_mul_bwd: bad args");
+    VLP_ENTER(h, "vlp_vqa_mul_bwd");
     hipLaunchKernelGGL(vqa_mul_bwd_kernel, dim3(cdiv((int64_t)B * H, 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)h, (const f16*)dout,
                        (f16*)dh, B, L, Nv, H);
     VLP_CHECK_LAUNCH("vlp_vqa_mul_bwd");
@@ -461,6 +469,7 @@ __global__ void relu_dropout_bwd_kernel(const f16* dy, const f16* y, f16* dz, in
 extern "C" int vlp_relu_dropout_bwd(const void* dy, const void* y, void* dz, int64_t n, int64_t ncols, float drop_p, uint64_t seed,
                                     uint32_t rng_stream, void* stream) {
     VLP_CHECK_ARG(dy && y && dz && n > 0 && ncols > 0 && ncols % 8 == 0 && n % ncols == 0, "vlp_relu_dropout_bwd: contiguous [rows, ncols], ncols % 8 == 0");
+    VLP_ENTER(dy, "vlp_relu_dropout_bwd");
     int blocks = (int)((n / 8 + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)dy, (const f16*)y, (f16*)dz, n / 8, ncols,
@@ -480,6 +489,7 @@ __global__ void gelu_bwd_kernel(const f16* dy, const f16* z, f16* dz, int64_t n8
 }
 extern "C" int vlp_gelu_bwd(const void* dy, const void* z, void* dz, int64_t n, void* stream) {
     VLP_CHECK_ARG(dy && z && dz && n > 0 && n % 8 == 0, "vlp_gelu_bwd: n must be a positive multiple of 8");
+    VLP_ENTER(dy, "vlp_gelu_bwd");
     int blocks = (int)((n / 8 + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)dy, (const f16*)z, (f16*)dz, n / 8);
@@ -533,6 +543,7 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const vlp_transp
 }
 extern "C" int vlp_transpose_batched(const vlp_transpose_desc* descs_dev, const int32_t* tile_start_dev, int32_t n, int32_t total_tiles, void* stream) {
     VLP_CHECK_ARG(descs_dev && tile_start_dev && n > 0 && total_tiles > 0, "vlp_transpose_batched: bad args");
+    VLP_ENTER(descs_dev, "vlp_transpose_batched");
     hipLaunchKernelGGL(transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, descs_dev, tile_start_dev, n);
     VLP_CHECK_LAUNCH("vlp_transpose_batched");
     return VLP_OK;
@@ -555,6 +566,7 @@ __global__ void kv_append_kernel(const f16* qkv, int64_t ld, f16* cache, int Lca
 }
 extern "C" int vlp_kv_append(const void* qkv_new, int64_t ld, void* cache, int32_t Lcap, int32_t B, int32_t T, int32_t start, int32_t H, void* stream) {
     VLP_CHECK_ARG(qkv_new && cache && B > 0 && T > 0 && start >= 0 && start + T <= Lcap && H % 8 == 0 && ld % 8 == 0, "vlp_kv_append: bad args");
+    VLP_ENTER(qkv_new, "vlp_kv_append");
     const int64_t total = (int64_t)B * T * (2 * H / 8);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
@@ -591,6 +603,7 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const f16* logits, int
 extern "C" int vlp_argmax_rows(const void* logits, int64_t ld, int32_t rows, int32_t V, int64_t* ids, int64_t ids_stride, float* vals,
                                int64_t vals_stride, void* stream) {
     VLP_CHECK_ARG(logits && ids && vals && rows > 0 && V > 0 && ld >= V, "vlp_argmax_rows: bad args");
+    VLP_ENTER(logits, "vlp_argmax_rows");
     hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const f16*)logits, ld, V, ids, ids_stride, vals, vals_stride);
     VLP_CHECK_LAUNCH("vlp_argmax_rows");
     return VLP_OK;
@@ -737,6 +750,7 @@ __global__ __launch_bounds__(256) void logsoftmax_topk_small_kernel(const f16* l
 extern "C" int vlp_logsoftmax_topk(const void* logits, int64_t ld, int32_t rows, int32_t V, int32_t K, const uint8_t* forbid, int32_t eos_id,
                                    int32_t block_eos, float* out_scores, int64_t* out_ids, void* stream) {
     VLP_CHECK_ARG(logits && out_scores && out_ids && rows > 0 && V > 0 && K > 0 && K <= V && ld >= V, "vlp_logsoftmax_topk: bad args");
+    VLP_ENTER(logits, "vlp_logsoftmax_topk");
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_TOPK(KM) hipLaunchKernelGGL(logsoftmax_topk_small_kernel<KM>, dim3(rows), dim3(256), 0, s, (const f16*)logits, ld, V, K, forbid, eos_id, \
                                            block_eos, out_scores, out_ids)
@@ -788,6 +802,7 @@ __global__ void beam_select_kernel(vlp_beam_select_args a) {
 extern "C" int vlp_beam_select(const vlp_beam_select_args* a, void* stream) {
     VLP_CHECK_ARG(a && a->kk_scores && a->kk_ids && a->out_scores && a->out_ids && a->out_ptrs && a->out_eos && a->src_rows && a->next_ids,
                   "vlp_beam_select: null operand");
+    VLP_ENTER(a->kk_scores, "vlp_beam_select");
     VLP_CHECK_ARG(a->B > 0 && a->K > 0 && a->K <= 64 && (a->first || (a->last_total && a->last_eos)), "vlp_beam_select: bad args");
     hipLaunchKernelGGL(beam_select_kernel, dim3(a->B), dim3(64), 0, (hipStream_t)stream, *a);
     VLP_CHECK_LAUNCH("vlp_beam_select");
@@ -810,6 +825,7 @@ extern "C" int vlp_kv_gather(const void* src, int64_t src_rows_per_batch, void* 
                              int32_t lo, int32_t hi, int32_t row_elems, void* stream) {
     VLP_CHECK_ARG(src && dst && idx && R > 0 && lo >= 0 && hi >= lo && hi <= src_rows_per_batch && hi <= dst_rows_per_batch && row_elems % 8 == 0,
                   "vlp_kv_gather: bad args");
+    VLP_ENTER(src, "vlp_kv_gather");
     if (hi == lo) return VLP_OK;
     const int64_t total = (int64_t)R * (hi - lo) * (row_elems / 8);
     int blocks = (int)((total + 255) / 256);
@@ -877,6 +893,7 @@ __global__ __launch_bounds__(256) void sample_rows_kernel(const f16* logits, int
 extern "C" int vlp_sample_rows(const void* logits, int64_t ld, int32_t rows, int32_t V, uint64_t seed, uint32_t rng_stream, int64_t* ids,
                                int64_t ids_stride, float* logp, int64_t logp_stride, void* stream) {
     VLP_CHECK_ARG(logits && ids && logp && rows > 0 && V > 0 && ld >= V, "vlp_sample_rows: bad args");
+    VLP_ENTER(logits, "vlp_sample_rows");
     DropCtx rng = make_drop(0.5f, seed, rng_stream);
     hipLaunchKernelGGL(sample_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const f16*)logits, ld, V, rng, ids, ids_stride, logp, logp_stride);
     VLP_CHECK_LAUNCH("vlp_sample_rows");
@@ -948,6 +965,7 @@ __global__ __launch_bounds__(256) void vis_pe_prep_kernel(vlp_vis_pe_prep_args a
 }
 extern "C" int vlp_vis_pe_prep(const vlp_vis_pe_prep_args* a, void* stream) {
     VLP_CHECK_ARG(a && a->bbox && a->cls && a->out && a->B > 0 && a->Nv > 0, "vlp_vis_pe_prep: null operand / bad shape");
+    VLP_ENTER(a->out, "vlp_vis_pe_prep");
     VLP_CHECK_ARG(a->n_cls > 0 && a->n_cls <= 2048 && a->ld_cls >= a->n_cls && a->pad_to >= 6 + a->n_cls && a->ld_out >= a->pad_to,
                   "vlp_vis_pe_prep: n_cls <= 2048, ld_cls >= n_cls, ld_out >= pad_to >= 6 + n_cls");
     const int64_t rows = (int64_t)a->B * a->Nv;

@@ -337,6 +337,7 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BN
 int vlp_gemm_nt_fill_params(const vlp_gemm_nt_args* a, GemmNtParams& p) {
     VLP_CHECK_ARG(a != nullptr, "vlp_gemm_nt: null args");
     VLP_CHECK_ARG(a->X && a->W && a->Y, "vlp_gemm_nt: null operand");
+    VLP_ENTER(a->X, "vlp_gemm_nt");
     VLP_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "vlp_gemm_nt: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
     VLP_CHECK_ARG(a->K % BK == 0, "vlp_gemm_nt: K=%d must be a multiple of %d (pad with vlp_copy2d)", a->K, BK);
     VLP_CHECK_ARG(a->ldx % 8 == 0 && a->ldw % 8 == 0 && a->ldy % 8 == 0, "vlp_gemm_nt: leading dims must be multiples of 8 halfs");
@@ -381,8 +382,7 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
 #define LAUNCH_NT_(V, BMT, BNT, NBUF, SGV, NSRV)                                                                  \
     do {                                                                                                                \
         const size_t smem = (size_t)(NBUF) * ((BMT) + (BNT)) * BK * sizeof(f16);                                        \
-        static bool attr = false;   /* one process drives one GPU (one rank per device); see DESIGN.md */                \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<V, BMT, BNT, SGV, NSRV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; } \
+        VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm_nt_kernel<V, BMT, BNT, SGV, NSRV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                                                            \
         p.tiles_n = cdiv(a->N, (BNT));                                                                                  \
         hipLaunchKernelGGL((gemm_nt_kernel<V, BMT, BNT, SGV, NSRV>), dim3(cdiv(a->M, (BMT)) * p.tiles_n), dim3(((BMT) / 64) * ((BNT) / 64) * 64), smem, s, p); \
     } while (0)

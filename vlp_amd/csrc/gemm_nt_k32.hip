@@ -137,12 +137,8 @@ int vlp_gemm_nt_k32_launch(GemmNtParams& p, bool sg, hipStream_t s) {
     const size_t smem = (size_t)K32_NS * (K32_BM + K32_BN) * K32_BK * sizeof(f16);      // 128 KiB
     p.tiles_n = cdiv(p.N, K32_BN);
     const dim3 grid(cdiv(p.M, K32_BM) * p.tiles_n), block(K32_T);
-    static bool attr = false;   // one process drives one GPU
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_k32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute((const void*)gemm_nt_k32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr = true;
-    }
+    VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm_nt_k32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm_nt_k32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     if (sg) hipLaunchKernelGGL(gemm_nt_k32_kernel<true>, grid, block, smem, s, p);
     else hipLaunchKernelGGL(gemm_nt_k32_kernel<false>, grid, block, smem, s, p);
     return VLP_OK;

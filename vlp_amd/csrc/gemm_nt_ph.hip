@@ -238,8 +238,7 @@ int vlp_gemm_nt_ph_launch(GemmNtParams& p, int bn, int mode, hipStream_t s) {
 #define LAUNCH_PH(BNT, MD)                                                                                                 \
     do {                                                                                                                 \
         const size_t smem = (size_t)2 * (2 * 128 + (BNT)) * PH_BK * sizeof(f16);                                         \
-        static bool attr = false;                                                                                        \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_ph_kernel<BNT, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; } \
+        VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm_nt_ph_kernel<BNT, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                                                            \
         p.tiles_n = cdiv(p.N, (BNT));                                                                                    \
         hipLaunchKernelGGL((gemm_nt_ph_kernel<BNT, MD>), dim3(cdiv(p.M, 256) * p.tiles_n), dim3(512), smem, s, p);           \
     } while (0)

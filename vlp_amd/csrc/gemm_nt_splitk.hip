@@ -160,8 +160,7 @@ int vlp_gemm_nt_splitk_launch(GemmNtParams& p, int splits, float* workspace, int
     q.kt_per_split = cdiv(nk, splits);
     q.splits = cdiv(nk, q.kt_per_split);                 // no empty slices
     const size_t smem = (size_t)2 * 2 * SK_BM * SK_BK * sizeof(f16);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_splitk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
+    VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm_nt_splitk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(gemm_nt_splitk_kernel, dim3(cdiv(p.M, SK_BM) * q.g.tiles_n * q.splits), dim3(256), smem, s, q);
     VLP_CHECK_LAUNCH("vlp_gemm_nt_splitk");
     const int64_t total = (int64_t)p.M * (q.ldslab / 8);

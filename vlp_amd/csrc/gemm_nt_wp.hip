@@ -447,8 +447,7 @@ int vlp_gemm_nt_wp_launch(GemmNtParams& p, int cfg, bool sg, hipStream_t s) {
     do {                                                                                                                               \
         const size_t smem = ((size_t)(NSXV) * 256 + (size_t)(NSWV) * (BNT)) * 64 * sizeof(f16);                                        \
         auto kfn = gemm_nt_wp_kernel<BNT, WGM, WGN, NSXV, NSWV, RLS, SPR, SGV, PBV, LDV>;                                                   \
-        static bool attr = false;                                                                                                      \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; } \
+        VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                                                            \
         p.tiles_n = cdiv(p.N, (BNT));                                                                                                  \
         hipLaunchKernelGGL(kfn, dim3(cdiv(p.M, 256) * p.tiles_n), dim3((WGM) * (WGN) * 64), smem, s, p);                               \
     } while (0)

@@ -500,6 +500,7 @@ extern "C" int64_t vlp_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K) 
 
 extern "C" int vlp_gemm_tn(const vlp_gemm_tn_args* a, void* stream) {
     VLP_CHECK_ARG(a != nullptr, "vlp_gemm_tn: null args");
+    VLP_ENTER(a->A, "vlp_gemm_tn");
     VLP_CHECK_ARG(a->A && a->B && a->C, "vlp_gemm_tn: null operand");
     VLP_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "vlp_gemm_tn: bad shape");
     VLP_CHECK_ARG(a->K % 8 == 0, "vlp_gemm_tn: K=%d must be a multiple of 8", a->K);
@@ -536,8 +537,7 @@ extern "C" int vlp_gemm_tn(const vlp_gemm_tn_args* a, void* stream) {
 #define LAUNCH_TN_GLDS(BNT, BKT)                                                                                        \
     do {                                                                                                                \
         const size_t smem2 = (size_t)2 * TN_BM * ((BNT) + (BKT)) * sizeof(f16);                                         \
-        static bool attr = false;                                                                                       \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<BNT, BKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2); attr = true; } \
+        VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<BNT, BKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));                                                            \
         p.tiles_k = cdiv(a->K, (BKT)); p.tiles_n = cdiv(a->N, (BNT));                                                   \
         hipLaunchKernelGGL((gemm_tn_glds_kernel<BNT, BKT>), dim3(p.tiles_k * p.tiles_n * splits), dim3(((BNT) / 64) * ((BKT) / 64) * 64), smem2, s, p); \
     } while (0)
@@ -550,12 +550,10 @@ extern "C" int vlp_gemm_tn(const vlp_gemm_tn_args* a, void* stream) {
         dim3 grid(p.tiles_k * p.tiles_n * splits), block(TN_THREADS);
         const size_t smem = 2 * 2 * TN_BM * TN_PITCH * sizeof(f16);   // 68 KiB
         if (base == 1) {
-            static bool attr1 = false;
-            if (!attr1) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr1 = true; }
+            VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm_tn_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, block, smem, s, p);
         } else {
-            static bool attr0 = false;
-            if (!attr0) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr0 = true; }
+            VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm_tn_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             hipLaunchKernelGGL(gemm_tn_kernel<0>, grid, block, smem, s, p);
         }
     }
@@ -586,6 +584,7 @@ static int tn_check_one(const vlp_gemm_tn_args* a) {
 
 extern "C" int vlp_gemm_tn_grouped(const vlp_gemm_tn_args* list, int32_t count, void* stream) {
     VLP_CHECK_ARG(list != nullptr && count >= 1 && count <= TN_GROUP_MAX, "vlp_gemm_tn_grouped: 1..%d problems", TN_GROUP_MAX);
+    VLP_ENTER(list[0].A, "vlp_gemm_tn_grouped");
     // tile shape / ring depth of the grouped launch: 0 = 128x128 tiles, 2 stages (two 4-wave workgroups per CU); 1 = 256x128, 2 stages;
     // 2 = 256x128, 3 stages; 3 = 128x256, 3 stages (8-wave workgroups, one per CU); 4 = 128x128, FOUR stages of 32 contraction rows (same 64 KiB:
     // two workgroups per CU, three stages in flight).  VLP_TN_GROUP_MODE overrides (A/B runs).
@@ -611,8 +610,7 @@ extern "C" int vlp_gemm_tn_grouped(const vlp_gemm_tn_args* list, int32_t count, 
 #define LAUNCH_TN_GROUP(BNT, BKT, NSV, BMV)                                                                                             \
     do {                                                                                                                                \
         const size_t smem = (size_t)(NSV) * (BMV) * ((BNT) + (BKT)) * sizeof(f16);                                                      \
-        static bool attr = false;                                                                                                       \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<BNT, BKT, NSV, BMV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; } \
+        VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<BNT, BKT, NSV, BMV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                                                            \
         hipLaunchKernelGGL((gemm_tn_grouped_kernel<BNT, BKT, NSV, BMV>), dim3(tiles), dim3(((BNT) / 64) * ((BKT) / 64) * 64), smem, (hipStream_t)stream, gp); \
     } while (0)
     if (mode == 0) LAUNCH_TN_GROUP(128, 128, 2, 64);

@@ -80,6 +80,7 @@ static int ln_fwd_blocks(int M) {
 
 extern "C" int vlp_layernorm_fwd(const vlp_layernorm_fwd_args* a, void* stream) {
     VLP_CHECK_ARG(a && a->x && a->gamma && a->beta && a->y, "vlp_layernorm_fwd: null operand");
+    VLP_ENTER(a->x, "vlp_layernorm_fwd");
     VLP_CHECK_ARG(a->M > 0 && a->H > 0 && a->H % 8 == 0 && a->H <= 4096, "vlp_layernorm_fwd: H=%d must be a multiple of 8 and <= 4096", a->H);
     VLP_CHECK_ARG(a->ldx % 8 == 0 && a->ldy % 8 == 0 && a->ldx >= a->H && a->ldy >= a->H, "vlp_layernorm_fwd: leading dims");
     VLP_CHECK_ARG(((uintptr_t)a->x | (uintptr_t)a->y | (uintptr_t)a->gamma | (uintptr_t)a->beta) % 16 == 0, "vlp_layernorm_fwd: alignment");
@@ -257,6 +258,7 @@ extern "C" int64_t vlp_layernorm_bwd_workspace_bytes(int32_t H) {
 
 extern "C" int vlp_layernorm_bwd(const vlp_layernorm_bwd_args* a, void* stream) {
     VLP_CHECK_ARG(a && a->dy && a->x && a->gamma && a->mean && a->rstd && a->dx && a->dgamma && a->dbeta, "vlp_layernorm_bwd: null operand");
+    VLP_ENTER(a->dy, "vlp_layernorm_bwd");
     VLP_CHECK_ARG(a->M > 0 && a->H > 0 && a->H % 8 == 0 && a->H <= 2048, "vlp_layernorm_bwd: H=%d must be a multiple of 8 and <= 2048", a->H);
     VLP_CHECK_ARG(a->lddy % 8 == 0 && a->ldx % 8 == 0 && a->lddx % 8 == 0, "vlp_layernorm_bwd: leading dims");
     VLP_CHECK_ARG(((uintptr_t)a->dy | (uintptr_t)a->x | (uintptr_t)a->dx | (uintptr_t)a->gamma) % 16 == 0, "vlp_layernorm_bwd: alignment");
@@ -316,6 +318,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_batched_kernel(const float
 
 extern "C" int vlp_layernorm_bwd_reduce_batched(const float* parts, const void* const* dst, int32_t count, int32_t M, int32_t H, int32_t beta, void* stream) {
     VLP_CHECK_ARG(parts && dst && count > 0 && count <= 65535 && M > 0 && H > 0 && H % 8 == 0 && H <= 2048, "vlp_layernorm_bwd_reduce_batched: bad args");
+    VLP_ENTER(parts, "vlp_layernorm_bwd_reduce_batched");
     VLP_CHECK_ARG(beta == 0 || beta == 1, "vlp_layernorm_bwd_reduce_batched: beta must be 0 or 1");
     const int blocks = lnb_blocks(M);
     hipLaunchKernelGGL(ln_bwd_reduce_batched_kernel, dim3(cdiv(2 * H, 64), count), dim3(1024), 0, (hipStream_t)stream, parts,
@@ -378,6 +381,7 @@ extern "C" int64_t vlp_colsum_workspace_bytes(int32_t M, int32_t N) {
 }
 extern "C" int vlp_colsum(const vlp_colsum_args* a, void* stream) {
     VLP_CHECK_ARG(a && a->A && a->out && a->M > 0 && a->N > 0, "vlp_colsum: bad args");
+    VLP_ENTER(a->A, "vlp_colsum");
     VLP_CHECK_ARG(a->lda % 8 == 0 && a->lda >= (a->N + 7) / 8 * 8 && (uintptr_t)a->A % 16 == 0, "vlp_colsum: layout (lda must cover roundup8(N))");
     int splits = a->M >= CS_SPLITS * 8 ? CS_SPLITS : (a->M + 7) / 8;
     if (splits < 1) splits = 1;

@@ -98,6 +98,7 @@ __global__ __launch_bounds__(1024) void mlm_finish_kernel(const float* __restric
 
 extern "C" int vlp_mlm_loss_fwd(const vlp_mlm_loss_fwd_args* a, void* stream) {
     VLP_CHECK_ARG(a && a->logits && a->labels && a->weights && a->loss && a->lse && a->coef && a->row_loss, "vlp_mlm_loss_fwd: null operand");
+    VLP_ENTER(a->logits, "vlp_mlm_loss_fwd");
     VLP_CHECK_ARG(a->B > 0 && a->P > 0 && a->V > 0 && a->B <= 4096, "vlp_mlm_loss_fwd: bad shape (B <= 4096)");
     VLP_CHECK_ARG(a->ld_logits % 8 == 0 && a->ld_logits >= a->V && (uintptr_t)a->logits % 16 == 0, "vlp_mlm_loss_fwd: logits layout");
     VLP_CHECK_ARG(a->drop_worst_ratio >= 0.f && a->drop_worst_ratio < 1.f, "vlp_mlm_loss_fwd: drop_worst_ratio");
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(const f16* __restric
 }
 extern "C" int vlp_mlm_loss_bwd(const vlp_mlm_loss_bwd_args* a, void* stream) {
     VLP_CHECK_ARG(a && a->logits && a->labels && a->lse && a->coef && a->grad_scale && a->dlogits, "vlp_mlm_loss_bwd: null operand");
+    VLP_ENTER(a->logits, "vlp_mlm_loss_bwd");
     VLP_CHECK_ARG(a->rows > 0 && a->V > 0 && a->ld_logits % 8 == 0 && a->ld_dlogits % 8 == 0 && a->ld_dlogits >= a->V, "vlp_mlm_loss_bwd: layout");
     VLP_CHECK_ARG(((uintptr_t)a->logits | (uintptr_t)a->dlogits) % 16 == 0, "vlp_mlm_loss_bwd: alignment");
     int bx = cdiv(a->ld_dlogits / 8, CE_THREADS);
@@ -177,6 +179,7 @@ __global__ void bce_finish_kernel(const float* part, int n, float inv, float* lo
 }
 extern "C" int vlp_bce_loss_fwd(const void* logits, int64_t ld, const void* labels, int64_t ldl, int32_t B, int32_t N, float* loss, void* stream) {
     VLP_CHECK_ARG(logits && labels && loss && B > 0 && N > 0 && ld >= N && ldl >= N, "vlp_bce_loss_fwd: bad args");
+    VLP_ENTER(logits, "vlp_bce_loss_fwd");
     // loss[1..257) is used as scratch: the caller passes a buffer of >= 257 floats
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bce_fwd_kernel, dim3(256), dim3(256), 0, s, (const f16*)logits, ld, (const float*)labels, ldl, B, N, loss + 1);
@@ -202,6 +205,7 @@ __global__ void bce_bwd_kernel(const f16* x, int64_t ld, const float* y, int64_t
 extern "C" int vlp_bce_loss_bwd(const void* logits, int64_t ld, const void* labels, int64_t ldl, int32_t B, int32_t N, const float* grad_scale,
                                 void* dlogits, int64_t ldd, void* stream) {
     VLP_CHECK_ARG(logits && labels && grad_scale && dlogits && B > 0 && N > 0 && ld >= N && ldl >= N && ldd >= N, "vlp_bce_loss_bwd: bad args");
+    VLP_ENTER(logits, "vlp_bce_loss_bwd");
     const int64_t total = (int64_t)B * ldd;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;

@@ -56,7 +56,7 @@ class _FlatGroup(object):
         self.p32 = torch.cat([p.data.detach().float().reshape(-1) for p in params])
         self.m = torch.zeros_like(self.p32)
         self.v = torch.zeros_like(self.p32)
-        self.norms = torch.zeros(len(params), device=dev)
+        self.norms = torch.zeros(K.bert_adam_norms_floats(self.n, len(params)), device=dev)    # per-tensor norms + per-chunk partials
         self.g32 = torch.zeros_like(self.p32)
         self.fp16 = params[0].dtype == torch.float16
         self.p16 = torch.empty(self.n, device=dev, dtype=torch.float16) if self.fp16 else None

@@ -257,7 +257,80 @@ class FP16_Optimizer_State(object):
         sd["vlp_rng"] = {"base_seed": self.engine.base_seed, "step_seed": self.engine.step_seed}
         return sd
 
+    # ---- interchange with the reference stack's files (apex FP16_Optimizer layout) ------------------------------------------
+    def _group_layout(self, i):
+        """[(engine offset, numel)] of the parameters of param group i in the CALLER'S order -- apex flattens a group's parameters densely in
+        exactly that order (apex/optimizers/fp16_optimizer.py: _flatten_dense_tensors over param_group['params']), whereas the engine keeps
+        them in backward-completion order on 128-byte boundaries."""
+        eng = self.engine
+        name_of = {id(p): n for n, p in eng._params.items()}
+        offs = eng.offsets[self._group_key[i]]
+        return [(offs[name_of[id(p)]], p.numel()) for p in self.param_groups[i]["params"]]
+
+    def _to_dense(self, flat, i):
+        return torch.cat([flat[o:o + n] for o, n in self._group_layout(i)])
+
+    def _from_dense(self, dense, flat, i):
+        lay = self._group_layout(i)
+        if dense.numel() != sum(n for _, n in lay):
+            raise ValueError("apex state: group %d holds %d elements, this model's group has %d" % (i, dense.numel(), sum(n for _, n in lay)))
+        pos = 0
+        for o, n in lay:
+            flat[o:o + n].copy_(dense[pos:pos + n])
+            pos += n
+
+    def apex_state_dict(self):
+        """The checkpoint the REFERENCE stack writes (optimization_fp16.py:17-38 on apex's FP16_Optimizer + FusedAdam): the inner optimizer
+        is a torch Optimizer whose param groups each hold ONE parameter -- the group's flat fp32 master -- so
+        optimizer_state_dict = {state: {gid: {step, exp_avg, exp_avg_sq}}, param_groups: [{..., params: [gid]}]} with dense flat tensors in
+        the caller's parameter order, and fp32_groups_flat likewise.  An optim.N.bin saved from this dict loads into the reference."""
+        self._sync()
+        sd = {"dynamic_loss_scale": self.dynamic_loss_scale, "cur_scale": self.cur_scale, "cur_iter": self.cur_iter}
+        if self.dynamic_loss_scale:
+            sd.update(last_overflow_iter=self.last_overflow_iter, scale_factor=self.scale_factor, scale_window=self.scale_window)
+        step = self.applied_steps
+        state, groups = {}, []
+        for i, g in enumerate(self.param_groups):
+            state[i] = {"step": step, "exp_avg": self._to_dense(self._m[i], i), "exp_avg_sq": self._to_dense(self._v[i], i)}
+            hp = {k: v for k, v in g.items() if k != "params"}
+            hp["params"] = [i]
+            groups.append(hp)
+        sd["optimizer_state_dict"] = {"state": state, "param_groups": groups}
+        sd["fp32_groups_flat"] = [self._to_dense(self.fp32_groups_flat[i], i) for i in range(len(self.param_groups))]
+        return sd
+
+    def load_apex_state_dict(self, sd):
+        """Resume from an optim.N.bin written by the reference stack (same two param groups in the same parameter order,
+        run_img2txt_dist.py:394-401)."""
+        self._sync()
+        inner = sd["optimizer_state_dict"]
+        if len(inner["param_groups"]) != len(self.param_groups):
+            raise ValueError("apex state: %d param groups, expected %d" % (len(inner["param_groups"]), len(self.param_groups)))
+        self.dynamic_loss_scale = sd["dynamic_loss_scale"]
+        st = self._scale_state.cpu()
+        st[0], st[1] = sd["cur_scale"], sd["cur_iter"]
+        if sd["dynamic_loss_scale"]:
+            st[2], st[3], st[4], st[5] = sd["last_overflow_iter"], sd["scale_factor"], sd["scale_window"], 1.0
+        self._scale_state.copy_(st)
+        step = 0
+        for i, (g, saved) in enumerate(zip(self.param_groups, inner["param_groups"])):
+            g.update({k: v for k, v in saved.items() if k != "params"})
+            pid = saved["params"][0]
+            stt = inner["state"].get(pid) or inner["state"].get(str(pid)) or {}
+            if stt:
+                self._from_dense(stt["exp_avg"].to(self._m[i].device).float().reshape(-1), self._m[i], i)
+                self._from_dense(stt["exp_avg_sq"].to(self._v[i].device).float().reshape(-1), self._v[i], i)
+                step = max(step, int(stt.get("step", 0)))
+            self._from_dense(sd["fp32_groups_flat"][i].detach().to(self._m[i].device).float().reshape(-1), self.fp32_groups_flat[i], i)
+        stl = self._scale_state.tolist()
+        self._applied0, self._iter0, self._skipped0 = step, stl[1], stl[6]
+        for i, key in enumerate(self._group_key):       # refresh the fp16 model copy from the restored masters
+            self.engine.flat[key].copy_(self.fp32_groups_flat[i])
+
     def load_state_dict(self, sd):
+        if "exp_avg" not in sd.get("optimizer_state_dict", {}) and "state" in sd.get("optimizer_state_dict", {}) \
+                and any(isinstance(v, dict) and "exp_avg" in v for v in sd["optimizer_state_dict"]["state"].values()):
+            return self.load_apex_state_dict(sd)            # a file of the reference stack
         self._sync()
         self.dynamic_loss_scale = sd["dynamic_loss_scale"]
         st = self._scale_state.cpu()

@@ -124,6 +124,9 @@ def build_parser():
     p.add_argument("--token_file", default="", help="json list of [image id, [caption token ids]] (captions pre-tokenised with the "
                                                      "reference's WordPiece vocabulary); used with --packed_features")
     p.add_argument("--num_hidden_layers", type=int, default=None, help="override the config's depth (plumbing tests)")
+    p.add_argument("--optim_format", default="vlp", choices=["vlp", "apex"],
+                   help="layout of optim.N.bin: 'vlp' = the engine's flat buffers (+ dropout stream position: bit-exact resume), 'apex' = the "
+                        "reference stack's FP16_Optimizer(FusedAdam) state_dict, loadable by the reference; both are accepted on resume")
     p.add_argument("--stop_after_epoch", type=int, default=0, help="stop after this epoch (schedule still spans --num_train_epochs); 0 = off")
     p.add_argument("--log_every", type=int, default=100, help="steps between loss read-backs (each read-back is a host sync)")
     return p
@@ -348,7 +351,8 @@ def main(argv=None):
             torch.save(copy.deepcopy(to_save).cpu().state_dict(), os.path.join(args.output_dir, "model.{0}.bin".format(i_epoch)))
             # the reference disabled this line ("need to sanitize state and ship everything back to cpu", :599); here the optimizer
             # state is three flat fp32 buffers per group + a few scalars, shipped to the host as they are
-            torch.save(_to_cpu(optimizer.state_dict()), os.path.join(args.output_dir, "optim.{0}.bin".format(i_epoch)))
+            osd = optimizer.apex_state_dict() if (args.optim_format == "apex" and hasattr(optimizer, "apex_state_dict")) else optimizer.state_dict()
+            torch.save(_to_cpu(osd), os.path.join(args.output_dir, "optim.{0}.bin".format(i_epoch)))
         if args.world_size > 1:
             torch.distributed.barrier()
     if distributed:
