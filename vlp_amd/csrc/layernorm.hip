@@ -66,6 +66,62 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(
     }
 }
 
+// Half-wave form for H % 256 == 0 (H = 768, 1024, 2048: every LayerNorm of the model): lanes 0-31 own one row, lanes 32-63 the next, a
+// lane holds NC 16-byte chunks (chunk k = columns 256 k + 8 (lane & 31) .. +7).  16-byte loads, twice the bytes in flight per wave, and
+// M / 2 waves (5 344 at M = 10 688) fit the chip in ONE round -- the one-row-per-wave grid needs 1.3 rounds of 8 192 resident waves.
+template <int NC>
+__global__ __launch_bounds__(LN_THREADS, NC <= 3 ? 6 : 4) void layernorm_fwd_hw_kernel(      // NC = 3: <= 80 VGPRs -> 6 144 resident waves >= the 5 344 of M = 10 688
+    const f16* __restrict__ x, int64_t ldx, const f16* __restrict__ gamma, const f16* __restrict__ beta,
+    f16* __restrict__ y, int64_t ldy, float* __restrict__ mean, float* __restrict__ rstd, int M, int H, float eps, DropCtx drop) {
+    const int lane = threadIdx.x & 63, hl = lane & 31;
+    const int wave = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * LN_WAVES;
+    const float invH = 1.f / (float)H;
+    for (int pair = wave; 2 * pair < M; pair += nwaves) {
+        const int row = 2 * pair + (lane >> 5);
+        const bool live = row < M;
+        const f16* xr = x + (int64_t)(live ? row : M - 1) * ldx;
+        f16x8 t[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) t[k] = ld8(xr + 256 * k + 8 * hl);
+        float v[NC][8];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[k][e] = (float)t[k][e]; s += v[k][e]; }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);          // within the 32-lane half
+        const float mu = s * invH;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[k][e] - mu; q += d * d; }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        const float rs = 1.f / sqrtf(q * invH + eps);
+        if (hl == 0 && live) {
+            if (mean) mean[row] = mu;
+            if (rstd) rstd[row] = rs;
+        }
+        if (!live) continue;
+        f16* yr = y + (int64_t)row * ldy;
+        const uint32_t rkey = drop.thresh ? drop_rowkey(drop, (uint64_t)row) : 0u;   // dropout element = (row, col)
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int c = 256 * k + 8 * hl;
+            const f16x8 gv = ld8(gamma + c), bv = ld8(beta + c);
+            float m8[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+            if (drop.thresh) drop_mult8(drop, rkey, (uint32_t)c, m8);
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (f16)(((float)gv[e] * ((v[k][e] - mu) * rs) + (float)bv[e]) * m8[e]);
+            st8(yr + c, o);
+        }
+    }
+}
+
 // one row per wave up to this many blocks (VLP_LN_BLOCKS overrides for A/B runs)
 static int ln_fwd_blocks(int M) {
     static int cap = 0;
@@ -90,6 +146,24 @@ extern "C" int vlp_layernorm_fwd(const vlp_layernorm_fwd_args* a, void* stream) 
 #define LAUNCH_LN_FWD(NP_)                                                                                                              \
     hipLaunchKernelGGL(layernorm_fwd_kernel<NP_>, dim3(blocks), dim3(LN_THREADS), 0, s, (const f16*)a->x, a->ldx, (const f16*)a->gamma, \
                        (const f16*)a->beta, (f16*)a->y, a->ldy, a->mean, a->rstd, a->M, a->H, a->eps, d)
+    static int use_hw = -1;      // VLP_LN_HALFWAVE=0: the one-row-per-wave kernel everywhere (A/B runs)
+    if (use_hw < 0) { const char* e = getenv("VLP_LN_HALFWAVE"); use_hw = e ? atoi(e) : 1; }
+    if (use_hw && a->H % 256 == 0 && a->H <= 2048) {
+        const int hblocks = ln_fwd_blocks((a->M + 1) / 2);
+#define LAUNCH_LN_HW(NC_)                                                                                                                  \
+    hipLaunchKernelGGL(layernorm_fwd_hw_kernel<NC_>, dim3(hblocks), dim3(LN_THREADS), 0, s, (const f16*)a->x, a->ldx, (const f16*)a->gamma, \
+                       (const f16*)a->beta, (f16*)a->y, a->ldy, a->mean, a->rstd, a->M, a->H, a->eps, d)
+        if (a->H == 768) LAUNCH_LN_HW(3);
+        else if (a->H == 256) LAUNCH_LN_HW(1);
+        else if (a->H == 512) LAUNCH_LN_HW(2);
+        else if (a->H == 1024) LAUNCH_LN_HW(4);
+        else if (a->H == 1536) LAUNCH_LN_HW(6);
+        else if (a->H == 2048) LAUNCH_LN_HW(8);
+        else use_hw = 2;
+#undef LAUNCH_LN_HW
+        if (use_hw != 2) { VLP_CHECK_LAUNCH("vlp_layernorm_fwd"); return VLP_OK; }
+        use_hw = 1;
+    }
     if (a->H <= 768) LAUNCH_LN_FWD(3);
     else if (a->H <= 1024) LAUNCH_LN_FWD(4);
     else if (a->H <= 2048) LAUNCH_LN_FWD(8);
