@@ -82,7 +82,7 @@ def test_gemm_nt_plain(variant, M, N, K, gen):
         assert float(y[:, N:].abs().max()) == 0.0        # padding columns are written as zero
 
 
-@pytest.mark.parametrize("variant", [6, 7, 14, 15, 22, 23, 54, 17, 19, 27, 21, 29, 53, 61, 64, 65, 66, 67, 68, 69, 70, 71, 72, 77, 78, 192, 193, 201])
+@pytest.mark.parametrize("variant", [6, 7, 14, 15, 22, 23, 54, 17, 19, 27, 21, 29, 53, 61, 64, 65, 66, 67, 68, 69, 70, 71, 72, 77, 78, 192, 193, 194, 201, 202])
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 768, 768), (77, 1000, 192), (256, 2304, 768), (515, 520, 1664),
                                    (10688, 768, 3072), (10688, 2304, 768)])
 def test_gemm_nt_phased(variant, M, N, K, gen):
@@ -140,7 +140,7 @@ def test_gemm_nt_splitk(M, N, K, splits, gen):
         K.gemm_nt_splitk(x, w, y, M, N, Kd, splits, ws[:16])                # workspace too small is refused
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 64, 65, 66, 67, 68, 69, 70, 71, 192, 193])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 64, 65, 66, 67, 68, 69, 70, 71, 192, 193, 194])
 def test_gemm_nt_asymmetric_identity(variant):
     """A = I against an asymmetric B catches swapped row/col in the MFMA C-layout handling."""
     M = N = Kd = 128
@@ -151,7 +151,7 @@ def test_gemm_nt_asymmetric_identity(variant):
     assert torch.equal(y, w.t().contiguous())
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, 6, 7, 19, 27, 29, 61, 64, 65, 66, 67, 68, 69, 70, 71, 192, 193])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, 6, 7, 19, 27, 29, 61, 64, 65, 66, 67, 68, 69, 70, 71, 192, 193, 194])
 def test_gemm_nt_epilogues(variant, gen):
     M, N, Kd = 200, 384, 256
     x, w = h16(M, Kd, gen=gen), h16(N, Kd, scale=0.06, gen=gen)

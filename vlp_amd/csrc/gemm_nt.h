@@ -16,6 +16,7 @@ struct GemmNtParams {
     float alpha;
     DropCtx drop;
     int tiles_n;
+    int tiles_total; // wave-pipelined kernels: tiles of the launch (persistent variants stride them over the grid)
     int xcd_remap;   // 1: workgroups of one XCD (blockIdx % 8) take a contiguous range of tiles (X-panel reuse in that XCD's L2)
 #ifdef VLP_NT_DEBUG
     int dbg;         // investigation build (tools/build_variant_lib.sh): 1 = ring loop without MFMAs, 2 = without refill DMA, 4 = without the epilogue

@@ -52,6 +52,58 @@ DEVFN void glds16_s(const char* sbase, uint32_t voff, uint32_t lds_dst) {
 DEVFN int wp_swz(int r) { return (((r >> 4) & 1) << 2) | (((r >> 3) & 1) << 1) | ((r >> 1) & 1); }   // X tile row -> chunk XOR (lane bits 4,3,1)
 DEVFN int wp_swz_w(int R) { return (R >> 1) & 7; }                                                    // the same lane bits seen from the permuted W row
 
+// light epilogue of 8 consecutive columns of row m, same order of operations as nt_epilogue8: pre-activation store, ReLU, multiplier,
+// dropout, residual; vv = alpha * acc + bias on entry
+DEVFN void wp_light_store8(const GemmNtParams& p, int m, int nc, bool ragged, float (&vv)[8], const f16x8& mulv, const f16x8& resv) {
+    if (p.preact) {
+        f16x8 z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = (nc + j < p.N) ? (f16)vv[j] : (f16)0.f;
+        st8(p.preact + (int64_t)m * p.ldp + nc, z);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vv[j] = (float)z[j];
+    }
+    if (p.act == VLP_ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vv[j] = fmaxf(vv[j], 0.f);
+    }
+    if (p.mulmode == VLP_MUL_PLAIN) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vv[j] *= (float)mulv[j];
+    } else if (p.mulmode != VLP_MUL_NONE) {           // VLP_MUL_RELU_MASK (GELU_GRAD is refused by the launcher)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vv[j] = ((float)mulv[j] > 0.f) ? vv[j] : 0.f;
+    }
+    if (p.drop.thresh) drop_mult8(p.drop, drop_rowkey(p.drop, (uint64_t)m), (uint32_t)nc, vv);
+    if (p.residual) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vv[j] += (float)resv[j];
+    }
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (!ragged || nc + j < p.N) ? (f16)vv[j] : (f16)0.f;
+    st8(p.Y + (int64_t)m * p.ldy + nc, o);
+}
+
+// save-grad GeLU epilogue of 8 columns: z = fp16-rounded pre-activation; y = gelu(z); preact <- gelu'(z)  (as nt_epilogue8<true>)
+DEVFN void wp_sg_store8(const GemmNtParams& p, int m, int nc, bool ragged, const float (&vv)[8]) {
+    f16x8 d, o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float gl, gp;
+        gelu_and_grad_f((float)(f16)vv[j], gl, gp);
+        o[j] = (f16)gl;
+        d[j] = (f16)gp;
+    }
+    if (ragged) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (nc + j >= p.N) { o[j] = (f16)0.f; d[j] = (f16)0.f; }
+    }
+    st8(p.preact + (int64_t)m * p.ldp + nc, d);
+    st8(p.Y + (int64_t)m * p.ldy + nc, o);
+}
+
 // what a step may issue: a group of X stage kx into X slot sx (if dox), a group of W stage kw into W slot sw (if dow)
 struct WpDma { int kx, sx, kw, sw; bool dox, dow; };
 
@@ -86,13 +138,17 @@ __global__ __launch_bounds__(WGM * WGN * 64, WGM * WGN / 4) void gemm_nt_wp_kern
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    int bid = blockIdx.x;
-    if (p.xcd_remap) {      // bijective for any grid size: XCD x owns (q+1) tiles if x < r else q
-        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN_T;
+    // tile t of the launch -> origin (XCD-aware order: bijective for any tile count, XCD x owns (q+1) tiles if x < r else q)
+    auto tile_origin = [&](int t, int& mo, int& no) {
+        if (p.xcd_remap) {
+            const int nb = p.tiles_total, q = nb >> 3, r = nb & 7, xcd = t & 7, loc = t >> 3;
+            t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        }
+        mo = (t / p.tiles_n) * BM;
+        no = (t % p.tiles_n) * BN_T;
+    };
+    int m0, n0;
+    tile_origin(blockIdx.x, m0, n0);
     const int nk = p.K / BK_T;
     const uint32_t lds0 = lds_addr_of(smem);
     const char* const xg = reinterpret_cast<const char*>(p.X);
@@ -102,19 +158,20 @@ __global__ __launch_bounds__(WGM * WGN * 64, WGM * WGN / 4) void gemm_nt_wp_kern
     const bool xrole = ROLES ? (wid < NW / 2) : true;
     const int lw = ROLES ? (xrole ? wid : wid - NW / 2) : wid;
     uint32_t voffx[LPX], voffw[LPW];
-    {
+    auto set_dma_tile = [&](int mo, int no) {
         const int rb = lane >> 3, pc = lane & 7;
         static_for<0, LPX>([&](auto J) {
             constexpr int j = decltype(J)::value;
             const int r = (lw + NIS * j) * 8 + rb;
-            voffx[j] = (uint32_t)min(m0 + r, p.M - 1) * (uint32_t)p.ldx * 2u + (uint32_t)((pc ^ wp_swz(r)) << 4);
+            voffx[j] = (uint32_t)min(mo + r, p.M - 1) * (uint32_t)p.ldx * 2u + (uint32_t)((pc ^ wp_swz(r)) << 4);
         });
         static_for<0, LPW>([&](auto J) {
             constexpr int j = decltype(J)::value;
             const int R = (lw + NIS * j) * 8 + rb;
-            voffw[j] = (uint32_t)min(n0 + R, p.N - 1) * (uint32_t)p.ldw * 2u + (uint32_t)((pc ^ wp_swz_w(R)) << 4);
+            voffw[j] = (uint32_t)min(no + R, p.N - 1) * (uint32_t)p.ldw * 2u + (uint32_t)((pc ^ wp_swz_w(R)) << 4);
         });
-    }
+    };
+    set_dma_tile(m0, n0);
     // X pieces [J0, J1) of stage kt into X ring slot `slot`; W likewise
     auto issue_x = [&](auto J0_, auto J1_, int kt, int slot) {
         if constexpr (WP_DBG & 2) return;
@@ -156,6 +213,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, WGM * WGN / 4) void gemm_nt_wp_kern
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    constexpr int CW = 32 * TN;                   // columns of the wave tile
     f16x8 xf[NB][TM], wf[NB][TN];
     if constexpr (WP_DBG & 24) {
 #pragma unroll
@@ -321,13 +379,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, WGM * WGN / 4) void gemm_nt_wp_kern
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();             // every wave is done with the stage buffers
     if constexpr (WP_DBG & 4) { if (acc[0][0][0] != 12345.678f) return; }
-    constexpr int CW = 32 * TN;               // columns of the wave tile
     constexpr int RS = CW * 4 + 16;           // padded row stride of the transpose buffer (bytes): conflict-free ds_write_b128 of 8 rows
-    constexpr int LPR = CW / 8, RPP = 64 / LPR, NPASS = 32 / RPP;
+    constexpr int LPR = CW / 8, RPP = 64 / LPR, NPASS = (32 + RPP - 1) / RPP;
+    constexpr bool EVEN = (64 % LPR == 0) && (32 % RPP == 0);     // CW = 96: 12 lanes per row, 5 rows per pass, 4 idle lanes
     char* const ebuf = smem + wid * (32 * RS);
     const int er = lane / LPR, ec = (lane % LPR) * 8;
     const int nc = n0 + wn * WROWS_N + ec;    // this lane's 8 columns (the same for every row it handles)
-    const bool ncol_ok = nc < p.N;
+    const bool ncol_ok = nc < p.N && (EVEN || er < RPP);
     float bias_v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bias_v[j] = 0.f;
@@ -362,73 +420,32 @@ __global__ __launch_bounds__(WGM * WGN * 64, WGM * WGN / 4) void gemm_nt_wp_kern
 #pragma unroll
                 for (int ps = 0; ps < NPASS; ++ps) {
                     const int m = mb + ps * RPP;
-                    if (m < p.M && ncol_ok) mulv[ps] = ld8(p.mulsrc + (int64_t)m * p.ldm + nc);
+                    if (m < p.M && ncol_ok && (EVEN || er + ps * RPP < 32)) mulv[ps] = ld8(p.mulsrc + (int64_t)m * p.ldm + nc);
                 }
             }
             if (p.residual) {
 #pragma unroll
                 for (int ps = 0; ps < NPASS; ++ps) {
                     const int m = mb + ps * RPP;
-                    if (m < p.M && ncol_ok) resv[ps] = ld8(p.residual + (int64_t)m * p.ldr + nc);
+                    if (m < p.M && ncol_ok && (EVEN || er + ps * RPP < 32)) resv[ps] = ld8(p.residual + (int64_t)m * p.ldr + nc);
                 }
             }
         }
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int m = mb + ps * RPP;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ebuf + (er + ps * RPP) * RS + ec * 4);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(ebuf + (er + ps * RPP) * RS + ec * 4 + 16);
+            const int erow = EVEN ? er + ps * RPP : min(er + ps * RPP, 31);
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ebuf + erow * RS + ec * 4);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(ebuf + erow * RS + ec * 4 + 16);
             if (m >= p.M || !ncol_ok) continue;
+            if (!EVEN && er + ps * RPP >= 32) continue;
             float vv[8];
 #pragma unroll
             for (int j = 0; j < 4; ++j) { vv[j] = a0[j] * p.alpha + bias_v[j]; vv[4 + j] = a1[j] * p.alpha + bias_v[4 + j]; }
             if constexpr (SG) {
-                // z = fp16-rounded pre-activation; y = gelu(z); preact <- gelu'(z)   (same arithmetic as nt_epilogue8<true>)
-                f16x8 d, o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float gl, gp;
-                    gelu_and_grad_f((float)(f16)vv[j], gl, gp);
-                    o[j] = (f16)gl;
-                    d[j] = (f16)gp;
-                }
-                if (ragged) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (nc + j >= p.N) { o[j] = (f16)0.f; d[j] = (f16)0.f; }
-                }
-                st8(p.preact + (int64_t)m * p.ldp + nc, d);
-                st8(p.Y + (int64_t)m * p.ldy + nc, o);
+                wp_sg_store8(p, m, nc, ragged, vv);
             } else {
-                // light epilogue, same order of operations as nt_epilogue8: pre-activation store, ReLU, multiplier, dropout, residual
-                if (p.preact) {
-                    f16x8 z;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) z[j] = (nc + j < p.N) ? (f16)vv[j] : (f16)0.f;
-                    st8(p.preact + (int64_t)m * p.ldp + nc, z);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) vv[j] = (float)z[j];
-                }
-                if (p.act == VLP_ACT_RELU) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) vv[j] = fmaxf(vv[j], 0.f);
-                }
-                if (p.mulmode == VLP_MUL_PLAIN) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) vv[j] *= (float)mulv[ps][j];
-                } else if (p.mulmode != VLP_MUL_NONE) {           // VLP_MUL_RELU_MASK (GELU_GRAD is refused by the launcher)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) vv[j] = ((float)mulv[ps][j] > 0.f) ? vv[j] : 0.f;
-                }
-                if (p.drop.thresh) drop_mult8(p.drop, drop_rowkey(p.drop, (uint64_t)m), (uint32_t)nc, vv);
-                if (p.residual) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) vv[j] += (float)resv[ps][j];
-                }
-                f16x8 o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (!ragged || nc + j < p.N) ? (f16)vv[j] : (f16)0.f;
-                st8(p.Y + (int64_t)m * p.ldy + nc, o);
+                wp_light_store8(p, m, nc, ragged, vv, mulv[ps], resv[ps]);
             }
         }
     }
@@ -440,6 +457,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, WGM * WGN / 4) void gemm_nt_wp_kern
 //   4: 256x128, 4 waves (128x64), rings 3/3, spread         5: 256x128, 8 waves (64x64), rings 3/3, spread
 //   6: as 4, 2 steps ahead                                  7: as 5, 2 steps ahead
 //   8: 256x128, 8 waves, roles, rings 3/3 (control)         9: 256x128, 8 waves, roles, rings 4/2 (160 KiB)
+//  10: 256x192, 8 waves (64x96), rings 2/2
 int vlp_gemm_nt_wp_launch(GemmNtParams& p, int cfg, bool sg, hipStream_t s) {
     VLP_CHECK_ARG(sg || nt_epilogue_is_light(p), "vlp_gemm_nt: the wave-pipelined variants carry bias / ReLU / multiplier / dropout / residual / save-grad GeLU epilogues only");
     VLP_CHECK_ARG((int64_t)p.M * p.ldx < (1ll << 31) && (int64_t)p.N * p.ldw < (1ll << 31), "vlp_gemm_nt: wave-pipelined variants need M*ldx, N*ldw < 2^31");
@@ -449,7 +467,8 @@ int vlp_gemm_nt_wp_launch(GemmNtParams& p, int cfg, bool sg, hipStream_t s) {
         auto kfn = gemm_nt_wp_kernel<BNT, WGM, WGN, NSXV, NSWV, RLS, SPR, SGV, PBV, LDV>;                                                   \
         VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                                                            \
         p.tiles_n = cdiv(p.N, (BNT));                                                                                                  \
-        hipLaunchKernelGGL(kfn, dim3(cdiv(p.M, 256) * p.tiles_n), dim3((WGM) * (WGN) * 64), smem, s, p);                               \
+        p.tiles_total = cdiv(p.M, 256) * p.tiles_n;                                                                                    \
+        hipLaunchKernelGGL(kfn, dim3(p.tiles_total), dim3((WGM) * (WGN) * 64), smem, s, p);                                            \
     } while (0)
 #define LAUNCH_WP(BNT, WGM, WGN, NSXV, NSWV, RLS, SPR, PBV, LDV) \
     do { if (sg) LAUNCH_WP_(BNT, WGM, WGN, NSXV, NSWV, RLS, SPR, true, PBV, LDV); else LAUNCH_WP_(BNT, WGM, WGN, NSXV, NSWV, RLS, SPR, false, PBV, LDV); } while (0)
@@ -463,6 +482,7 @@ int vlp_gemm_nt_wp_launch(GemmNtParams& p, int cfg, bool sg, hipStream_t s) {
         case 6: LAUNCH_WP(128, 2, 2, 3, 3, false, true, 2, 2); break;
         case 7: LAUNCH_WP(128, 4, 2, 3, 3, false, true, 0, 2); break;
         case 8: LAUNCH_WP(128, 4, 2, 3, 3, true, true, 0, 1); break;
+        case 10: LAUNCH_WP(192, 4, 2, 2, 2, false, false, 2, 1); break;
         default: LAUNCH_WP(128, 4, 2, 4, 2, true, true, 0, 1); break;
     }
 #undef LAUNCH_WP
