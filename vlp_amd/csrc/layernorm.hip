@@ -179,6 +179,8 @@ extern "C" int vlp_layernorm_fwd(const vlp_layernorm_fwd_args* a, void* stream) 
 // A lane owns NP pieces of 4 columns (piece k = columns 256k + 4*lane .. +3, 8-byte loads): at H = 768 every lane is busy with 12
 // columns and the kernel needs ~100 VGPRs, so two 8-wave blocks fit a CU.  (The earlier 8-column chunks left half the lanes idle
 // in the second chunk at H = 768 and took 142 VGPRs -- one block per CU, 2 waves per SIMD, one row of prefetch each: 3.4 TB/s.)
+// Round 3 tried the half-wave form of the forward here (two rows per wave, 16-byte loads, 48 column sums per lane, values recomputed in
+// the second pass): 168 VGPRs + spills, 3 waves per SIMD, no next-row prefetch -- 20.9 us against 14.5 us for this kernel (tools/ln_lab.py).
 // ---------------------------------------------------------------------------------------------
 #define LNB_BLOCKS 512
 #define LNB_THREADS 512
@@ -345,13 +347,11 @@ extern "C" int vlp_layernorm_bwd(const vlp_layernorm_bwd_args* a, void* stream) 
     hipStream_t s = (hipStream_t)stream;
     float* part = (float*)a->workspace;
     const size_t lnb_smem = (size_t)LNB_WAVES * 2 * a->H * sizeof(float);   // <= 128 KiB at H = 2048
-    static bool lnb_attr = false;
-    if (!lnb_attr) {
-        hipFuncSetAttribute((const void*)layernorm_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * 768 * 4);
-        hipFuncSetAttribute((const void*)layernorm_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * 1024 * 4);
-        hipFuncSetAttribute((const void*)layernorm_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * 2048 * 4);
-        lnb_attr = true;
-    }
+    VLP_ONCE_PER_DEVICE({
+        (void)hipFuncSetAttribute((const void*)layernorm_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * 768 * 4);
+        (void)hipFuncSetAttribute((const void*)layernorm_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * 1024 * 4);
+        (void)hipFuncSetAttribute((const void*)layernorm_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * 2048 * 4);
+    });
     if (a->H <= 768)
         hipLaunchKernelGGL(layernorm_bwd_kernel<3>, dim3(blocks), dim3(LNB_THREADS), lnb_smem, s, (const f16*)a->dy, a->lddy, (const f16*)a->x, a->ldx,
                            (const f16*)a->gamma, a->mean, a->rstd, (f16*)a->dx, a->lddx, (f16*)a->dx_drop, a->lddxd, part, a->M, a->H, dyd, outd);
