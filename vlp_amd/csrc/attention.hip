@@ -332,7 +332,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 f16x4 ov = (f16x4){(f16)(o[n][0] * inv), (f16)(o[n][1] * inv), (f16)(o[n][2] * inv), (f16)(o[n][3] * inv)};
-                st4(p.ctx + ((int64_t)b * Lq + q) * p.ld_ctx + h * HD + n * 16 + 4 * g, ov);
+                st4_out<VLP_SS_ATTN>(p.ctx + ((int64_t)b * Lq + q) * p.ld_ctx + h * HD + n * 16 + 4 * g, ov);
             }
         }
         if (qt == wid) TRACE(6);       // first tile stored
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(ATT_THREADS, NT <= 12 ? 2 : 1) void attn_bwd_dq_ker
             }
             if (q < L) {
                 f16x4 ov = (f16x4){(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
-                st4(p.dqkv + ((int64_t)b * L + q) * p.ld_dqkv + h * HD + n * 16 + 4 * g, ov);
+                st4_out<VLP_SS_ATTN>(p.dqkv + ((int64_t)b * L + q) * p.ld_dqkv + h * HD + n * 16 + 4 * g, ov);
             }
         }
     }
@@ -583,8 +583,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT >= 8 ? 4 : 2)) void attn
             for (int n = 0; n < 4; ++n) {
                 f16x4 kv = (f16x4){(f16)dk[n][0], (f16)dk[n][1], (f16)dk[n][2], (f16)dk[n][3]};
                 f16x4 vv = (f16x4){(f16)dv[n][0], (f16)dv[n][1], (f16)dv[n][2], (f16)dv[n][3]};
-                st4(drow + p.H + n * 16 + 4 * g, kv);
-                st4(drow + 2 * p.H + n * 16 + 4 * g, vv);
+                st4_out<VLP_SS_ATTN>(drow + p.H + n * 16 + 4 * g, kv);
+                st4_out<VLP_SS_ATTN>(drow + 2 * p.H + n * 16 + 4 * g, vv);
             }
         }
     }

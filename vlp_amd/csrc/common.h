@@ -203,3 +203,27 @@ DEVFN f16x8 ld8(const f16* p) { return *reinterpret_cast<const f16x8*>(p); }
 DEVFN void st8(f16* p, f16x8 v) { *reinterpret_cast<f16x8*>(p) = v; }
 DEVFN f16x4 ld4(const f16* p) { return *reinterpret_cast<const f16x4*>(p); }
 DEVFN void st4(f16* p, f16x4 v) { *reinterpret_cast<f16x4*>(p) = v; }
+// Streamed (non-temporal) output stores, per kernel family -- OFF in the product (VLP_STREAM_STORES = 0).  Measured in round 3
+// (profiles/r03_nt_wp_decomposition.txt): on a lone NT GEMM with cold operands they gain 3 - 12 % (the written lines no longer evict
+// operand lines from the 4 MB L2 of an XCD), but inside the step the NEXT kernel reads the tensor from the Infinity Cache when it was
+// stored normally and from HBM when it was streamed: 10.14 -> 10.99 ms / step with the NT GEMM outputs streamed, 9.64 -> 9.73 ms with only
+// the FFN side outputs the backward pass reads much later.  Kept as an investigation switch (tools/build_variant_lib.sh -DVLP_STREAM_STORES=mask).
+#define VLP_SS_NT 1        // NT GEMM outputs
+#define VLP_SS_TN 2        // weight gradients
+#define VLP_SS_ATTN 4      // attention context / dQ dK dV
+#define VLP_SS_LN 8        // LayerNorm outputs
+#define VLP_SS_EW 16       // element-wise kernels
+#define VLP_SS_SAVED 32    // NT GEMM side outputs that only the backward pass reads (pre-activation / gelu' of the FFN)
+#ifndef VLP_STREAM_STORES
+#define VLP_STREAM_STORES 0
+#endif
+template <int FAM>
+DEVFN void st8_out(f16* p, f16x8 v) {
+    if constexpr ((VLP_STREAM_STORES & FAM) != 0) __builtin_nontemporal_store(v, reinterpret_cast<f16x8*>(p));
+    else st8(p, v);
+}
+template <int FAM>
+DEVFN void st4_out(f16* p, f16x4 v) {
+    if constexpr ((VLP_STREAM_STORES & FAM) != 0) __builtin_nontemporal_store(v, reinterpret_cast<f16x4*>(p));
+    else st4(p, v);
+}

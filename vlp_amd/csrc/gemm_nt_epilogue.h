@@ -13,7 +13,7 @@ DEVFN void st8_pol(const GemmNtParams& p, f16* dst, f16x8 v) {      // store cac
 }
 #define ST8_OUT(p, dst, v) st8_pol(p, dst, v)
 #else
-#define ST8_OUT(p, dst, v) st8(dst, v)
+#define ST8_OUT(p, dst, v) st8_out<VLP_SS_NT>(dst, v)
 #endif
 // LIGHT (compile time): the caller guarantees act is NONE / RELU and mul_mode is not GELU_GRAD (nt_epilogue_is_light): the erf / exp /
 // tanh expansions are compiled out -- the wave-pipelined kernels inline this function 16-32 times per lane.
@@ -48,7 +48,7 @@ DEVFN void nt_epilogue8(const GemmNtParams& p, int m, int nc, float* vv, uint32_
             for (int j = 0; j < 8; ++j)
                 if (nc + j >= p.N) { o[j] = (f16)0.f; d[j] = (f16)0.f; }
         }
-        ST8_OUT(p, p.preact + (int64_t)m * p.ldp + nc, d);
+        st8_out<VLP_SS_SAVED>(p.preact + (int64_t)m * p.ldp + nc, d);
         ST8_OUT(p, p.Y + (int64_t)m * p.ldy + nc, o);
         return;
     } else {
@@ -56,7 +56,7 @@ DEVFN void nt_epilogue8(const GemmNtParams& p, int m, int nc, float* vv, uint32_
             f16x8 z;
 #pragma unroll
             for (int j = 0; j < 8; ++j) z[j] = (nc + j < p.N) ? (f16)vv[j] : (f16)0.f;
-            st8(p.preact + (int64_t)m * p.ldp + nc, z);
+            st8_out<VLP_SS_SAVED>(p.preact + (int64_t)m * p.ldp + nc, z);
 #pragma unroll
             for (int j = 0; j < 8; ++j) vv[j] = (float)z[j];      // the activation sees the fp16-rounded pre-activation (as backward will)
         }

@@ -59,7 +59,7 @@ DEVFN void wp_light_store8(const GemmNtParams& p, int m, int nc, bool ragged, fl
         f16x8 z;
 #pragma unroll
         for (int j = 0; j < 8; ++j) z[j] = (nc + j < p.N) ? (f16)vv[j] : (f16)0.f;
-        st8(p.preact + (int64_t)m * p.ldp + nc, z);
+        st8_out<VLP_SS_SAVED>(p.preact + (int64_t)m * p.ldp + nc, z);
 #pragma unroll
         for (int j = 0; j < 8; ++j) vv[j] = (float)z[j];
     }
@@ -82,7 +82,7 @@ DEVFN void wp_light_store8(const GemmNtParams& p, int m, int nc, bool ragged, fl
     f16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (!ragged || nc + j < p.N) ? (f16)vv[j] : (f16)0.f;
-    st8(p.Y + (int64_t)m * p.ldy + nc, o);
+    st8_out<VLP_SS_NT>(p.Y + (int64_t)m * p.ldy + nc, o);
 }
 
 // save-grad GeLU epilogue of 8 columns: z = fp16-rounded pre-activation; y = gelu(z); preact <- gelu'(z)  (as nt_epilogue8<true>)
@@ -100,8 +100,8 @@ DEVFN void wp_sg_store8(const GemmNtParams& p, int m, int nc, bool ragged, const
         for (int j = 0; j < 8; ++j)
             if (nc + j >= p.N) { o[j] = (f16)0.f; d[j] = (f16)0.f; }
     }
-    st8(p.preact + (int64_t)m * p.ldp + nc, d);
-    st8(p.Y + (int64_t)m * p.ldy + nc, o);
+    st8_out<VLP_SS_SAVED>(p.preact + (int64_t)m * p.ldp + nc, d);
+    st8_out<VLP_SS_NT>(p.Y + (int64_t)m * p.ldy + nc, o);
 }
 
 // what a step may issue: a group of X stage kx into X slot sx (if dox), a group of W stage kw into W slot sw (if dow)

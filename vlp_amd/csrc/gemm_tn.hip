@@ -196,7 +196,7 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(GemmTnParams p) 
                     float v = acc[tn][2 * h + (j >> 2)][j & 3];
                     o[j] = (f16)(p.beta ? (float)o[j] + v : v);
                 }
-                st8(dst + 8 * h, o);
+                st8_out<VLP_SS_TN>(dst + 8 * h, o);
             }
         }
     }
@@ -389,7 +389,7 @@ DEVFN void tn_glds_tile(const GemmTnParams& p, int bid, f16* smem) {
                 if (p.beta) o = ld4(dst);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (f16)(p.beta ? (float)o[j] + acc[tn][tk][j] : acc[tn][tk][j]);
-                st4(dst, o);
+                st4_out<VLP_SS_TN>(dst, o);
             }
         }
     }
@@ -478,7 +478,7 @@ __global__ void gemm_tn_reduce_kernel(const float* slab, f16* C, int64_t ldc, in
         if (beta) o = ld8(dst);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (f16)(beta ? (float)o[j] + v[j] : v[j]);
-        st8(dst, o);
+        st8_out<VLP_SS_TN>(dst, o);
     }
 }
 

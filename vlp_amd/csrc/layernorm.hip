@@ -60,7 +60,7 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(
                 if (drop.thresh) drop_mult4(drop, rkey, (uint32_t)c, m4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (f16)(((float)gv[e] * ((v[k][e] - mu) * rs) + (float)bv[e]) * m4[e]);
-                st4(yr + c, o);
+                st4_out<VLP_SS_LN>(yr + c, o);
             }
         }
     }
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(LN_THREADS, NC <= 3 ? 6 : 4) void layernorm_fwd_hw_
             f16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (f16)(((float)gv[e] * ((v[k][e] - mu) * rs) + (float)bv[e]) * m8[e]);
-            st8(yr + c, o);
+            st8_out<VLP_SS_LN>(yr + c, o);
         }
     }
 }
@@ -265,8 +265,8 @@ __global__ __launch_bounds__(LNB_THREADS, NP <= 3 ? 4 : (NP == 4 ? 3 : 2)) void 
                     o[e] = (f16)t;
                     od[e] = (f16)(t * m4[e]);
                 }
-                st4(dx + (int64_t)row * lddx + c, o);
-                if (dxd) st4(dxd + (int64_t)row * lddxd + c, od);
+                st4_out<VLP_SS_LN>(dx + (int64_t)row * lddx + c, o);
+                if (dxd) st4_out<VLP_SS_LN>(dxd + (int64_t)row * lddxd + c, od);
             }
         }
 #pragma unroll
