@@ -73,6 +73,59 @@ def test_fp16_optimizer_step_matches_apex_restatement():
     assert opt.cur_iter == 2
 
 
+def test_ten_step_trajectory_against_the_independent_fp32_oracle():
+    """The HIP path (fp16 storage, FP16_Optimizer + FusedAdam, dynamic loss scale) and the oracle (fp32 forward / autograd backward /
+    fused_adam_step on ITS OWN gradients) start from the same weights and see the same ten batches: the loss of every step and the
+    final weights must agree to fp16 working precision.  Unlike the one-step optimizer tests nothing of the HIP path feeds the oracle."""
+    LR, STEPS = 2e-4, 10
+    model, p0 = small_model(drop=0.0)
+    model.train()
+    # a start scale the first steps do not overflow at: a skipped step is the scaler's business (tested above), not this comparison's
+    opt = FP16_Optimizer_State(FusedAdam(groups_of(model), lr=LR, bias_correction=False, max_grad_norm=1.0), dynamic_loss_scale=True,
+                               dynamic_loss_args={"init_scale": 2.0 ** 10})
+    ref = {k: v.clone().to(DEV).requires_grad_(True) for k, v in p0.items()}
+    rm = {k: torch.zeros_like(v) for k, v in ref.items()}
+    rv = {k: torch.zeros_like(v) for k, v in ref.items()}
+    is_nd = {k: any(x in k for x in ND) for k in ref}
+    hip_losses, ref_losses = [], []
+    for it in range(STEPS):
+        raw = S.make_batch(4, max_len_b=20, vocab_size=1024, max_pred=3, seed=100 + it)
+        lt = train_step(model, opt, S.batch_to(raw, DEV, half=True), LR)
+        hip_losses.append(float(lt[0].detach()))
+        out, grads = O.loss_and_grads(ref, S.batch_to(raw, DEV), tasks="img2txt")
+        ref_losses.append(float(out["loss"].sum().detach()))
+        used = [k for k in ref if grads[k] is not None]
+        norm = {nd: float(torch.sqrt(sum((grads[k].double() ** 2).sum() for k in used if is_nd[k] == nd))) for nd in (False, True)}
+        with torch.no_grad():
+            for k in used:      # apex: one clip factor per param group (fp16_optimizer norm_groups), scale 1 on the fp32 side
+                O.fused_adam_step(ref[k], grads[k], rm[k], rv[k], lr=LR, grad_norm_scaled=norm[is_nd[k]], scale=1.0,
+                                  weight_decay=0.0 if is_nd[k] else 0.01)
+        for k in ref:
+            ref[k].grad = None
+    assert not opt.overflow and opt.skipped_steps == 0
+    rel = [abs(a - b) / abs(b) for a, b in zip(hip_losses, ref_losses)]
+    print("trajectory: max rel loss difference %.2e" % max(rel), hip_losses, ref_losses)
+    assert max(rel) <= 5e-4, (hip_losses, ref_losses)              # measured 9.1e-5 over the ten steps (fp16 logits under a 7-nat loss)
+    # weights: distance between the two end points relative to the distance travelled (Adam moves every weight by ~LR per step whatever
+    # the size of its gradient, so where a gradient is at the fp16 noise level the two runs may step in different directions)
+    d2 = u2 = 0.0
+    worst = 0.0
+    for i, key in enumerate(opt._group_key):
+        flat = opt.fp32_groups_flat[i]
+        offs = model.engine.offsets[key]
+        for n, q in model.named_parameters():
+            if n in offs and float(rm[n].abs().max()) > 0:
+                mine = flat[offs[n]:offs[n] + q.numel()].view_as(ref[n]).double()
+                theirs, start = ref[n].detach().double(), p0[n].to(DEV).double()
+                d2 += float(((mine - theirs) ** 2).sum())
+                u2 += float(((theirs - start) ** 2).sum())
+                worst = max(worst, float((mine - theirs).abs().max()))
+    ratio = (d2 / u2) ** 0.5
+    print("trajectory: |w_hip - w_oracle| / |w_oracle - w_0| = %.3f, worst element %.2e (%.1f LR)" % (ratio, worst, worst / LR))
+    assert u2 > 0 and ratio <= 0.05, ratio                          # measured 0.016
+    # no bias correction (the reference's FusedAdam configuration): a step moves a weight by up to (1 - b1) / sqrt(1 - b2) = 3.16 LR
+    assert worst <= 2 * STEPS * LR * 3.17, worst
+
 def test_overflow_skips_step_and_halves_scale():
     model, _ = small_model()
     model.train()
