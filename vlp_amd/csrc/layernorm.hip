@@ -181,6 +181,7 @@ extern "C" int vlp_layernorm_fwd(const vlp_layernorm_fwd_args* a, void* stream) 
 // in the second chunk at H = 768 and took 142 VGPRs -- one block per CU, 2 waves per SIMD, one row of prefetch each: 3.4 TB/s.)
 // Round 3 tried the half-wave form of the forward here (two rows per wave, 16-byte loads, 48 column sums per lane, values recomputed in
 // the second pass): 168 VGPRs + spills, 3 waves per SIMD, no next-row prefetch -- 20.9 us against 14.5 us for this kernel (tools/ln_lab.py).
+// A third row in flight (prefetch two rows ahead, 128 VGPRs): 17.4 us -- a wave only sees 2.6 rows, the extra requests just queue up front.
 // ---------------------------------------------------------------------------------------------
 #define LNB_BLOCKS 512
 #define LNB_THREADS 512
