@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VLP_ABI_VERSION 2
+#define VLP_ABI_VERSION 3
 
 typedef enum {
     VLP_OK = 0,
@@ -83,6 +83,9 @@ typedef struct {
                                             Every variant computes the same result (up to the fp32 summation order). */
 } vlp_gemm_nt_args;
 int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream);
+/* The variant the calling thread's last vlp_gemm_nt launched after its fallbacks (a wave-pipelined variant without the requested
+ * epilogue, or with operands beyond 32-bit offsets, runs on the rings 27 / 29); -1 before the first call. */
+int vlp_gemm_nt_resolved_variant(void);
 /* Split-K form for skinny problems (incremental decoding, M = 128..640 rows: only N/128 output tiles): the k range is cut into `splits`
  * slices computed by separate workgroups into an fp32 workspace of vlp_gemm_nt_splitk_workspace_bytes(M, N, splits) bytes; a second
  * kernel sums the slices in a fixed order (deterministic) and applies the same fused epilogue.  `variant` is ignored. */
@@ -453,7 +456,7 @@ typedef struct {
     const void* g; int32_t g_is_f32;
     void* p16;                           /* optional fp16 copy out (NULL for pure-fp32 use) */
     const int64_t* seg_off; int32_t ntensors; int64_t n;
-    float* norms;
+    float* norms; int64_t norms_floats;  /* ABI 3: size of `norms` in floats, checked against vlp_bert_adam_norms_floats() */
     float lr, b1, b2, eps, decay, max_grad_norm;
     float grad_scale;                    /* gradients are divided by this (loss scale), 1 for fp32 */
     const int32_t* active;               /* [ntensors] device flags or NULL: tensors with 0 are skipped entirely

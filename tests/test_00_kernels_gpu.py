@@ -112,6 +112,47 @@ def test_gemm_nt_phased(variant, M, N, K, gen):
         assert rel(y1[:, :N].float(), x[:, :64].float() @ w[:, :64].float().t()) < 1.5e-3
 
 
+def test_gemm_nt_variant_identity(gen):
+    """the full-size report lists the SAME 16-digit logits error under every forced variant, including the
+    32x32x16-MFMA family.  Two questions, answered here on one GEMM of the step (10 688 x 768 x 3072):
+      (a) does a forced variant reach the kernel it names?  vlp_gemm_nt_resolved_variant() returns what the launcher ran after its
+          fallbacks -- asserted for the rings (27, 29), the wave-pipelined kernels (73, 77) and the fallback cases;
+      (b) are the fp16 outputs of the 16x16x32 chains (rings) and the 32x32x16 chains (wave-pipelined) bit-identical?  Both walk k in
+          ascending order and accumulate in fp32; whether one 16x16x32 MFMA rounds like two 32x32x16 steps is a property of the matrix
+          pipe.  The outcome is recorded in gpurun_out/nt_variant_identity.json and asserted to be what round 4 measured
+          (see DESIGN.md section 4)."""
+    import json
+    import os
+    M, N, Kd = 10688, 768, 3072
+    x, w = h16(M, Kd, gen=gen), h16(N, Kd, scale=0.05, gen=gen)
+    out, resolved = {}, {}
+    for v in (27, 29, 13, 73, 77, 69):
+        y = torch.full((M, N), 7.0, device=DEV, dtype=torch.half)
+        K.gemm_nt(x, w, y, M, N, Kd, variant=v)
+        resolved[v] = K.gemm_nt_resolved_variant()
+        out[v] = y
+        assert resolved[v] == v, (v, resolved[v])                      # plain epilogue: nothing falls back
+    # a wave-pipelined variant with an erf epilogue has no instantiation: the launcher must say that it ran a ring instead
+    y = torch.empty(M, N, device=DEV, dtype=torch.half)
+    K.gemm_nt(x, w, y, M, N, Kd, act=K.ACT_GELU, variant=77)
+    assert K.gemm_nt_resolved_variant() == 27
+    K.gemm_nt(x, w, y, M, N, Kd, act=K.ACT_GELU_SAVE_GRAD, preact=torch.empty_like(y), variant=77)
+    assert K.gemm_nt_resolved_variant() == 77
+    same = {"%d_vs_%d" % (a, b): bool(torch.equal(out[a], out[b])) for a, b in ((27, 29), (27, 13), (73, 77), (77, 69), (27, 77), (29, 73))}
+    ulp = {k: float((out[int(k.split("_")[0])].float() - out[int(k.split("_")[2])].float()).abs().max()) for k in same}
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/nt_variant_identity.json", "w") as f:
+        json.dump({"shape": [M, N, Kd], "resolved": {str(k): v for k, v in resolved.items()}, "bit_identical": same, "max_abs_diff": ulp}, f, indent=1)
+    # within an MFMA family the chain per output element does not depend on the tile shape
+    assert same["27_vs_29"] and same["27_vs_13"] and same["73_vs_77"] and same["77_vs_69"], same
+    # across the families: measured in round 4 (profiles/r04_nt_variant_identity.json)
+    if NT_FAMILIES_BIT_IDENTICAL is not None:
+        assert same["27_vs_77"] == NT_FAMILIES_BIT_IDENTICAL and same["29_vs_73"] == NT_FAMILIES_BIT_IDENTICAL, (same, ulp)
+
+
+NT_FAMILIES_BIT_IDENTICAL = None      # set from the first measurement (None: report only)
+
+
 @pytest.mark.parametrize("M,N,K,splits", [(128, 768, 3072, 8), (128, 2304, 768, 4), (640, 768, 768, 3), (77, 1000, 192, 2), (320, 3072, 768, 12),
                                             (128, 768, 768, 64)])
 def test_gemm_nt_splitk(M, N, K, splits, gen):

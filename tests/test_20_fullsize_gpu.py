@@ -285,18 +285,26 @@ def test_full_size_logits_under_every_nt_variant():
     t = truth["mlm_logits"].float()
     yard = _relmax(ref16["mlm_logits"].float(), t)
     m = _build(p, "img2txt")
+    from vlp_amd import _lib as K
     old = Engine.GEMM_NT_VARIANT
-    rep = {}
+    rep, ran = {}, {}
     try:
         for v in sorted(set(Engine.NT_CANDIDATES) | {1, 3, 11, 13}):
             Engine.GEMM_NT_VARIANT = v
             losses = _hip(m, batch)
+            # the last GEMM of the forward is the tied decoder (plain epilogue + bias): the launcher must have run the forced variant
+            # there (vlp_gemm_nt_resolved_variant: what ran after the launcher's fallbacks)
+            ran[v] = K.gemm_nt_resolved_variant()
+            assert ran[v] == v, (v, ran[v])
             rep[v] = _relmax(m.last_mlm_logits.float().reshape(t.shape), t)
             assert rep[v] <= yard + 1e-3, (v, rep, yard)
             assert abs(float(losses[0]) - float(truth["mlm_loss"])) <= 2e-3 * float(truth["mlm_loss"]), v
     finally:
         Engine.GEMM_NT_VARIANT = old
+    # (the numbers may coincide to the last digit: variants of one MFMA family accumulate every output element in the same order whatever
+    # the tile shape, and tests/test_00_kernels_gpu.py::test_gemm_nt_variant_identity records whether the two families agree bit for bit)
     FULL_REPORT["nt_variants_logits_vs_fp32"] = {"reference_fp16": yard, **{str(k): x for k, x in rep.items()}}
+    FULL_REPORT["nt_variants_resolved"] = {str(k): x for k, x in ran.items()}
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/parity_fullsize.json", "w") as f:
         json.dump(FULL_REPORT, f, indent=1)

@@ -118,7 +118,7 @@ class FusedAdamArgs(C.Structure):
 
 class BertAdamArgs(C.Structure):
     _fields_ = [("p32", vp), ("m", vp), ("v", vp), ("g", vp), ("g_is_f32", i32), ("p16", vp),
-                ("seg_off", vp), ("ntensors", i32), ("n", i64), ("norms", vp),
+                ("seg_off", vp), ("ntensors", i32), ("n", i64), ("norms", vp), ("norms_floats", i64),
                 ("lr", f32), ("b1", f32), ("b2", f32), ("eps", f32), ("decay", f32), ("max_grad_norm", f32), ("grad_scale", f32),
                 ("active", vp)]
 
@@ -128,6 +128,7 @@ SYMBOLS = {
     "vlp_version": (C.c_int, []),
     "vlp_last_error_string": (C.c_char_p, []),
     "vlp_gemm_nt": (C.c_int, [C.POINTER(GemmNtArgs), vp]),
+    "vlp_gemm_nt_resolved_variant": (C.c_int, []),
     "vlp_gemm_nt_splitk_workspace_bytes": (C.c_int64, [i32, i32, i32]),
     "vlp_gemm_nt_splitk": (C.c_int, [C.POINTER(GemmNtArgs), i32, vp, i64, vp]),
     "vlp_gemm_tn_workspace_bytes": (i64, [i32, i32, i32]),
@@ -241,7 +242,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.vlp_version() != 2:      # include/vlp_hip.h VLP_ABI_VERSION
+    if lib.vlp_version() != 3:      # include/vlp_hip.h VLP_ABI_VERSION
         raise RuntimeError("libvlp_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -281,6 +282,11 @@ def gemm_nt(x, w, y, M, N, K, ldx=None, ldw=None, ldy=None, bias=None, residual=
                    ptr(mul_src), (ldm if ldm is not None else (mul_src.stride(0) if mul_src is not None else 0)),
                    M, N, K, act, mul_mode, alpha, dropout_p, seed, rng_stream, variant)
     _check(load().vlp_gemm_nt(C.byref(a), stream_ptr()))
+
+
+def gemm_nt_resolved_variant():
+    """The variant this thread's last gemm_nt actually launched (after the launcher's fallbacks)."""
+    return int(load().vlp_gemm_nt_resolved_variant())
 
 
 def gemm_nt_splitk_workspace_bytes(M, N, splits):
@@ -577,9 +583,6 @@ def bert_adam_norms_floats(n, ntensors):
 def bert_adam(p32, m, v, g, g_is_f32, p16, seg_off, ntensors, n, norms, lr, b1=0.9, b2=0.999, eps=1e-6, decay=0.01,
               max_grad_norm=1.0, grad_scale=1.0, active=None):
     _req_cuda(p32, m, v, g, seg_off, norms)
-    if norms.numel() < bert_adam_norms_floats(n, ntensors):
-        raise RuntimeError("vlp_bert_adam: `norms` needs vlp_bert_adam_norms_floats(n, ntensors) = %d floats, got %d"
-                           % (bert_adam_norms_floats(n, ntensors), norms.numel()))
-    a = BertAdamArgs(ptr(p32), ptr(m), ptr(v), ptr(g), int(g_is_f32), ptr(p16), ptr(seg_off), ntensors, n, ptr(norms),
+    a = BertAdamArgs(ptr(p32), ptr(m), ptr(v), ptr(g), int(g_is_f32), ptr(p16), ptr(seg_off), ntensors, n, ptr(norms), norms.numel(),   # the library checks the scratch size (ABI 3)
                      lr, b1, b2, eps, decay, max_grad_norm, grad_scale, ptr(active))
     _check(load().vlp_bert_adam(C.byref(a), stream_ptr()))

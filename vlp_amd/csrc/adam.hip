@@ -214,6 +214,7 @@ __global__ __launch_bounds__(256) void bert_adam_norm_kernel(vlp_bert_adam_args 
     int t = ba_find(a.seg_off, a.ntensors, start);
     int64_t pos = start;
     while (pos < end) {
+        if (t >= a.ntensors) break;                  // n beyond seg_off[ntensors] (padded flat buffer): the tail belongs to no tensor
         const int64_t tend = min(end, a.seg_off[t + 1]);
         if (a.active && !a.active[t]) { pos = tend; ++t; continue; }
         float s = 0.f;
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(256) void bert_adam_update_kernel(vlp_bert_adam_arg
     int64_t pos = start;
     f16* p16 = (f16*)a.p16;
     while (pos < end) {
+        if (t >= a.ntensors) break;
         const int64_t tend = min(end, a.seg_off[t + 1]);
         if (a.active && !a.active[t]) { pos = tend; ++t; continue; }
         float coef = 1.f;
@@ -281,6 +283,11 @@ extern "C" int vlp_bert_adam(const vlp_bert_adam_args* a, void* stream) {
     VLP_CHECK_ARG(a && a->p32 && a->m && a->v && a->g && a->seg_off && a->norms, "vlp_bert_adam: null operand");
     VLP_ENTER(a->p32, "vlp_bert_adam");
     VLP_CHECK_ARG(a->n > 0 && a->ntensors > 0 && a->grad_scale > 0.f, "vlp_bert_adam: bad sizes");
+    // ABI 3: the scratch size travels with the call (an ABI-1 consumer that sized `norms` as [ntensors] would otherwise get silent
+    // out-of-bounds device writes from the two-stage norm reduction)
+    VLP_CHECK_ARG(a->norms_floats >= vlp_bert_adam_norms_floats(a->n, a->ntensors),
+                  "vlp_bert_adam: norms_floats=%lld < vlp_bert_adam_norms_floats(n, ntensors)=%lld", (long long)a->norms_floats,
+                  (long long)vlp_bert_adam_norms_floats(a->n, a->ntensors));
     hipStream_t s = (hipStream_t)stream;
     const int blocks = (int)((a->n + BA_CHUNK - 1) / BA_CHUNK);
     if (a->max_grad_norm > 0.f) {

@@ -2,6 +2,10 @@
 #include <hip/hip_runtime_api.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "common.h"
 
 #include "vlp_hip.h"
 
@@ -19,23 +23,44 @@ extern "C" int vlp_version(void) { return VLP_ABI_VERSION; }
 extern "C" const char* vlp_last_error_string(void) { return g_err; }
 
 // ---- device selection on entry (common.h) -----------------------------------------------------------------------------------------
-static thread_local int t_device = -1;         // device this thread last made current through the library
+// The library never trusts a private notion of "the current device": the host (torch.cuda.set_device, `with torch.cuda.device()`) may
+// change it between two calls.  Every entry compares the device that owns its first operand with hipGetDevice() (thread-local inside the
+// runtime, no driver call), switches if they differ and RESTORES the caller's device on return (VlpDeviceGuard, common.h) -- so torch's
+// own bookkeeping of the current device stays true.  Which device owns a pointer is a driver query (hipPointerGetAttributes); it is
+// asked once per allocation and remembered per thread as an address range (the caching allocator hands out views of a few dozen
+// segments), re-validated every VLP_RANGE_REVALIDATE hits in case an allocation was freed and its addresses re-used on another device.
 static int device_count() {
-    static int n = [] { int c = 0; if (hipGetDeviceCount(&c) != hipSuccess) { (void)hipGetLastError(); c = 0; } return c; }();
+    static int n = [] {
+        int c = 0;
+        if (hipGetDeviceCount(&c) != hipSuccess) { (void)hipGetLastError(); c = 0; }
+        if (const char* e = getenv("VLP_FAKE_DEVICE_COUNT")) { const int f = atoi(e); if (f > 0) c = f; }   // tests: the multi-device path on a 1-GPU box
+        return c;
+    }();
     return n;
 }
 int vlp_current_device(void) {
-    if (t_device >= 0) return t_device;
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; }
     return d;
 }
-int vlp_enter_device(const void* p, const char* who) {
-    if (p == nullptr) return VLP_OK;           // the entry's own argument check reports the null operand
-    if (device_count() == 1) {                 // a single-GPU process: nothing to select, and no driver query per call
-        if (t_device != 0) { (void)hipSetDevice(0); t_device = 0; }
-        return VLP_OK;
+#define VLP_RANGE_SLOTS 64
+#define VLP_RANGE_REVALIDATE 4096
+struct VlpRange { uintptr_t lo, hi; int dev; unsigned hits; };
+static thread_local VlpRange t_ranges[VLP_RANGE_SLOTS];
+static thread_local int t_nranges = 0, t_next = 0;
+static thread_local unsigned long long t_lookups = 0, t_queries = 0;      // vlp_debug_device_lookup_stats
+static int owner_of(const void* p, const char* who, int* dev) {
+    const uintptr_t a = (uintptr_t)p;
+    ++t_lookups;
+    for (int i = 0; i < t_nranges; ++i) {
+        VlpRange& r = t_ranges[i];
+        if (a >= r.lo && a < r.hi) {
+            if (++r.hits % VLP_RANGE_REVALIDATE) { *dev = r.dev; return VLP_OK; }
+            r = t_ranges[--t_nranges];            // periodic re-validation: drop the entry and ask the driver again
+            break;
+        }
     }
+    ++t_queries;
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, p) != hipSuccess) {
         (void)hipGetLastError();
@@ -43,9 +68,36 @@ int vlp_enter_device(const void* p, const char* who) {
     }
     if (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged && at.type != hipMemoryTypeUnified)
         return vlp_set_error(VLP_ERR_BAD_ARG, "%s: operand %p is host memory (libvlp_hip has no CPU path)", who, p);
-    if (at.device != t_device) {
-        if (hipSetDevice(at.device) != hipSuccess) return vlp_set_error(VLP_ERR_HIP, "%s: hipSetDevice(%d): %s", who, at.device, hipGetErrorString(hipGetLastError()));
-        t_device = at.device;
+    *dev = at.device;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) == hipSuccess && size > 0) {
+        VlpRange r = {(uintptr_t)base, (uintptr_t)base + size, at.device, 0u};
+        if (t_nranges < VLP_RANGE_SLOTS) t_ranges[t_nranges++] = r;
+        else { t_ranges[t_next] = r; t_next = (t_next + 1) % VLP_RANGE_SLOTS; }
+    } else {
+        (void)hipGetLastError();
     }
     return VLP_OK;
+}
+VlpDeviceGuard::VlpDeviceGuard(const void* p, const char* who) : prev(-1), rc(VLP_OK) {
+    if (p == nullptr) return;                  // the entry's own argument check reports the null operand
+    int dev = 0;
+    rc = owner_of(p, who, &dev);               // also refuses host pointers, on single-GPU processes too
+    if (rc != VLP_OK || device_count() <= 1) return;
+    const int cur = vlp_current_device();
+    if (dev == cur) return;
+    if (hipSetDevice(dev) != hipSuccess) {
+        rc = vlp_set_error(VLP_ERR_HIP, "%s: hipSetDevice(%d): %s", who, dev, hipGetErrorString(hipGetLastError()));
+        return;
+    }
+    prev = cur;
+}
+VlpDeviceGuard::~VlpDeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);   // the caller's current device is left as it was found
+}
+// test hook: (owner lookups, driver queries) of the calling thread
+extern "C" void vlp_debug_device_lookup_stats(unsigned long long* lookups, unsigned long long* driver_queries) {
+    if (lookups) *lookups = t_lookups;
+    if (driver_queries) *driver_queries = t_queries;
 }

@@ -36,16 +36,21 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------------------------
 // device selection on entry (SURVEY.md 8b threading contract): every entry point makes the device that owns its first operand current
-// for the calling thread (hipPointerGetAttributes; skipped on single-GPU processes), so the library can be driven from any host thread
-// and for several devices of one process.  A host pointer is refused here with a clear message instead of faulting in a kernel.
+// for the calling thread for the duration of the call and puts the caller's device back on return (the owner of a pointer is asked from
+// the driver once per allocation and cached per thread), so the library can be driven from any host thread and for several devices of
+// one process.  A host pointer is refused here with a clear message instead of faulting in a kernel.
 // ---------------------------------------------------------------------------------------------
-int vlp_enter_device(const void* device_ptr, const char* who);      // api.cpp; returns VLP_OK or VLP_ERR_BAD_ARG / VLP_ERR_HIP
-int vlp_current_device(void);                                       // the device vlp_enter_device selected for this thread (hipGetDevice otherwise)
+struct VlpDeviceGuard {      // api.cpp: selects the operand's device for the scope of one entry point, restores the caller's on return
+    int prev, rc;
+    VlpDeviceGuard(const void* device_ptr, const char* who);
+    ~VlpDeviceGuard();
+    VlpDeviceGuard(const VlpDeviceGuard&) = delete;
+    VlpDeviceGuard& operator=(const VlpDeviceGuard&) = delete;
+};
+int vlp_current_device(void);                                       // hipGetDevice() of the calling thread
 #define VLP_ENTER(ptr, who)                                 \
-    do {                                                    \
-        const int erc_ = vlp_enter_device((ptr), (who));    \
-        if (erc_ != VLP_OK) return erc_;                    \
-    } while (0)
+    VlpDeviceGuard vlp_guard_((ptr), (who));                \
+    if (vlp_guard_.rc != VLP_OK) return vlp_guard_.rc
 // launcher state that HIP keeps per device (hipFuncSetAttribute: dynamic LDS limit): set once per (kernel instantiation, device), race-free --
 // two threads may both run `stmt` (idempotent), nobody launches before it has run on his device
 #define VLP_ONCE_PER_DEVICE(stmt)                                                      \

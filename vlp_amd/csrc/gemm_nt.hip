@@ -337,7 +337,6 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BN
 int vlp_gemm_nt_fill_params(const vlp_gemm_nt_args* a, GemmNtParams& p) {
     VLP_CHECK_ARG(a != nullptr, "vlp_gemm_nt: null args");
     VLP_CHECK_ARG(a->X && a->W && a->Y, "vlp_gemm_nt: null operand");
-    VLP_ENTER(a->X, "vlp_gemm_nt");
     VLP_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "vlp_gemm_nt: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
     VLP_CHECK_ARG(a->K % BK == 0, "vlp_gemm_nt: K=%d must be a multiple of %d (pad with vlp_copy2d)", a->K, BK);
     VLP_CHECK_ARG(a->ldx % 8 == 0 && a->ldw % 8 == 0 && a->ldy % 8 == 0, "vlp_gemm_nt: leading dims must be multiples of 8 halfs");
@@ -374,7 +373,13 @@ int vlp_gemm_nt_fill_params(const vlp_gemm_nt_args* a, GemmNtParams& p) {
     return VLP_OK;
 }
 
+// the variant the calling thread's last vlp_gemm_nt actually launched (after the fallbacks below): lets a test assert that a forced
+// variant is the kernel that ran (tests/test_00_kernels_gpu.py::test_gemm_nt_variant_identity)
+static thread_local int t_last_variant = -1;
+extern "C" int vlp_gemm_nt_resolved_variant(void) { return t_last_variant; }
+
 extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
+    VLP_ENTER(a ? a->X : nullptr, "vlp_gemm_nt");        // the guard lives until the launch below has been issued
     GemmNtParams p;
     const int frc = vlp_gemm_nt_fill_params(a, p);
     if (frc != VLP_OK) return frc;
@@ -397,6 +402,9 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
     if ((variant & 64) && !sg && !nt_epilogue_is_light(p)) variant = (a->N > 1024) ? 29 : 27;
     // the phased kernels (6, 7) do not instantiate the save-grad epilogue: same fallback instead of an error for a table / override entry
     if (sg && !(variant & 64) && ((variant & 7) == 6 || (variant & 7) == 7)) variant = (a->N > 1024) ? 29 : 27;
+    // the wave-pipelined kernels address their operands with 32-bit lane offsets: a problem beyond that falls back to the rings too
+    if ((variant & 64) && ((int64_t)p.M * p.ldx >= (1ll << 31) || (int64_t)p.N * p.ldw >= (1ll << 31))) variant = (a->N > 1024) ? 29 : 27;
+    t_last_variant = variant;
     if (sg) {
         VLP_CHECK_ARG(!a->residual && a->mul_mode == VLP_MUL_NONE && a->dropout_p == 0.f,
                       "vlp_gemm_nt: VLP_ACT_GELU_SAVE_GRAD fuses bias + gelu + derivative only (no residual / multiplier / dropout)");
@@ -438,6 +446,7 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
 
 // split-K form for skinny M (gemm_nt_splitk.hip); same arguments, plus the slice count and an fp32 workspace
 extern "C" int vlp_gemm_nt_splitk(const vlp_gemm_nt_args* a, int32_t splits, void* workspace, int64_t workspace_bytes, void* stream) {
+    VLP_ENTER(a ? a->X : nullptr, "vlp_gemm_nt_splitk");
     GemmNtParams p;
     const int frc = vlp_gemm_nt_fill_params(a, p);
     if (frc != VLP_OK) return frc;

@@ -146,9 +146,11 @@ extern "C" int vlp_layernorm_fwd(const vlp_layernorm_fwd_args* a, void* stream) 
 #define LAUNCH_LN_FWD(NP_)                                                                                                              \
     hipLaunchKernelGGL(layernorm_fwd_kernel<NP_>, dim3(blocks), dim3(LN_THREADS), 0, s, (const f16*)a->x, a->ldx, (const f16*)a->gamma, \
                        (const f16*)a->beta, (f16*)a->y, a->ldy, a->mean, a->rstd, a->M, a->H, a->eps, d)
-    static int use_hw = -1;      // VLP_LN_HALFWAVE=0: the one-row-per-wave kernel everywhere (A/B runs)
-    if (use_hw < 0) { const char* e = getenv("VLP_LN_HALFWAVE"); use_hw = e ? atoi(e) : 1; }
+    // VLP_LN_HALFWAVE=0: the one-row-per-wave kernel everywhere (A/B runs).  Read once; the per-call decision is a local (the entry
+    // points may be driven from several host threads)
+    static const int use_hw = [] { const char* e = getenv("VLP_LN_HALFWAVE"); return e ? atoi(e) : 1; }();
     if (use_hw && a->H % 256 == 0 && a->H <= 2048) {
+        bool launched = true;
         const int hblocks = ln_fwd_blocks((a->M + 1) / 2);
 #define LAUNCH_LN_HW(NC_)                                                                                                                  \
     hipLaunchKernelGGL(layernorm_fwd_hw_kernel<NC_>, dim3(hblocks), dim3(LN_THREADS), 0, s, (const f16*)a->x, a->ldx, (const f16*)a->gamma, \
@@ -159,10 +161,9 @@ extern "C" int vlp_layernorm_fwd(const vlp_layernorm_fwd_args* a, void* stream) 
         else if (a->H == 1024) LAUNCH_LN_HW(4);
         else if (a->H == 1536) LAUNCH_LN_HW(6);
         else if (a->H == 2048) LAUNCH_LN_HW(8);
-        else use_hw = 2;
+        else launched = false;         // no half-wave instantiation for this H: the row-per-wave kernel below
 #undef LAUNCH_LN_HW
-        if (use_hw != 2) { VLP_CHECK_LAUNCH("vlp_layernorm_fwd"); return VLP_OK; }
-        use_hw = 1;
+        if (launched) { VLP_CHECK_LAUNCH("vlp_layernorm_fwd"); return VLP_OK; }
     }
     if (a->H <= 768) LAUNCH_LN_FWD(3);
     else if (a->H <= 1024) LAUNCH_LN_FWD(4);

@@ -14,12 +14,15 @@ absent here; this module restates that contract on the flat buffers of vlp_amd.e
 Every scalar decision stays on the device: a training step issues no host synchronisation
 (`cur_scale`, `overflow` are read back lazily, only when inspected).
 """
+import logging
 import os
 
 import torch
 
 from . import _lib as K
 from .engine import is_no_decay
+
+logger = logging.getLogger(__name__)
 
 
 class FusedAdam(object):
@@ -326,11 +329,17 @@ class FP16_Optimizer_State(object):
         self._applied0, self._iter0, self._skipped0 = step, stl[1], stl[6]
         for i, key in enumerate(self._group_key):       # refresh the fp16 model copy from the restored masters
             self.engine.flat[key].copy_(self.fp32_groups_flat[i])
+        # apex's layout has no slot for the engine's dropout stream position: weights, moments and the loss scale resume exactly, the
+        # dropout MASK sequence restarts from this process's seed (a native optim.N.bin carries `vlp_rng` and resumes mask-exactly)
+        logger.info("FP16_Optimizer_State: resumed from an apex-layout file; the dropout stream position is not part of that layout "
+                    "(masks restart from base_seed=%d, step_seed=%d)", self.engine.base_seed, self.engine.step_seed)
 
     def load_state_dict(self, sd):
-        if "exp_avg" not in sd.get("optimizer_state_dict", {}) and "state" in sd.get("optimizer_state_dict", {}) \
-                and any(isinstance(v, dict) and "exp_avg" in v for v in sd["optimizer_state_dict"]["state"].values()):
-            return self.load_apex_state_dict(sd)            # a file of the reference stack
+        inner = sd.get("optimizer_state_dict", {})
+        # the reference stack's layout is recognised by its STRUCTURE (a torch Optimizer state_dict: 'state' + 'param_groups', none of
+        # this class's own keys) -- also when the inner state is still empty (a file saved before the first applied step)
+        if "state" in inner and "param_groups" in inner and "exp_avg" not in inner and "group_keys" not in inner:
+            return self.load_apex_state_dict(sd)
         self._sync()
         self.dynamic_loss_scale = sd["dynamic_loss_scale"]
         st = self._scale_state.cpu()
