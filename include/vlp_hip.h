@@ -236,6 +236,41 @@ int vlp_layernorm_bwd(const vlp_layernorm_bwd_args* a, void* stream);
 int vlp_layernorm_bwd_reduce_batched(const float* parts, const void* const* dst, int32_t count, int32_t M, int32_t H, int32_t beta, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * mask_image_regions / vis_pretext_loss (modeling.py:1049-1056, 1113-1131; loader: seq2seq_loader.py:267-269, 303-304).
+ * vlp_region_mask_build: vis_masked_pos [B, Pm] (int64, values 1..Nv) -> out [B*Nv] bytes, 1 on the masked region rows.
+ * vlp_pretext_fwd: per sample b, with r_i = vis_masked_pos[b,i] - 1:  A_i = vispe_h[b, r_i] + pooled[b]  (rounded to fp16 like the
+ *   reference's in-place add :1124),  V_j = vis_h[b, r_j],  sim = A . V^T ([Pm, Pm], rounded to fp16 like the half matmul :1126),
+ *   probs = softmax(sim) rows (fp32, kept for backward),  sample_loss[b] = -mean_i log probs[i,i];  loss[0] = mean_b sample_loss[b]
+ *   (:1127-1131; summed in a fixed order: bitwise reproducible).  Pm <= 64.
+ * vlp_pretext_bwd: gscale[0] = upstream gradient of the pretext loss (x loss scale).  dsim = gscale / (B Pm) (probs - I);
+ *   dA = dsim . V, dV = dsim^T . A.  Writes ONLY the masked rows of d_vis_h / d_vispe_h (through ReLU + dropout exactly as
+ *   vlp_embed_bwd does for the other rows: y > 0 mask and the dropout multiplier of element (region row, col) of streams
+ *   vis_stream / vispe_stream), and d_pooled_pre[b] = (sum_i dA_i) * (1 - pooled[b]^2) (backward of the pooler's tanh, :416).
+ */
+int vlp_region_mask_build(const int64_t* vis_masked_pos, int32_t B, int32_t Pm, int32_t Nv, uint8_t* out, void* stream);
+typedef struct {
+    const void* vis_h; const void* vispe_h;                 /* f16 [B*Nv, H] (post ReLU + dropout) */
+    const void* pooled;                                     /* f16 [B, H] */
+    const int64_t* vis_masked_pos;                          /* [B, Pm] */
+    float* probs;                                           /* f32 [B, Pm, Pm] out */
+    float* sample_loss;                                     /* f32 [B] out */
+    float* loss;                                            /* f32 [1] out */
+    int32_t B, Nv, Pm, H;
+} vlp_pretext_fwd_args;
+int vlp_pretext_fwd(const vlp_pretext_fwd_args* a, void* stream);
+typedef struct {
+    const void* vis_h; const void* vispe_h; const void* pooled;
+    const int64_t* vis_masked_pos;
+    const float* probs;                                     /* from vlp_pretext_fwd */
+    const float* gscale;                                    /* device f32 [1] */
+    void* d_vis_h; void* d_vispe_h;                         /* f16 [B*Nv, H]: masked rows written */
+    void* d_pooled_pre;                                     /* f16 [B, H] out */
+    int32_t B, Nv, Pm, H;
+    float drop_p; uint64_t seed; uint32_t vis_stream; uint32_t vispe_stream;
+} vlp_pretext_bwd_args;
+int vlp_pretext_bwd(const vlp_pretext_bwd_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Embedding splice (modeling.py:217-236): pre[b,l,:] = word(l) + pos(l) + type[seg[b,l]] where for
  * l in [1, Nv] word(l) = vis_h[b,l-1] and pos(l) = vispe_h[b,l-1] (projected region features / box
  * encodings), else word = word_emb[input_ids[b,l]], pos = pos_emb[l].  (LayerNorm + dropout :239-240
@@ -249,6 +284,8 @@ typedef struct {
     int32_t B, L, Nv, H, vocab, type_vocab;
     const int64_t* position_ids;                            /* [B,L] or NULL (= 0..L-1); incremental decoding passes them (:856-865) */
     int32_t max_pos;                                        /* rows of pos_emb */
+    const uint8_t* region_mask;                             /* ABI 3: [B*Nv] or NULL; 1 = this region row enters as zeros (word and position
+                                                               stream; mask_image_regions, modeling.py:1049-1056), vlp_region_mask_build */
 } vlp_embed_fwd_args;
 int vlp_embed_fwd(const vlp_embed_fwd_args* a, void* stream);
 
@@ -267,6 +304,8 @@ typedef struct {
     float* acc32;
     int32_t B, L, Nv, H, vocab, type_vocab;
     float drop_p; uint64_t seed; uint32_t vis_stream; uint32_t vispe_stream;
+    const uint8_t* region_mask;                             /* ABI 3: [B*Nv] or NULL; rows with 1 got no signal from the encoder: their d_vis_h /
+                                                               d_vispe_h rows are NOT written here (vlp_pretext_bwd owns them) */
 } vlp_embed_bwd_args;
 int vlp_embed_bwd(const vlp_embed_bwd_args* a, void* stream);
 
@@ -313,8 +352,10 @@ int vlp_argmax_rows(const void* logits, int64_t ld, int32_t rows, int32_t V, int
  *       -> the 6+n_cls encoding of seq2seq_loader.py:338-351 (corners / largest corner of the image, clamped relative area, layer norm of the 6
  *       box numbers and of the class probabilities, eps inside the sqrt) in f16, zero padded to pad_to columns = the K-padded operand of the
  *       vis_pe_embed GEMM (modeling.py:1016). */
+/* ABI 3: region_mask ([B*Nv] bytes from vlp_region_mask_build, or NULL) additionally blocks the key columns 1..Nv of masked regions
+ * for every query (mask_image_regions, seq2seq_loader.py:303-304). */
 int vlp_mask_build(const int32_t* second_st, const int32_t* second_end, const int32_t* is_s2s, uint8_t* out, uint8_t* out_t, int32_t B, int32_t L,
-                   int32_t Lp, void* stream);
+                   int32_t Lp, const uint8_t* region_mask, int32_t Nv, void* stream);
 typedef struct {
     const float* bbox;       /* [B, Nv, 6] f32 */
     const void* cls;         /* [B*Nv, ld_cls] f16 or f32 */

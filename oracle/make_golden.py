@@ -35,6 +35,12 @@ CASES = {
                      dict(batch_size=2, max_len_b=20, vocab_size=1024, max_pred=1, tasks="vqa2", seed=103)),
     "img2txt_L167_12l": (dict(vocab_size=2048, layers=12, tasks="img2txt", seed=14),
                          dict(batch_size=2, max_len_b=64, vocab_size=2048, max_pred=3, s2s_prob=0.75, seed=104)),
+    # --vis_mask_prob 0.25: masked region rows + the Selfie-style pretext loss over the pooled output (modeling.py:1049-1056, 1113-1131);
+    # the reference's .byte() row mask (:1050) is shimmed to .bool() around the unmodified call (torch >= 1.2 refuses byte masks)
+    "img2txt_L123_2l_vismask": (dict(vocab_size=1024, layers=2, tasks="img2txt", seed=15, mask_image_regions=True),
+                                dict(batch_size=3, max_len_b=20, vocab_size=1024, max_pred=3, s2s_prob=0.5, seed=105, vis_mask_prob=0.25)),
+    "vqa2_L123_2l_vismask": (dict(vocab_size=1024, layers=2, tasks="vqa2", seed=16, mask_image_regions=True),
+                             dict(batch_size=2, max_len_b=20, vocab_size=1024, max_pred=1, tasks="vqa2", seed=106, vis_mask_prob=0.25)),
 }
 
 # greedy decoding cases (BertForSeq2SeqDecoder, modeling.py:1189-1253): (model kwargs, B, T, input seed)
@@ -61,6 +67,7 @@ GRAD_SAMPLES = [
     "bert.encoder.layer.1.intermediate.dense.weight", "bert.encoder.layer.1.output.LayerNorm.bias",
     "vis_embed.0.weight", "vis_embed.2.bias", "vis_pe_embed.0.weight",
     "cls.predictions.transform.dense.weight", "cls.predictions.bias", "ans_classifier.2.weight",
+    "bert.pooler.dense.weight", "bert.pooler.dense.bias",      # live in the vismask cases only
 ]
 
 
@@ -99,10 +106,18 @@ def run_reference_case(mk, bk):
     model.bert.embeddings.register_forward_hook(lambda m, i, o: hid.append(o.detach()))
     for lyr in model.bert.encoder.layer:
         lyr.register_forward_hook(lambda m, i, o: hid.append(o.detach()))
-    losses = model(batch.img, batch.vis_pe, batch.input_ids, batch.segment_ids, batch.input_mask,
-                   batch.lm_label_ids, batch.ans_labels, batch.is_next, masked_pos=batch.masked_pos,
-                   masked_weights=batch.masked_weights, task_idx=batch.task_idx,
-                   vis_masked_pos=batch.vis_masked_pos, mask_image_regions=False, drop_worst_ratio=0)
+    mir = bool(mk.get("mask_image_regions", False))
+    true_byte = torch.Tensor.byte
+    if mir:
+        torch.Tensor.byte = lambda self: self.bool()
+        model.bert.pooler.register_forward_hook(lambda m, i, o: cap.__setitem__("pooled_output", o.detach()))
+    try:
+        losses = model(batch.img, batch.vis_pe, batch.input_ids, batch.segment_ids, batch.input_mask,
+                       batch.lm_label_ids, batch.ans_labels, batch.is_next, masked_pos=batch.masked_pos,
+                       masked_weights=batch.masked_weights, task_idx=batch.task_idx,
+                       vis_masked_pos=batch.vis_masked_pos, mask_image_regions=mir, drop_worst_ratio=0)
+    finally:
+        torch.Tensor.byte = true_byte
     loss = losses[0] + losses[1] + losses[2]          # run_img2txt_dist.py:531
     loss.sum().backward()
     out = {"fingerprint": fingerprint(p, batch),
@@ -249,6 +264,15 @@ def run_reference_loader_case(mode, n_tokens, seed, max_len_b=20, Nv=100, always
 def main():
     torch.set_num_threads(8)
     os.makedirs(GOLDEN_DIR, exist_ok=True)
+    only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]
+    if only:            # python -m oracle.make_golden --only=name[,name]: (re)generate the named forward / backward cases only
+        for name in only[0]:
+            mk, bk = CASES[name]
+            out = run_reference_case(mk, bk)
+            path = os.path.join(GOLDEN_DIR, name + ".npz")
+            np.savez_compressed(path, **out)
+            print("%s: losses=%s  -> %s (%.1f KB)" % (name, out["losses"], path, os.path.getsize(path) / 1024))
+        return
     for name, (mode, n_tokens, seed) in LOADER_CASES.items():
         out, bbox, cls, feat, nb = run_reference_loader_case(mode, n_tokens, seed)
         path = os.path.join(GOLDEN_DIR, name + ".npz")

@@ -267,9 +267,26 @@ def vqa_head(p, h, len_vis_input):
     return linear(z, p["ans_classifier.2.weight"], p["ans_classifier.2.bias"])
 
 
+def vis_pretext_loss(vf, vp, pooled, vis_masked_pos):
+    """modeling.py:1113-1131 (the Selfie-style pretext task of mask_image_regions, enable_butd=True): for every sample the masked
+    regions' projected box/class encodings (+ the pooled [CLS] output) are matched against the masked regions' projected features;
+    the loss is the mean over samples of the mean negative log-softmax on the diagonal of the [P, P] similarity matrix.
+    vf / vp are the UNMASKED projections (:1035-1036; masked_fill at :1054-1055 is out of place)."""
+    idx = (vis_masked_pos - 1).unsqueeze(-1)
+    masked_vis_feats = torch.gather(vf, 1, idx.expand(-1, -1, vf.size(-1)))                 # :1115-1116
+    masked_pos_enc = torch.gather(vp, 1, idx.expand(-1, -1, vp.size(-1)))                   # :1119-1120
+    masked_pos_enc = masked_pos_enc + pooled.unsqueeze(1).expand_as(masked_pos_enc)          # :1124
+    sim = torch.matmul(masked_pos_enc, masked_vis_feats.permute(0, 2, 1).contiguous())       # :1126
+    sim = F.log_softmax(sim, dim=-1)                                                          # :1127
+    per = [sim[i].diag().mean().view(1) * -1.0 for i in range(sim.size(0))]                   # :1128-1130
+    return torch.cat(per).mean()                                                               # :1131
+
+
 def forward_pretraining_loss_mask(p, batch, num_heads=12, len_vis_input=100, tasks="img2txt",
-                                  drop_worst_ratio=0.0, vqa_inference=False, capture=False):
-    """modeling.py:1033-1143 (BertForPreTrainingLossMask.forward; mask_image_regions off, dropout 0).
+                                  drop_worst_ratio=0.0, vqa_inference=False, capture=False, mask_image_regions=False):
+    """modeling.py:1033-1143 (BertForPreTrainingLossMask.forward; dropout 0).  mask_image_regions=True: the rows of the projected
+    region features / encodings named by batch.vis_masked_pos enter the encoder as zeros (:1049-1056) and the pretext loss
+    (:1113-1131) is returned in `vis_pretext_loss` (a 0-dim tensor then, as in the reference).
 
     Returns a dict: losses (`mlm_loss`, `vis_pretext_loss`, `vqa_loss` shaped like the reference's
     3-tuple) plus the parity capture points `mlm_logits` / `vqa_logits` / `hidden` (list)."""
@@ -278,7 +295,12 @@ def forward_pretraining_loss_mask(p, batch, num_heads=12, len_vis_input=100, tas
     vf = vis_embed(p, batch.img.to(dt))
     vp = vis_pe_embed(p, batch.vis_pe.to(dt))
     ext = extended_attention_mask(batch.input_mask, dt)
-    emb, emb_pre = embeddings(p, vf, vp, batch.input_ids, batch.segment_ids, len_vis_input)
+    if mask_image_regions and not vqa_inference:                   # :1049-1056 (the inference branch returns before it, :1039-1047)
+        keep = torch.ones(vf.shape[0], vf.shape[1], 1, dtype=torch.bool, device=vf.device)
+        keep.scatter_(1, (batch.vis_masked_pos - 1).unsqueeze(-1), False)
+        emb, emb_pre = embeddings(p, vf * keep, vp * keep, batch.input_ids, batch.segment_ids, len_vis_input)
+    else:
+        emb, emb_pre = embeddings(p, vf, vp, batch.input_ids, batch.segment_ids, len_vis_input)
     hs = encoder(p, emb, ext, num_heads)
     seq = hs[-1]
     if capture:
@@ -300,14 +322,18 @@ def forward_pretraining_loss_mask(p, batch, num_heads=12, len_vis_input=100, tas
         out["mlm_logits"] = logits
         ce = F.cross_entropy(logits.transpose(1, 2).float(), batch.lm_label_ids, reduction="none")   # :1108
         mlm_loss = loss_mask_and_normalize(ce.float(), batch.masked_weights, drop_worst_ratio)
-    vis_pretext_loss = zero1.clone()                               # :1133
+    if mask_image_regions:
+        out["pooled_output"] = pooler(p, seq)
+        pretext = vis_pretext_loss(vf, vp, out["pooled_output"], batch.vis_masked_pos)      # :1113-1131 (0-dim)
+    else:
+        pretext = zero1.clone()                                    # :1133
     if tasks == "vqa2":
         logits = vqa_head(p, seq, len_vis_input)
         out["vqa_logits"] = logits
         vqa_loss = F.binary_cross_entropy_with_logits(logits, batch.ans_labels.to(dt)) * batch.ans_labels.size(1)
-        out.update(mlm_loss=zero1.clone(), vis_pretext_loss=vis_pretext_loss, vqa_loss=vqa_loss)   # :1141
+        out.update(mlm_loss=zero1.clone(), vis_pretext_loss=pretext, vqa_loss=vqa_loss)   # :1141
     else:
-        out.update(mlm_loss=mlm_loss, vis_pretext_loss=vis_pretext_loss, vqa_loss=zero1.clone())  # :1143
+        out.update(mlm_loss=mlm_loss, vis_pretext_loss=pretext, vqa_loss=zero1.clone())  # :1143
     out["loss"] = out["mlm_loss"] + out["vis_pretext_loss"] + out["vqa_loss"]   # run_img2txt_dist.py:531
     return out
 

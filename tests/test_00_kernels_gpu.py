@@ -803,3 +803,97 @@ def test_bert_adam(g_is_f32, gen):
         runs.append((a, b, c, nn_[:len(sizes)].clone()))
     for r in runs[1:]:
         assert all(torch.equal(x, y) for x, y in zip(runs[0], r))
+
+
+# =====================================================================================================
+# mask_image_regions / vis_pretext_loss kernels (modeling.py:1049-1056, 1113-1131)
+# =====================================================================================================
+@pytest.mark.parametrize("B,Nv,Pm,H,p", [(3, 100, 25, 768, 0.0), (2, 100, 25, 768, 0.1), (2, 20, 5, 256, 0.1), (1, 100, 50, 768, 0.0)])
+def test_pretext_fwd_bwd(B, Nv, Pm, H, p, gen):
+    """vlp_pretext_fwd / vlp_pretext_bwd against the oracle's vis_pretext_loss under torch autograd (fp32 on the same fp16 inputs;
+    A = vispe + pooled and the similarity matrix are rounded to fp16 in both, as the reference's half tensors are).  With p > 0 the
+    gradient passes through the projections' ReLU + dropout exactly like vlp_embed_bwd does for the unmasked rows: checked against
+    the python mirror of the dropout hash; rows that are not masked must stay untouched."""
+    seed, s_vis, s_vpe = 77, 1001, 1002
+    vis = torch.relu(h16(B * Nv, H, scale=0.5, gen=gen))
+    vpe = torch.relu(h16(B * Nv, H, scale=0.5, gen=gen))
+    rows, cols = list(range(B * Nv)), list(range(H))
+    mv, mp = drop_mult_ref(p, seed, s_vis, rows, cols), drop_mult_ref(p, seed, s_vpe, rows, cols)
+    vis, vpe = (vis.float() * mv).half(), (vpe.float() * mp).half()                 # post-ReLU, post-dropout forward outputs
+    pooled = torch.tanh(h16(B, H, gen=gen).float()).half()
+    vmp = torch.stack([torch.randperm(Nv, generator=torch.Generator().manual_seed(10 + b))[:Pm] + 1 for b in range(B)]).to(DEV)
+    probs = torch.empty(B, Pm, Pm, device=DEV)
+    sample, loss = torch.empty(B, device=DEV), torch.empty(1, device=DEV)
+    K.pretext_fwd(vis, vpe, pooled, vmp, probs, sample, loss, B, Nv, Pm, H)
+    # reference: fp32 autograd over the same rounding points
+    v32 = vis.float().view(B, Nv, H).clone().requires_grad_(True)
+    e32 = vpe.float().view(B, Nv, H).clone().requires_grad_(True)
+    q32 = pooled.float().clone().requires_grad_(True)
+    idx = (vmp - 1).unsqueeze(-1).expand(-1, -1, H)
+    Vm, Em = torch.gather(v32, 1, idx), torch.gather(e32, 1, idx)
+    A = Em + q32.unsqueeze(1)
+    A = A + (A.half().float() - A).detach()                                         # fp16 rounding of the in-place add (:1124), straight-through
+    sim = A @ Vm.transpose(1, 2)
+    sim = sim + (sim.half().float() - sim).detach()                                 # the half matmul's output (:1126)
+    ls = torch.log_softmax(sim, dim=-1)
+    ref_loss = torch.stack([-ls[b].diag().mean() for b in range(B)]).mean()
+    assert abs(float(loss) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss)) + 1e-6
+    assert rel(probs, torch.softmax(sim, -1).detach()) < 1e-5
+    g = 4096.0
+    (ref_loss * g).backward()
+    d_vis = torch.full((B * Nv, H), 3.0, device=DEV, dtype=torch.half)
+    d_vpe = torch.full((B * Nv, H), 3.0, device=DEV, dtype=torch.half)
+    dpool = torch.empty(B, H, device=DEV, dtype=torch.half)
+    K.pretext_bwd(vis, vpe, pooled, vmp, probs, torch.full((1,), g, device=DEV), d_vis, d_vpe, dpool, B, Nv, Pm, H, drop_p=p, seed=seed,
+                  vis_stream=s_vis, vispe_stream=s_vpe)
+    masked = torch.zeros(B, Nv, dtype=torch.bool, device=DEV)
+    masked.scatter_(1, vmp - 1, True)
+    masked = masked.view(-1)
+    assert float((d_vis[~masked].float() - 3.0).abs().max()) == 0.0 and float((d_vpe[~masked].float() - 3.0).abs().max()) == 0.0
+    want_v = (v32.grad.view(B * Nv, H) * (vis.float() > 0) * mv)[masked]
+    want_e = (e32.grad.view(B * Nv, H) * (vpe.float() > 0) * mp)[masked]
+    assert rel(d_vis[masked].float(), want_v) < 2e-3                                # fp16 output rounding
+    assert rel(d_vpe[masked].float(), want_e) < 2e-3
+    want_pool = q32.grad * (1.0 - pooled.float() ** 2)
+    assert rel(dpool.float(), want_pool) < 2e-3
+    # bitwise reproducible
+    d2, e2, p2 = torch.empty_like(d_vis), torch.empty_like(d_vpe), torch.empty_like(dpool)
+    K.pretext_bwd(vis, vpe, pooled, vmp, probs, torch.full((1,), g, device=DEV), d2, e2, p2, B, Nv, Pm, H, drop_p=p, seed=seed,
+                  vis_stream=s_vis, vispe_stream=s_vpe)
+    assert torch.equal(d2[masked], d_vis[masked]) and torch.equal(e2[masked], d_vpe[masked]) and torch.equal(p2, dpool)
+    with pytest.raises(RuntimeError):
+        K.pretext_fwd(vis, vpe, pooled, vmp, probs, sample, loss, B, Nv, 65, H)       # more masked regions than a wave has lanes: refused
+
+
+def test_device_guard_multi_device_path():
+    """under torchrun every rank sees all 8 GPUs, so every launch goes through the multi-device branch of the entry
+    guard.  A 1-GPU box cannot switch devices, but it can run that branch: VLP_FAKE_DEVICE_COUNT=2 makes the guard resolve the owner of
+    every operand and compare it with hipGetDevice().  Checked in a child process (the count is read once): results are correct, the
+    driver is asked once per ALLOCATION and not once per launch (the owner cache), the caller's current device is what it was, and a
+    host pointer is still refused."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import ctypes, torch
+from vlp_amd import _lib as K
+dev = torch.device('cuda:0')
+x = torch.randn(256, 128, device=dev).half(); w = torch.randn(128, 128, device=dev).half(); y = torch.empty(256, 128, device=dev, dtype=torch.half)
+for _ in range(200):
+    K.gemm_nt(x, w, y, 256, 128, 128)
+torch.cuda.synchronize()
+assert float((y.float() - x.float() @ w.float().t()).abs().max()) < 0.25
+lk, q = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+K.load().vlp_debug_device_lookup_stats(ctypes.byref(lk), ctypes.byref(q))
+assert lk.value >= 200 and q.value <= 8, (lk.value, q.value)
+assert torch.cuda.current_device() == 0
+host = torch.zeros(256, 128, dtype=torch.half).pin_memory()
+a = K.GemmNtArgs(host.data_ptr(), 128, w.data_ptr(), 128, y.data_ptr(), 128, None, None, 0, None, 0, None, 0, 256, 128, 128, 0, 0, 1.0, 0.0, 0, 0, 0)
+rc = K.load().vlp_gemm_nt(ctypes.byref(a), None)
+assert rc != 0 and b'host memory' in K.load().vlp_last_error_string(), (rc, K.load().vlp_last_error_string())
+print('GUARD_OK', lk.value, q.value)
+"""
+    env = dict(os.environ, VLP_FAKE_DEVICE_COUNT="2")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=300)
+    assert "GUARD_OK" in r.stdout, r.stdout + r.stderr

@@ -51,18 +51,19 @@ def run_model(m, batch, drop_worst_ratio=0.0):
     b = S.batch_to(batch, DEV, half=True)
     losses = m(b.img, b.vis_pe, b.input_ids, b.segment_ids, b.input_mask, b.lm_label_ids, b.ans_labels, b.is_next,
                masked_pos=b.masked_pos, masked_weights=b.masked_weights, task_idx=b.task_idx, vis_masked_pos=b.vis_masked_pos,
-               mask_image_regions=False, drop_worst_ratio=drop_worst_ratio)
+               mask_image_regions=b.vis_masked_pos.numel() > 0, drop_worst_ratio=drop_worst_ratio)      # run_img2txt_dist.py:194: vis_mask_prob > 0
     return losses
 
 
 def oracle_on_device(p, batch, tasks, dtype, Nv=100, grads=False):
     pd = {k: v.to(DEV).to(dtype).clone().requires_grad_(grads) for k, v in p.items()}
     b = S.batch_to(batch, DEV)
+    mir = batch.vis_masked_pos.numel() > 0
     if grads:
-        out, g = O.loss_and_grads(pd, b, tasks=tasks, len_vis_input=Nv, capture=True)
+        out, g = O.loss_and_grads(pd, b, tasks=tasks, len_vis_input=Nv, capture=True, mask_image_regions=mir)
         return out, g
     with torch.no_grad():
-        return O.forward_pretraining_loss_mask(pd, b, tasks=tasks, len_vis_input=Nv, capture=True), None
+        return O.forward_pretraining_loss_mask(pd, b, tasks=tasks, len_vis_input=Nv, capture=True, mask_image_regions=mir), None
 
 
 @pytest.mark.parametrize("name", list(CASES.keys()))
@@ -94,6 +95,15 @@ def test_forward_backward_vs_reference_fixture(name):
     # losses: fp32 CE over fp16 logits
     lt = float(g["losses"].sum())
     assert abs(float(total.sum()) - lt) <= 2e-3 * abs(lt), (float(total.sum()), lt)
+    if "pooled_output" in g:       # vismask cases (modeling.py:1049-1056, 1113-1131): pooler output and the pretext loss on their own
+        pt = torch.from_numpy(g["pooled_output"])
+        yard_p = relmax(ref16["pooled_output"].float().cpu(), pt)
+        mine_p = relmax(m.last_pooled_output.float().cpu(), pt)
+        REPORT[name].update(pooled_err_vs_fp32_truth=mine_p, pooled_reference_fp16=yard_p, pretext_loss=float(losses[1]),
+                            pretext_loss_reference=float(g["losses"][1]), pretext_loss_reference_fp16=float(ref16["vis_pretext_loss"]))
+        assert mine_p <= yard_p + 1e-3, REPORT[name]
+        # the loss is a mean of 25 x B log-softmax terms over fp16 similarities of magnitude ~5: the reference's own fp16 run is the yardstick
+        assert abs(float(losses[1]) - float(g["losses"][1])) <= abs(float(ref16["vis_pretext_loss"]) - float(g["losses"][1])) + 2e-3 * float(g["losses"][1])
     # hidden states of the last layer (strided sample, same sampling as the fixture)
     nl = mk["layers"]
     eng = m.engine
@@ -144,7 +154,8 @@ def test_reference_fp16_self_spread(name):
     tasks = mk["tasks"]
     key = "vqa_logits" if tasks == "vqa2" else "mlm_logits"
     with torch.no_grad():
-        cpu16 = O.forward_pretraining_loss_mask({k: v.half() for k, v in p.items()}, S.batch_to(batch, torch.device("cpu")), tasks=tasks)[key].float()
+        cpu16 = O.forward_pretraining_loss_mask({k: v.half() for k, v in p.items()}, S.batch_to(batch, torch.device("cpu")), tasks=tasks,
+                                                mask_image_regions=mk.get("mask_image_regions", False))[key].float()
     gpu16, _ = oracle_on_device(p, batch, tasks, torch.float16)
     gpu16 = gpu16[key].float().cpu().reshape(cpu16.shape)
     m = build(p, mk).eval()

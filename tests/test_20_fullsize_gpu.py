@@ -107,7 +107,8 @@ def _build(p, tasks, layers=12):
 def _hip(m, batch, scale=None):
     b = S.batch_to(batch, DEV, half=True)
     losses = m(b.img, b.vis_pe, b.input_ids, b.segment_ids, b.input_mask, b.lm_label_ids, b.ans_labels, b.is_next, masked_pos=b.masked_pos,
-               masked_weights=b.masked_weights, task_idx=b.task_idx, vis_masked_pos=b.vis_masked_pos, mask_image_regions=False, drop_worst_ratio=0.0)
+               masked_weights=b.masked_weights, task_idx=b.task_idx, vis_masked_pos=b.vis_masked_pos,
+               mask_image_regions=b.vis_masked_pos.numel() > 0, drop_worst_ratio=0.0)
     if scale is not None:
         m.engine.zero_grad()
         ((losses[0] + losses[1] + losses[2]).sum() * scale).backward()
@@ -118,10 +119,11 @@ def _hip(m, batch, scale=None):
 def _oracle(p, batch, tasks, dtype, scale=None):
     pd = {k: v.to(DEV).to(dtype).clone().requires_grad_(scale is not None) for k, v in p.items()}
     b = S.batch_to(batch, DEV)
+    mir = batch.vis_masked_pos.numel() > 0
     if scale is None:
         with torch.no_grad():
-            return O.forward_pretraining_loss_mask(pd, b, tasks=tasks), None
-    out = O.forward_pretraining_loss_mask(pd, b, tasks=tasks)
+            return O.forward_pretraining_loss_mask(pd, b, tasks=tasks, mask_image_regions=mir), None
+    out = O.forward_pretraining_loss_mask(pd, b, tasks=tasks, mask_image_regions=mir)
     (out["loss"].sum().float() * scale).backward()
     grads = {k: (None if t.grad is None else t.grad.float() / scale) for k, t in pd.items()}
     return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}, grads
@@ -135,6 +137,9 @@ FULL_CASES = {
     # configs[4]: VQA 2.0 fine-tune, bidirectional, P = 1, answer-classifier head + BCE
     # (the BCE x 3129 loss of random labels is ~2 200: a x4 scale keeps loss x scale inside fp16 for the fp16 oracle)
     "vqa2": dict(tasks="vqa2", s2s_prob=0.0, max_pred=1, seed=103, gscale=4.0),
+    # the pre-training shape with --vis_mask_prob 0.25 (mask_image_regions): 25 masked region rows per sample enter as zeros, their
+    # mask columns are blocked, and the vis_pretext loss over the pooled output joins the sum (modeling.py:1049-1056, 1113-1131)
+    "cc_vismask": dict(tasks="img2txt", s2s_prob=0.75, max_pred=3, seed=104, gscale=4096.0, vis_mask_prob=0.25),
 }
 
 
@@ -143,7 +148,8 @@ def test_full_size_parity_vs_device_oracle(case):
     c = FULL_CASES[case]
     tasks, GSCALE = c["tasks"], c["gscale"]
     p = O.init_params(vocab_size=V, layers=12, tasks=tasks, seed=c["seed"])
-    batch = S.make_batch(B, max_len_b=64, vocab_size=V, max_pred=c["max_pred"], s2s_prob=c["s2s_prob"], tasks=tasks, seed=c["seed"] + 7)
+    batch = S.make_batch(B, max_len_b=64, vocab_size=V, max_pred=c["max_pred"], s2s_prob=c["s2s_prob"], tasks=tasks, seed=c["seed"] + 7,
+                         vis_mask_prob=c.get("vis_mask_prob", 0.0))
     assert batch.input_ids.shape == (B, 167)
     m = _build(p, tasks)
     losses = _hip(m, batch, scale=GSCALE)
@@ -161,6 +167,12 @@ def test_full_size_parity_vs_device_oracle(case):
     lt = float(truth["loss"].sum())
     lh = float((losses[0] + losses[1] + losses[2]).sum())
     rep.update(loss_fp32=lt, loss_hip=lh, loss_ref16=float(ref16["loss"].sum()))
+    if c.get("vis_mask_prob"):
+        rep.update(pretext_loss_fp32=float(truth["vis_pretext_loss"]), pretext_loss_hip=float(losses[1]), pretext_loss_ref16=float(ref16["vis_pretext_loss"]),
+                   pooled_hip_vs_fp32=_relmax(m.last_pooled_output.float(), truth["pooled_output"].float()),
+                   pooled_ref16_vs_fp32=_relmax(ref16["pooled_output"].float(), truth["pooled_output"].float()))
+        assert rep["pooled_hip_vs_fp32"] <= rep["pooled_ref16_vs_fp32"] + 1e-3, rep
+        assert abs(rep["pretext_loss_hip"] - rep["pretext_loss_fp32"]) <= abs(rep["pretext_loss_ref16"] - rep["pretext_loss_fp32"]) + 2e-3 * rep["pretext_loss_fp32"], rep
     # ---- gradients, element-wise, every tensor --------------------------------------------------------------------
     params = dict(m.named_parameters())
     unused = m.engine.unused_parameter_names()
@@ -205,7 +217,7 @@ def test_full_size_parity_vs_device_oracle(case):
     # below attributes the difference to rounding-point placement)
     assert rep["logits_hip_vs_ref16"] <= rep["logits_ref16_vs_ref16_other_summation_order"] + 1e-3, rep
     assert abs(lh - lt) <= 2e-3 * abs(lt), rep
-    assert n_checked >= (208 if tasks == "img2txt" else 206), n_checked
+    assert n_checked >= (208 if tasks == "img2txt" else 206) + (2 if c.get("vis_mask_prob") else 0), n_checked       # + the pooler
     for n, (rel_h, rel_r) in per_tensor.items():
         if n.endswith("attention.self.key.bias"):          # true value 0: bounded against the sibling query-bias gradient
             assert rel_h <= 5e-3, (n, rel_h, rel_r)         # measured <= 2.3e-3 of the query-bias gradient norm

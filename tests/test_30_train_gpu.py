@@ -173,6 +173,32 @@ def test_training_reduces_loss_and_checkpoint_round_trip(tmp_path):
     opt.load_state_dict(osd)
 
 
+def test_training_with_masked_regions_learns_the_pretext_task():
+    """--vis_mask_prob 0.25 through the train loop (run_img2txt_dist.py:194,482,531): the summed loss (MLM + vis_pretext) falls on a
+    repeated batch, the pretext loss itself falls (its gradient reaches the region projections and the pooler), the pooler's
+    parameters move (they are frozen without the branch), dropout 0.1 active, bitwise reproducible."""
+    def run():
+        model, _ = small_model(drop=0.1)
+        model.train()
+        opt = FP16_Optimizer_State(FusedAdam(groups_of(model), lr=2e-4, bias_correction=False, max_grad_norm=1.0), dynamic_loss_scale=True)
+        batch = S.batch_to(S.make_batch(8, max_len_b=20, vocab_size=1024, max_pred=3, seed=2, vis_mask_prob=0.25), DEV, half=True)
+        w0 = model.bert.pooler.dense.weight.detach().float().clone()
+        hist = []
+        for it in range(30):
+            lt = train_step(model, opt, batch, 2e-4, mask_image_regions=True)
+            hist.append((float(lt[0]), float(lt[1])))
+        assert lt[1].dim() == 0 and lt[0].dim() == 0 and tuple(lt[2].shape) == (1,)              # the reference's tuple shapes
+        return hist, w0, model
+    hist, w0, model = run()
+    assert all(a == a and b == b for a, b in hist)
+    assert sum(b for _, b in hist[-5:]) < 0.8 * sum(b for _, b in hist[:5]), hist                  # the pretext task is being learned
+    assert sum(a for a, _ in hist[-5:]) < 0.8 * sum(a for a, _ in hist[:5]), hist
+    assert float((model.bert.pooler.dense.weight.detach().float() - w0).abs().max()) > 0
+    assert "bert.pooler.dense.weight" not in model.engine.unused_parameter_names()
+    hist2, _, _ = run()
+    assert hist == hist2
+
+
 def test_pipelined_optimizer_step_is_bit_identical():
     """FP16_Optimizer_State.pipeline_with_forward: the update runs on the optimizer stream, chunked in the order the next forward reads
     the parameters, and the forward waits per chunk.  Same kernels, same arithmetic: losses of every step, parameters, Adam moments
@@ -319,6 +345,12 @@ def test_entry_script_synthetic(tmp_path):
     assert os.path.exists(os.path.join(out, "model.1.bin")) and os.path.exists(os.path.join(out, "opt.json"))
     sd = torch.load(os.path.join(out, "model.1.bin"))
     assert "bert.encoder.layer.1.output.LayerNorm.bias" in sd and sd["bert.embeddings.word_embeddings.weight"].shape == (28996, 768)
+    # --vis_mask_prob > 0 (mask_image_regions + vis_pretext_loss): the same entry point, pooler trained
+    out2 = os.path.join(tmp_path, "run_vm")
+    R.main(["--output_dir", out2, "--do_train", "--fp16", "--enable_butd", "--new_segment_ids", "--from_scratch", "--max_len_b", "20",
+            "--train_batch_size", "4", "--num_train_epochs", "1", "--synthetic", "3", "--num_hidden_layers", "2", "--len_vis_input", "100",
+            "--vis_mask_prob", "0.25"])
+    assert os.path.exists(os.path.join(out2, "model.1.bin"))
 
 
 @pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])

@@ -42,6 +42,32 @@ def test_mask_build_bit_exact(L):
     assert torch.equal(spec.dense(L), dense)
 
 
+def test_mask_build_with_masked_regions_bit_exact():
+    """--vis_mask_prob > 0: the loader blocks the masked regions' key columns on its dense mask (seq2seq_loader.py:303-304); on the
+    device vlp_region_mask_build + vlp_mask_build(region_mask) must produce exactly the packed form of that mask."""
+    L, Nv, B, Pm = 167, 100, 7, 25
+    rng = np.random.RandomState(5)
+    len_b = rng.randint(1, L - Nv - 3, size=B)
+    modes = ["s2s" if rng.rand() < 0.6 else "bi" for _ in range(B)]
+    vmp = torch.stack([torch.randperm(Nv, generator=torch.Generator().manual_seed(b))[:Pm] + 1 for b in range(B)])
+    dense = torch.from_numpy(np.stack([LO.attention_mask(Nv, int(nb), L, m) for nb, m in zip(len_b, modes)]))
+    for b in range(B):
+        dense[b][:, vmp[b]] = 0
+    dense = dense.to(DEV)
+    spec = MaskSpec.from_lengths(Nv, len_b.tolist(), [m == "s2s" for m in modes], device=DEV)
+    Lp = (L + 31) // 32 * 32
+    ref, ref_t = torch.empty(B, L, Lp, dtype=torch.uint8, device=DEV), torch.empty(B, Lp, Lp, dtype=torch.uint8, device=DEV)
+    K.mask_pack(dense, ref, B, L, Lp, out_t=ref_t)
+    rmask = torch.full((B * Nv,), 9, dtype=torch.uint8, device=DEV)
+    K.region_mask_build(vmp.to(DEV), rmask, B, Pm, Nv)
+    want = torch.zeros(B, Nv, dtype=torch.uint8)
+    want.scatter_(1, vmp - 1, 1)
+    assert torch.equal(rmask.cpu().view(B, Nv), want)
+    out, out_t = torch.full_like(ref, 9), torch.full_like(ref_t, 9)
+    K.mask_build(spec.second_st, spec.second_end, spec.is_s2s, out, B, L, Lp, out_t=out_t, region_mask=rmask, Nv=Nv)
+    assert torch.equal(out, ref) and torch.equal(out_t, ref_t)
+
+
 @pytest.mark.parametrize("name", list(LOADER_CASES.keys()))
 @pytest.mark.parametrize("cls_f32", [False, True])
 def test_vis_pe_prep_vs_reference_fixture(name, cls_f32):

@@ -44,6 +44,37 @@ def test_forward_backward_vs_reference(tasks, drop_worst):
             assert float((q.grad - grads[n]).norm()) <= 1e-4 * float(q.grad.norm()) + 1e-6 * gscale, n
 
 
+@pytest.mark.parametrize("tasks", ["img2txt", "vqa2"])
+def test_mask_image_regions_pretext_branch_vs_reference(tasks, monkeypatch):
+    """--vis_mask_prob > 0: masked region rows enter the encoder as zeros (modeling.py:1049-1056) and the Selfie-style pretext loss
+    over the pooled output (:1113-1131) is the second element of the loss tuple.  The reference builds its row mask with .byte()
+    (:1050), which torch >= 1.2 no longer accepts in masked_fill: patched to .bool() (a torch-version shim of the same kind as the
+    beam-search ones below; the reference file itself is untouched).  Losses, logits and EVERY gradient -- including the pooler's,
+    which only this branch uses -- are compared."""
+    monkeypatch.setattr(torch.Tensor, "byte", lambda self: self.bool())
+    model = ref_loader.build_reference_model(dict(vocab_size=1024, num_hidden_layers=2), tasks=tasks, seed=13).eval()
+    b = S.make_batch(4, max_len_b=20, vocab_size=1024, tasks=tasks, s2s_prob=0.5, seed=15, max_pred=3 if tasks == "img2txt" else 1,
+                     vis_mask_prob=0.25)
+    assert b.vis_masked_pos.shape == (4, 25)
+    losses = model(b.img, b.vis_pe, b.input_ids, b.segment_ids, b.input_mask, b.lm_label_ids, b.ans_labels,
+                   b.is_next, masked_pos=b.masked_pos, masked_weights=b.masked_weights, task_idx=b.task_idx,
+                   vis_masked_pos=b.vis_masked_pos, mask_image_regions=True, drop_worst_ratio=0)
+    (losses[0] + losses[1] + losses[2]).sum().backward()
+    p = O.params_from_state_dict(model.state_dict(), requires_grad=True)
+    out, grads = O.loss_and_grads(p, b, tasks=tasks, drop_worst_ratio=0.0, mask_image_regions=True)
+    assert float(losses[1]) > 0.5          # ~ ln 25 for an untrained model
+    for ref_l, k in zip(losses, ("mlm_loss", "vis_pretext_loss", "vqa_loss")):
+        assert tuple(ref_l.shape) == tuple(out[k].shape), k
+        assert float(ref_l.sum()) == pytest.approx(float(out[k].sum()), rel=1e-5, abs=1e-6)
+    gscale = max(float(q.grad.norm()) for _, q in model.named_parameters() if q.grad is not None)
+    assert model.bert.pooler.dense.weight.grad is not None and float(model.bert.pooler.dense.weight.grad.abs().max()) > 0
+    for n, q in model.named_parameters():
+        if q.grad is None:
+            assert grads[n] is None or float(grads[n].abs().max()) == 0.0, n
+        else:
+            assert float((q.grad - grads[n]).norm()) <= 1e-4 * float(q.grad.norm()) + 1e-6 * gscale, n
+
+
 def test_vqa_inference_vs_reference():
     model = ref_loader.build_reference_model(dict(vocab_size=1024, num_hidden_layers=2), tasks="vqa2", seed=4).eval()
     b = S.make_batch(3, max_len_b=20, vocab_size=1024, tasks="vqa2", seed=6, max_pred=1)

@@ -70,7 +70,7 @@ class EmbedFwdArgs(C.Structure):
     _fields_ = [("input_ids", vp), ("segment_ids", vp), ("word_emb", vp), ("pos_emb", vp), ("type_emb", vp),
                 ("vis_h", vp), ("vispe_h", vp), ("pre", vp),
                 ("B", i32), ("L", i32), ("Nv", i32), ("H", i32), ("vocab", i32), ("type_vocab", i32),
-                ("position_ids", vp), ("max_pos", i32)]
+                ("position_ids", vp), ("max_pos", i32), ("region_mask", vp)]
 
 
 class AttnDecodeArgs(C.Structure):
@@ -94,6 +94,17 @@ class EmbedBwdArgs(C.Structure):
     _fields_ = [("dpre", vp), ("input_ids", vp), ("segment_ids", vp), ("vis_h", vp), ("vispe_h", vp),
                 ("d_word_emb", vp), ("d_pos_emb", vp), ("d_type_emb", vp), ("d_vis_h", vp), ("d_vispe_h", vp), ("acc32", vp),
                 ("B", i32), ("L", i32), ("Nv", i32), ("H", i32), ("vocab", i32), ("type_vocab", i32),
+                ("drop_p", f32), ("seed", u64), ("vis_stream", u32), ("vispe_stream", u32), ("region_mask", vp)]
+
+
+class PretextFwdArgs(C.Structure):
+    _fields_ = [("vis_h", vp), ("vispe_h", vp), ("pooled", vp), ("vis_masked_pos", vp), ("probs", vp), ("sample_loss", vp), ("loss", vp),
+                ("B", i32), ("Nv", i32), ("Pm", i32), ("H", i32)]
+
+
+class PretextBwdArgs(C.Structure):
+    _fields_ = [("vis_h", vp), ("vispe_h", vp), ("pooled", vp), ("vis_masked_pos", vp), ("probs", vp), ("gscale", vp),
+                ("d_vis_h", vp), ("d_vispe_h", vp), ("d_pooled_pre", vp), ("B", i32), ("Nv", i32), ("Pm", i32), ("H", i32),
                 ("drop_p", f32), ("seed", u64), ("vis_stream", u32), ("vispe_stream", u32)]
 
 
@@ -145,7 +156,7 @@ SYMBOLS = {
     "vlp_beam_select": (C.c_int, [C.POINTER(BeamSelectArgs), vp]),
     "vlp_kv_gather": (C.c_int, [vp, i64, vp, i64, vp, i32, i32, i32, i32, vp]),
     "vlp_embed_bwd_workspace_floats": (C.c_int64, [i32, i32, i32, i32]),
-    "vlp_mask_build": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "vlp_mask_build": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp, i32, vp]),
     "vlp_vis_pe_prep": (C.c_int, [C.POINTER(VisPePrepArgs), vp]),
     "vlp_sample_rows": (C.c_int, [vp, i64, i32, i32, C.c_uint64, C.c_uint32, vp, i64, vp, i64, vp]),
     "vlp_argmax_rows": (C.c_int, [vp, i64, i32, i32, vp, i64, vp, i64, vp]),
@@ -156,6 +167,9 @@ SYMBOLS = {
     "vlp_layernorm_bwd_reduce_batched": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "vlp_embed_fwd": (C.c_int, [C.POINTER(EmbedFwdArgs), vp]),
     "vlp_embed_bwd": (C.c_int, [C.POINTER(EmbedBwdArgs), vp]),
+    "vlp_region_mask_build": (C.c_int, [vp, i32, i32, i32, vp, vp]),
+    "vlp_pretext_fwd": (C.c_int, [C.POINTER(PretextFwdArgs), vp]),
+    "vlp_pretext_bwd": (C.c_int, [C.POINTER(PretextBwdArgs), vp]),
     "vlp_copy2d": (C.c_int, [vp, i64, i32, vp, i64, i32, i32, i32, i32, vp]),
     "vlp_transpose": (C.c_int, [vp, i64, vp, i64, i32, i32, i32, vp]),
     "vlp_transpose_batched": (C.c_int, [vp, vp, i32, i32, vp]),
@@ -396,12 +410,12 @@ def kv_gather(src, src_rows, dst, dst_rows, idx, R, lo, hi, row_elems):
     _check(load().vlp_kv_gather(ptr(src), src_rows, ptr(dst), dst_rows, ptr(idx), R, lo, hi, row_elems, stream_ptr()))
 
 
-def mask_build(second_st, second_end, is_s2s, out_u8, B, L, Lp, out_t=None):
-    """second_st / second_end / is_s2s: int32 [B] device tensors."""
-    _req_cuda(second_st, second_end, is_s2s, out_u8, out_t)
+def mask_build(second_st, second_end, is_s2s, out_u8, B, L, Lp, out_t=None, region_mask=None, Nv=0):
+    """second_st / second_end / is_s2s: int32 [B] device tensors; region_mask: u8 [B*Nv] (region_mask_build) -> those key columns are blocked."""
+    _req_cuda(second_st, second_end, is_s2s, out_u8, out_t, region_mask)
     for t in (second_st, second_end, is_s2s):
         assert t.dtype == torch.int32 and t.is_contiguous() and t.numel() == B
-    _check(load().vlp_mask_build(ptr(second_st), ptr(second_end), ptr(is_s2s), ptr(out_u8), ptr(out_t), B, L, Lp, stream_ptr()))
+    _check(load().vlp_mask_build(ptr(second_st), ptr(second_end), ptr(is_s2s), ptr(out_u8), ptr(out_t), B, L, Lp, ptr(region_mask), Nv, stream_ptr()))
 
 
 def vis_pe_prep(bbox, cls, out, B, Nv, n_cls, pad_to, eps=1e-5):
@@ -452,10 +466,10 @@ def layernorm_bwd_reduce_batched(parts, dst_table, count, M, H, beta=0):
     _check(load().vlp_layernorm_bwd_reduce_batched(ptr(parts), ptr(dst_table), count, M, H, beta, stream_ptr()))
 
 
-def embed_fwd(input_ids, segment_ids, word_emb, pos_emb, type_emb, vis_h, vispe_h, pre, B, L, Nv, H, position_ids=None):
-    _req_cuda(input_ids, segment_ids, word_emb, pos_emb, type_emb, pre, position_ids)
+def embed_fwd(input_ids, segment_ids, word_emb, pos_emb, type_emb, vis_h, vispe_h, pre, B, L, Nv, H, position_ids=None, region_mask=None):
+    _req_cuda(input_ids, segment_ids, word_emb, pos_emb, type_emb, pre, position_ids, region_mask)
     a = EmbedFwdArgs(ptr(input_ids), ptr(segment_ids), ptr(word_emb), ptr(pos_emb), ptr(type_emb), ptr(vis_h), ptr(vispe_h),
-                     ptr(pre), B, L, Nv, H, word_emb.shape[0], type_emb.shape[0], ptr(position_ids), pos_emb.shape[0])
+                     ptr(pre), B, L, Nv, H, word_emb.shape[0], type_emb.shape[0], ptr(position_ids), pos_emb.shape[0], ptr(region_mask))
     _check(load().vlp_embed_fwd(C.byref(a), stream_ptr()))
 
 
@@ -464,11 +478,32 @@ def embed_bwd_workspace_floats(B, L, Nv, H):
 
 
 def embed_bwd(dpre, input_ids, segment_ids, vis_h, vispe_h, d_word, d_pos, d_type, d_vis_h, d_vispe_h, acc32,
-              B, L, Nv, H, vocab, type_vocab, drop_p=0.0, seed=0, vis_stream=0, vispe_stream=0):
-    _req_cuda(dpre, input_ids, segment_ids, d_word, d_pos, d_type, acc32)
+              B, L, Nv, H, vocab, type_vocab, drop_p=0.0, seed=0, vis_stream=0, vispe_stream=0, region_mask=None):
+    _req_cuda(dpre, input_ids, segment_ids, d_word, d_pos, d_type, acc32, region_mask)
     a = EmbedBwdArgs(ptr(dpre), ptr(input_ids), ptr(segment_ids), ptr(vis_h), ptr(vispe_h), ptr(d_word), ptr(d_pos), ptr(d_type),
-                     ptr(d_vis_h), ptr(d_vispe_h), ptr(acc32), B, L, Nv, H, vocab, type_vocab, drop_p, seed, vis_stream, vispe_stream)
+                     ptr(d_vis_h), ptr(d_vispe_h), ptr(acc32), B, L, Nv, H, vocab, type_vocab, drop_p, seed, vis_stream, vispe_stream,
+                     ptr(region_mask))
     _check(load().vlp_embed_bwd(C.byref(a), stream_ptr()))
+
+
+def region_mask_build(vis_masked_pos, out, B, Pm, Nv):
+    """vis_masked_pos i64 [B, Pm] (1..Nv) -> out u8 [B*Nv], 1 on masked region rows (seq2seq_loader.py:267-269)."""
+    _req_cuda(vis_masked_pos, out)
+    _check(load().vlp_region_mask_build(ptr(vis_masked_pos), B, Pm, Nv, ptr(out), stream_ptr()))
+
+
+def pretext_fwd(vis_h, vispe_h, pooled, vis_masked_pos, probs, sample_loss, loss, B, Nv, Pm, H):
+    _req_cuda(vis_h, vispe_h, pooled, vis_masked_pos, probs, sample_loss, loss)
+    a = PretextFwdArgs(ptr(vis_h), ptr(vispe_h), ptr(pooled), ptr(vis_masked_pos), ptr(probs), ptr(sample_loss), ptr(loss), B, Nv, Pm, H)
+    _check(load().vlp_pretext_fwd(C.byref(a), stream_ptr()))
+
+
+def pretext_bwd(vis_h, vispe_h, pooled, vis_masked_pos, probs, gscale, d_vis_h, d_vispe_h, d_pooled_pre, B, Nv, Pm, H,
+                drop_p=0.0, seed=0, vis_stream=0, vispe_stream=0):
+    _req_cuda(vis_h, vispe_h, pooled, vis_masked_pos, probs, gscale, d_vis_h, d_vispe_h, d_pooled_pre)
+    a = PretextBwdArgs(ptr(vis_h), ptr(vispe_h), ptr(pooled), ptr(vis_masked_pos), ptr(probs), ptr(gscale), ptr(d_vis_h), ptr(d_vispe_h),
+                       ptr(d_pooled_pre), B, Nv, Pm, H, drop_p, seed, vis_stream, vispe_stream)
+    _check(load().vlp_pretext_bwd(C.byref(a), stream_ptr()))
 
 
 def copy2d(src, lds, src_f32, dst, ldd, rows, cols_src, cols_dst, beta=0):

@@ -776,7 +776,9 @@ extern "C" int vlp_mask_pack_rect(const int64_t* mask, int64_t batch_stride, int
 //   s2s[b] != 0:  attend(q, k) = k < st[b]  ||  (st[b] <= q < en[b]  &&  st[b] <= k <= q)
 //   else (bi):    attend(q, k) = k < en[b]
 // same byte format as mask_pack (1 attend, 0 masked, 2 = padding column / row of the key-major copy)
-__global__ void mask_build_kernel(const int32_t* st, const int32_t* en, const int32_t* s2s, uint8_t* out, uint8_t* out_t, int L, int Lp, int B) {
+// region_mask (optional, [B*Nv] bytes): key columns 1..Nv of masked regions are blocked for every query (seq2seq_loader.py:303-304)
+__global__ void mask_build_kernel(const int32_t* st, const int32_t* en, const int32_t* s2s, uint8_t* out, uint8_t* out_t, int L, int Lp, int B,
+                                  const uint8_t* region_mask, int Nv) {
     const int64_t n1 = (int64_t)B * L * Lp, n2 = out_t ? (int64_t)B * Lp * Lp : 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (int64_t)gridDim.x * blockDim.x) {
         int q, k;
@@ -798,19 +800,21 @@ __global__ void mask_build_kernel(const int32_t* st, const int32_t* en, const in
         if (q < L && k < L) {
             const int s = st[b], e = en[b];
             v = s2s[b] ? ((k < s || (q >= s && q < e && k >= s && k <= q)) ? 1 : 0) : (k < e ? 1 : 0);
+            if (region_mask && k >= 1 && k <= Nv && region_mask[b * Nv + (k - 1)]) v = 0;
         }
         *dst = v;
     }
 }
 extern "C" int vlp_mask_build(const int32_t* second_st, const int32_t* second_end, const int32_t* is_s2s, uint8_t* out, uint8_t* out_t, int32_t B,
-                              int32_t L, int32_t Lp, void* stream) {
+                              int32_t L, int32_t Lp, const uint8_t* region_mask, int32_t Nv, void* stream) {
     VLP_CHECK_ARG(second_st && second_end && is_s2s && out && B > 0 && L > 0, "vlp_mask_build: bad args");
     VLP_ENTER(second_st, "vlp_mask_build");
     VLP_CHECK_ARG(Lp == (L + 31) / 32 * 32, "vlp_mask_build: Lp must be roundup32(L)");
+    VLP_CHECK_ARG(region_mask == nullptr || (Nv > 0 && Nv < L), "vlp_mask_build: region_mask needs 0 < Nv < L");
     const int64_t total = (int64_t)B * L * Lp + (out_t ? (int64_t)B * Lp * Lp : 0);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(mask_build_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, second_st, second_end, is_s2s, out, out_t, L, Lp, B);
+    hipLaunchKernelGGL(mask_build_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, second_st, second_end, is_s2s, out, out_t, L, Lp, B, region_mask, Nv);
     VLP_CHECK_LAUNCH("vlp_mask_build");
     return VLP_OK;
 }

@@ -22,8 +22,13 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(vlp_embed_fwd_args a) {
         f16x8 w, p;
         if (l >= 1 && l <= a.Nv) {
             const int64_t vr = (int64_t)b * a.Nv + (l - 1);
-            w = ld8(vis + vr * a.H + c * 8);
-            p = ld8(vpe + vr * a.H + c * 8);
+            if (a.region_mask && a.region_mask[vr]) {          // masked region: zeros in the word and the position stream (modeling.py:1054-1055)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { w[e] = (f16)0.f; p[e] = (f16)0.f; }
+            } else {
+                w = ld8(vis + vr * a.H + c * 8);
+                p = ld8(vpe + vr * a.H + c * 8);
+            }
         } else {
             int64_t id = a.input_ids[row];
             id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
@@ -71,6 +76,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(vlp_embed_bwd_args a, Dr
         const f16x8 d = ld8(dpre + row * a.H + c * 8);
         if (l >= 1 && l <= a.Nv) {
             const int64_t vr = (int64_t)b * a.Nv + (l - 1);
+            if (a.region_mask && a.region_mask[vr]) continue;  // a masked region fed zeros into the encoder: its rows belong to vlp_pretext_bwd
             const f16x8 yv = ld8((const f16*)a.vis_h + vr * a.H + c * 8);
             const f16x8 yp = ld8((const f16*)a.vispe_h + vr * a.H + c * 8);
             f16x8 ov, op;

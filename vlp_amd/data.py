@@ -160,8 +160,12 @@ class BatchPrefetcher(object):
     is prepared ahead on a worker thread: host buffers are pinned and the H2D copies run on their own stream, so they overlap the
     training step; the consumer's stream waits on the copy event only."""
 
-    def __init__(self, store, examples, batch_size, proc_s2s, proc_bi=None, s2s_prob=1.0, device=None, steps=None, depth=2, seed=0):
+    def __init__(self, store, examples, batch_size, proc_s2s, proc_bi=None, s2s_prob=1.0, device=None, steps=None, depth=2, seed=0,
+                 vis_mask_prob=0.0):
         self.store, self.examples, self.B = store, examples, batch_size
+        # --vis_mask_prob > 0 (mask_image_regions): int(Nv * prob) distinct region positions per sample (seq2seq_loader.py:267-269); the
+        # engine blocks their mask columns itself (vlp_mask_build region_mask, :303-304)
+        self.n_vis_masked = int(store.nv * vis_mask_prob)
         self.procs, self.weights = [proc_s2s, proc_bi or proc_s2s], [s2s_prob, 1.0 - s2s_prob]
         self.device = torch.device(device) if device is not None else torch.device("cuda")
         self.steps = steps if steps is not None else len(examples) // batch_size
@@ -175,6 +179,8 @@ class BatchPrefetcher(object):
         pin = lambda *s, dt: torch.empty(*s, dtype=dt).pin_memory()                                  # noqa: E731
         host = {"feat": pin(B, Nv, FEAT_DIM, dt=torch.float16), "cls": pin(B, Nv, N_CLS, dt=torch.float16), "bbox": pin(B, Nv, BOX_DIM, dt=torch.float32),
                 "ids": pin(2, B, L, dt=torch.long), "pred": pin(3, B, P, dt=torch.long), "spec": pin(3, B, dt=torch.int32), "task": pin(B, dt=torch.long)}
+        if self.n_vis_masked:
+            host["vmp"] = pin(B, self.n_vis_masked, dt=torch.long)
         dev = {k: torch.empty_like(v, device=self.device) for k, v in host.items()}
         return host, dev, torch.cuda.Event()
 
@@ -196,6 +202,8 @@ class BatchPrefetcher(object):
             host["pred"][2, j] = torch.tensor(t["masked_weights"])
             host["spec"][0, j], host["spec"][1, j], host["spec"][2, j] = t["len_a"] + 2, t["len_a"] + t["len_b"] + 3, int(t["is_s2s"])
             host["task"][j] = t["task_idx"]
+            if self.n_vis_masked:
+                host["vmp"][j] = torch.tensor(random.sample(range(1, self.Nv + 1), self.n_vis_masked))      # +1 for [CLS] (:269)
         with torch.cuda.stream(self._copy_stream):
             for k in host:
                 dev[k].copy_(host[k], non_blocking=True)
@@ -208,7 +216,7 @@ class BatchPrefetcher(object):
         spec = MaskSpec(d["spec"][0], d["spec"][1], d["spec"][2])
         raw = RawRegions(d["bbox"], d["cls"])
         is_next = torch.full((B,), -1, dtype=torch.long, device=self.device)
-        vis_masked_pos = torch.zeros(B, 0, dtype=torch.long, device=self.device)
+        vis_masked_pos = d["vmp"] if self.n_vis_masked else torch.zeros(B, 0, dtype=torch.long, device=self.device)
         ans = torch.zeros(B, 1, dtype=torch.float16, device=self.device)
         # (input_ids, segment_ids, input_mask, lm_label_ids, masked_pos, masked_weights, is_next, task_idx, img, vis_masked_pos, vis_pe, ans)
         return (d["ids"][0], d["ids"][1], spec, d["pred"][0], d["pred"][1], d["pred"][2], is_next, d["task"], d["feat"], vis_masked_pos, raw, ans)

@@ -42,7 +42,7 @@ def is_no_decay(name):
 
 class _State(object):
     """What one forward leaves behind for its backward."""
-    __slots__ = ("gen", "B", "L", "P", "seed", "p_drop", "ws", "batch", "task", "has_mlm", "task_labels")
+    __slots__ = ("gen", "B", "L", "P", "seed", "p_drop", "ws", "batch", "task", "has_mlm", "task_labels", "pretext")
 
 
 class Engine(object):
@@ -209,6 +209,10 @@ class Engine(object):
         return self._params[name].grad
 
     def unused_parameter_names(self):
+        """Parameters that receive no gradient (static per task).  The pooler is used by the vis_pretext branch only:
+        it leaves the set while the latest forward ran with mask_image_regions."""
+        if getattr(self, "_pretext_on", False):
+            return set(self._unused) - {"bert.pooler.dense.weight", "bert.pooler.dense.bias"}
         return set(self._unused)
 
     # ------------------------------------------------------------------------------------------
@@ -472,8 +476,24 @@ class Engine(object):
         else:
             K.gemm_nt_splitk(x, w, y, M, N, Kd, ch[1], skws, **kw)
 
-    def forward(self, vis_feats, vis_pe, input_ids, token_type_ids, attention_mask, masked_pos, train, want_mlm, want_vqa):
-        """Runs embeddings + encoder (+ heads' forward up to the logits).  Returns the _State."""
+    def _pretext_workspace(self, ws, B, Pm):
+        """Buffers of the mask_image_regions / vis_pretext branch (modeling.py:1049-1056, 1113-1131), created on first use."""
+        key = ("pt", Pm)
+        if key not in ws:
+            model = self._model()
+            H, Nv, dev = model.config.hidden_size, model.len_vis_input, self.device
+            ws[key] = dict(rmask=torch.empty(B * Nv, device=dev, dtype=torch.uint8), pos0=torch.zeros(B, 1, device=dev, dtype=torch.long),
+                           sel0=torch.empty(B, H, device=dev, dtype=torch.float16), pooled=torch.empty(B, H, device=dev, dtype=torch.float16),
+                           probs=torch.empty(B, Pm, Pm, device=dev, dtype=torch.float32), sample=torch.empty(B, device=dev, dtype=torch.float32),
+                           loss=torch.empty(1, device=dev, dtype=torch.float32), dpool=torch.empty(B, H, device=dev, dtype=torch.float16),
+                           dsel0=torch.empty(B, H, device=dev, dtype=torch.float16), pT=torch.empty(H, H, device=dev, dtype=torch.float16))
+        return ws[key]
+
+    def forward(self, vis_feats, vis_pe, input_ids, token_type_ids, attention_mask, masked_pos, train, want_mlm, want_vqa,
+                vis_masked_pos=None):
+        """Runs embeddings + encoder (+ heads' forward up to the logits).  Returns the _State.  vis_masked_pos ([B, Pm] int64, values
+        1..Nv): the mask_image_regions branch -- those region rows enter the encoder as zeros and the pooled output is computed
+        for the pretext loss (pretext_loss())."""
         self.pack()
         model = self._model()
         cfg = model.config
@@ -517,9 +537,19 @@ class Engine(object):
                 self._shadow_ev.record(self._side)
         # ---- inputs -----------------------------------------------------------------------------
         want_t = ws["maskt"] if train or torch.is_grad_enabled() else None
+        pt = None
+        if vis_masked_pos is not None and vis_masked_pos.numel() > 0:
+            Pm = vis_masked_pos.shape[1]
+            pt = self._pretext_workspace(ws, B, Pm)
+            st_vmp = vis_masked_pos.to(torch.long).contiguous()
+            K.region_mask_build(st_vmp, pt["rmask"], B, Pm, Nv)
+        self._pretext_on = pt is not None
+        st.pretext = (pt, st_vmp) if pt is not None else None
         if mask_spec:                       # per-sample lengths -> packed masks on the device (seq2seq_loader.py:292-301)
             attention_mask.check(B, L)
-            K.mask_build(attention_mask.second_st, attention_mask.second_end, attention_mask.is_s2s, ws["maskb"], B, L, ws["Lp"], out_t=want_t)
+            # (with mask_image_regions the masked regions' key columns are blocked here, as the loader does on its dense mask, :303-304)
+            K.mask_build(attention_mask.second_st, attention_mask.second_end, attention_mask.is_s2s, ws["maskb"], B, L, ws["Lp"], out_t=want_t,
+                         region_mask=pt["rmask"] if pt is not None else None, Nv=Nv)
         else:
             if attention_mask is None:
                 attention_mask = torch.ones(B, L, dtype=torch.long, device=input_ids.device)
@@ -556,7 +586,8 @@ class Engine(object):
         # ---- embeddings (modeling.py:217-241) ------------------------------------------------------
         E = "bert.embeddings."
         K.embed_fwd(st.batch[1], st.batch[2], self.P(E + "word_embeddings.weight"), self.P(E + "position_embeddings.weight"),
-                    self.P(E + "token_type_embeddings.weight"), ws["vis_h"], ws["vispe_h"], ws["emb_pre"], B, L, Nv, H)
+                    self.P(E + "token_type_embeddings.weight"), ws["vis_h"], ws["vispe_h"], ws["emb_pre"], B, L, Nv, H,
+                    region_mask=pt["rmask"] if pt is not None else None)
         K.layernorm_fwd(ws["emb_pre"], self.P(E + "LayerNorm.weight"), self.P(E + "LayerNorm.bias"), ws["x0"], M, H, ws["stat0"][0], ws["stat0"][1],
                         dropout_p=p, seed=seed, rng_stream=1000)
         # ---- encoder (modeling.py:268-372) -----------------------------------------------------------
@@ -598,7 +629,19 @@ class Engine(object):
             K.vqa_mul_fwd(x, ws["vq_e"], B, L, Nv, H)
             self._nt(ws["vq_e"], self.P("ans_classifier.0.weight"), ws["vq_a1"], B, 2 * H, H, bias=self.P("ans_classifier.0.bias"), act=K.ACT_RELU)
             self._nt(ws["vq_a1"], self.P("ans_classifier.2.weight"), ws["vq_logits"], B, NA, 2 * H, bias=self.P("ans_classifier.2.bias"), ldy=ws["NAp"])
+        if pt is not None:
+            # BertPooler (modeling.py:411-417) -- only this branch reads it -- and the pretext loss (:1113-1131)
+            K.gather_rows(x, H, pt["pos0"], pt["sel0"], H, B, 1, L, H)
+            self._nt(pt["sel0"], self.P("bert.pooler.dense.weight"), pt["pooled"], B, H, H, bias=self.P("bert.pooler.dense.bias"), act=K.ACT_TANH)
+            K.pretext_fwd(ws["vis_h"], ws["vispe_h"], pt["pooled"], st_vmp, pt["probs"], pt["sample"], pt["loss"], B, Nv, st_vmp.shape[1], H)
         return st
+
+    def pretext_loss(self, st):
+        """[1] f32 view holding the vis_pretext_loss of this forward (modeling.py:1131)."""
+        return st.pretext[0]["loss"]
+
+    def pooled_output(self, st):
+        return st.pretext[0]["pooled"]
 
     def mlm_loss(self, st, labels, weights, drop_worst_ratio):
         """modeling.py:1083-1111 on the logits of this forward; returns a [1] f32 view holding the loss."""
@@ -964,9 +1007,9 @@ class Engine(object):
         if self.grad_ready_hook is not None:
             self.grad_ready_hook(idx)
 
-    def backward(self, st, gscale, task):
-        """gscale: device f32 tensor [1] = upstream gradient of the loss (x loss scale).  Writes every
-        parameter gradient into the flat gradient buffers."""
+    def backward(self, st, gscale, task, g_pretext=None):
+        """gscale: device f32 tensor [1] = upstream gradient of the task loss (x loss scale); g_pretext: the same for the pretext loss of
+        a mask_image_regions forward.  Writes every parameter gradient into the flat gradient buffers."""
         if st.gen != self.gen:
             raise RuntimeError("vlp_amd: the activations of this forward were overwritten by a later forward "
                                "(one in-flight forward per model; run backward before the next forward)")
@@ -1005,6 +1048,11 @@ class Engine(object):
             K.vqa_mul_bwd(x_last, ws["vq_de"], dx, B, L, Nv, H)
             if beta == 0:
                 self.G(E + "word_embeddings.weight").zero_()     # no tied-decoder wgrad in this task: scatter needs zeros
+        elif not st.has_mlm:
+            if beta == 0:                                        # empty masked_pos (modeling.py:1096-1098): only the pretext loss is live
+                self.G(E + "word_embeddings.weight").zero_()
+                for n in ("bias", "transform.dense.weight", "transform.dense.bias", "transform.LayerNorm.weight", "transform.LayerNorm.bias"):
+                    self.G("cls.predictions." + n).zero_()
         else:
             C = "cls.predictions."
             R, Vp = B * P, ws["Vp"]
@@ -1023,6 +1071,23 @@ class Engine(object):
             self._tn(ws["dtz"], ws["sel"], self.G(C + "transform.dense.weight"), R, H, H, ws, beta, bias=self.G(C + "transform.dense.bias"))
             self._nt(ws["dtz"], sh["tT"], ws["dsel"], R, H, H)
             K.scatter_add_rows(ws["dsel"], H, masked_pos.contiguous(), dx, H, B, P, L, H)
+        pt = st.pretext
+        if pt is not None:
+            # vis_pretext_loss backward (modeling.py:1113-1131): masked rows of d_vis_h / d_vispe_h (embed_bwd below leaves them alone),
+            # then the pooler: tanh' is applied by the kernel, dW = d^T . h[:, 0], dh[:, 0] += d . W
+            ptw, vmp = pt
+            if g_pretext is None:
+                g_pretext = torch.zeros(1, device=self.device, dtype=torch.float32)
+            K.pretext_bwd(ws["vis_h"], ws["vispe_h"], ptw["pooled"], vmp, ptw["probs"], g_pretext, ws["d_vis_h"], ws["d_vispe_h"], ptw["dpool"],
+                          B, Nv, vmp.shape[1], H, drop_p=p, seed=seed, vis_stream=1001, vispe_stream=1002)
+            self._tn(ptw["dpool"], ptw["sel0"], self.G("bert.pooler.dense.weight"), B, H, H, ws, beta, bias=self.G("bert.pooler.dense.bias"))
+            K.transpose(self.P("bert.pooler.dense.weight"), H, ptw["pT"], H, H, H, H)
+            self._nt(ptw["dpool"], ptw["pT"], ptw["dsel0"], B, H, H)
+            K.scatter_add_rows(ptw["dsel0"], H, ptw["pos0"], dx, H, B, 1, L, H)
+        elif beta == 0 and getattr(self, "_pooler_dirty", False):
+            self.G("bert.pooler.dense.weight").zero_()           # a previous pretext step left gradients there; unused now
+            self.G("bert.pooler.dense.bias").zero_()
+        self._pooler_dirty = pt is not None
         self._bucket_done(0)
 
         # ---- encoder layers, last to first ----------------------------------------------------------------
@@ -1127,7 +1192,8 @@ class Engine(object):
             K.layernorm_bwd_reduce_batched(ws["ln_slots"], self._ln_table(), 2 * NL + 1, M, H, beta=beta)
         K.embed_bwd(dpre, input_ids, token_type_ids, ws["vis_h"], ws["vispe_h"], self.G(E + "word_embeddings.weight"),
                     self.G(E + "position_embeddings.weight"), self.G(E + "token_type_embeddings.weight"), ws["d_vis_h"], ws["d_vispe_h"],
-                    ws["acc32"], B, L, Nv, H, V, cfg.type_vocab_size, drop_p=p, seed=seed, vis_stream=1001, vispe_stream=1002)
+                    ws["acc32"], B, L, Nv, H, V, cfg.type_vocab_size, drop_p=p, seed=seed, vis_stream=1001, vispe_stream=1002,
+                    region_mask=pt[0]["rmask"] if pt is not None else None)
         self._bucket_done(NL + 1)           # position / type / word embedding tables (tied decoder wgrad + embedding backward) are final
         # vis_pe_embed: Linear(1607, H) -- wgrad into the padded shadow, then crop-accumulate
         # vis_embed: Linear(2048,2048)+ReLU -> Linear(2048,H)+ReLU+Dropout

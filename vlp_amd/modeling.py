@@ -7,8 +7,8 @@ arithmetic of `BertForPreTrainingLossMask.forward` runs as hand-written HIP kern
 libvlp_hip.so, sequenced by vlp_amd.engine.Engine (one fused forward/backward, no per-op autograd graph).
 
 Not implemented (raise loudly; see DESIGN.md "out of scope"): fp32 execution, `enable_butd=False`
-(the reference asserts it is True, run_img2txt_dist.py:199), `relax_projection`, `mask_image_regions`
-(:1050-1057), label smoothing, and the dead HF heads (:878-978, :1497-1966).
+(the reference asserts it is True, run_img2txt_dist.py:199), `relax_projection`, label smoothing, and the dead HF heads
+(:878-978, :1497-1966).  `mask_image_regions` / `vis_pretext_loss` (:1049-1056, 1113-1131) and the pooler they use are built.
 """
 import copy
 import json
@@ -438,18 +438,24 @@ def _load_fc7(module, allow_random):
 
 class _LossFn(torch.autograd.Function):
     """Hands the fused backward to autograd: `loss.backward()` (run_img2txt_dist.py:571-575) reaches
-    Engine.backward with the upstream scalar gradient (which carries the fp16 loss scale)."""
+    Engine.backward with the upstream scalar gradient (which carries the fp16 loss scale).  With mask_image_regions the forward has two
+    live losses (task loss, vis_pretext_loss; the train loop sums them, :531): both are outputs of ONE node, so a single backward call
+    receives both upstream gradients."""
 
     @staticmethod
-    def forward(ctx, anchor, loss, engine, state, task):
+    def forward(ctx, anchor, loss, pretext, engine, state, task):
         ctx.engine, ctx.state, ctx.task = engine, state, task
-        return loss.clone()
+        ctx.has_pretext = pretext is not None
+        if pretext is None:
+            return loss.clone()
+        return loss.clone(), pretext.clone()
 
     @staticmethod
-    def backward(ctx, grad):
+    def backward(ctx, grad, grad_pt=None):
         g = grad.detach().to(torch.float32).reshape(1).contiguous()
-        ctx.engine.backward(ctx.state, g, ctx.task)
-        return None, None, None, None, None
+        gp = grad_pt.detach().to(torch.float32).reshape(1).contiguous() if ctx.has_pretext else None
+        ctx.engine.backward(ctx.state, g, ctx.task, g_pretext=gp)
+        return None, None, None, None, None, None
 
 
 class BertForPreTrainingLossMask(PreTrainedBertModel):
@@ -485,13 +491,11 @@ class BertForPreTrainingLossMask(PreTrainedBertModel):
                 next_sentence_label=None, masked_pos=None, masked_weights=None, task_idx=None, vis_masked_pos=[],
                 mask_image_regions=False, drop_worst_ratio=0.2, vqa_inference=False):
         eng = self.engine
-        if mask_image_regions:
-            raise NotImplementedError("mask_image_regions (--vis_mask_prob > 0) is not implemented in vlp_amd (DESIGN.md: next)")
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_ids)
         train = self.training
 
-        if vqa_inference:                                              # :1039-1047
+        if vqa_inference:                                              # :1039-1047 (returns before the region masking of :1049)
             assert ans_labels is None
             st = eng.forward(vis_feats, vis_pe, input_ids, token_type_ids, attention_mask, None, False, False, True)
             logits = eng.vqa_logits(st)
@@ -499,25 +503,46 @@ class BertForPreTrainingLossMask(PreTrainedBertModel):
             return torch.max(logits[:, 1:].float(), -1)[1] + 1
         if masked_lm_labels is None or next_sentence_label is None:    # :1062-1063
             raise NotImplementedError
+        vmp = None
+        if mask_image_regions:                                         # :1049-1056, 1113-1131
+            if not torch.is_tensor(vis_masked_pos) or vis_masked_pos.dim() != 2 or vis_masked_pos.shape[1] == 0:
+                raise ValueError("mask_image_regions=True needs vis_masked_pos [B, n_masked] (seq2seq_loader.py:267-269)")
+            vmp = vis_masked_pos
         is_vqa = self.tasks == "vqa2"
         if is_vqa:
             assert ans_labels is not None
         want_mlm = (not is_vqa) and masked_pos is not None and masked_pos.numel() > 0
-        st = eng.forward(vis_feats, vis_pe, input_ids, token_type_ids, attention_mask, masked_pos, train, want_mlm, is_vqa)
+        st = eng.forward(vis_feats, vis_pe, input_ids, token_type_ids, attention_mask, masked_pos, train, want_mlm, is_vqa, vis_masked_pos=vmp)
         dev = input_ids.device
         zero1 = torch.zeros(1, device=dev, dtype=torch.float32)
         need_grad = torch.is_grad_enabled()
+        raw_pt = eng.pretext_loss(st) if vmp is not None else None
+        if vmp is not None:
+            self.last_pooled_output = eng.pooled_output(st)
+
+        def live(raw, task):
+            """(task loss, pretext loss) as autograd outputs of one node; the pretext placeholder is the reference's [1] zero (:1133)."""
+            if not need_grad:
+                return raw.clone(), (raw_pt.clone().reshape(()) if raw_pt is not None else zero1.clone())
+            if raw_pt is None:
+                return _LossFn.apply(eng._anchor, raw, None, eng, st, task), zero1.clone()
+            a, b = _LossFn.apply(eng._anchor, raw, raw_pt, eng, st, task)
+            return a, b.reshape(())                                     # :1131: a 0-dim mean
+
         if is_vqa:
             raw = eng.vqa_loss(st, ans_labels)
             self.last_vqa_logits = eng.vqa_logits(st)
-            loss = _LossFn.apply(eng._anchor, raw, eng, st, "vqa2") if need_grad else raw.clone()
-            return zero1, zero1.clone(), loss.reshape(())               # :1141 shapes ([1], [1], [])
+            loss, pt_loss = live(raw, "vqa2")
+            return zero1, pt_loss, loss.reshape(())                     # :1141 shapes ([1], [1] | [], [])
         if not want_mlm:
-            return zero1, zero1.clone(), zero1.clone()                  # :1096-1098
+            if raw_pt is None:
+                return zero1, zero1.clone(), zero1.clone()              # :1096-1098
+            loss, pt_loss = live(zero1.clone(), "img2txt")              # empty masked_pos: only the pretext loss is live
+            return loss, pt_loss, zero1.clone()
         raw = eng.mlm_loss(st, masked_lm_labels, masked_weights, drop_worst_ratio)
         self.last_mlm_logits = eng.mlm_logits(st)
-        loss = _LossFn.apply(eng._anchor, raw, eng, st, "img2txt") if need_grad else raw.clone()
-        return loss.reshape(()), zero1, zero1.clone()                   # :1143 shapes ([], [1], [1])
+        loss, pt_loss = live(raw, "img2txt")
+        return loss.reshape(()), pt_loss, zero1.clone()                 # :1143 shapes ([], [1] | [], [1])
 
 
 class BertForSeq2SeqDecoder(PreTrainedBertModel):

@@ -256,7 +256,7 @@ def build_packed_loader(args, device):
               len_vis_input=args.len_vis_input, new_segment_ids=args.new_segment_ids, trunc_seg=args.trunc_seg,
               always_truncate_tail=args.always_truncate_tail)
     return BatchPrefetcher(store, examples, args.train_batch_size, TextPreprocessor(mode="s2s", **kw), TextPreprocessor(mode="bi", **kw),
-                           s2s_prob=args.s2s_prob, device=device, seed=args.seed)
+                           s2s_prob=args.s2s_prob, device=device, seed=args.seed, vis_mask_prob=args.vis_mask_prob)
 
 
 def synthetic_batches(args, device, steps, rank):
@@ -266,7 +266,7 @@ def synthetic_batches(args, device, steps, rank):
         b = synthetic.make_batch(args.train_batch_size, max_len_b=args.max_len_b, len_vis_input=args.len_vis_input,
                                  vocab_size=KNOWN_VOCABS.get(args.bert_model, 28996), max_pred=args.max_pred, mask_prob=args.mask_prob,
                                  s2s_prob=args.s2s_prob, tasks=args.tasks, seed=args.seed + 1000 * max(rank, 0) + i,
-                                 new_segment_ids=args.new_segment_ids)
+                                 new_segment_ids=args.new_segment_ids, vis_mask_prob=args.vis_mask_prob)
         pool.append(synthetic.batch_to(b, device, half=True))
     for s in range(steps):
         yield pool[s % len(pool)]
