@@ -150,7 +150,7 @@ def test_gemm_nt_variant_identity(gen):
         assert same["27_vs_77"] == NT_FAMILIES_BIT_IDENTICAL and same["29_vs_73"] == NT_FAMILIES_BIT_IDENTICAL, (same, ulp)
 
 
-NT_FAMILIES_BIT_IDENTICAL = None      # set from the first measurement (None: report only)
+NT_FAMILIES_BIT_IDENTICAL = True      # measured in round 4 (profiles/r04_nt_variant_identity.json): one 16x16x32 MFMA rounds like two 32x32x16 k16 steps
 
 
 @pytest.mark.parametrize("M,N,K,splits", [(128, 768, 3072, 8), (128, 2304, 768, 4), (640, 768, 768, 3), (77, 1000, 192, 2), (320, 3072, 768, 12),
@@ -815,32 +815,34 @@ def test_pretext_fwd_bwd(B, Nv, Pm, H, p, gen):
     gradient passes through the projections' ReLU + dropout exactly like vlp_embed_bwd does for the unmasked rows: checked against
     the python mirror of the dropout hash; rows that are not masked must stay untouched."""
     seed, s_vis, s_vpe = 77, 1001, 1002
-    vis = torch.relu(h16(B * Nv, H, scale=0.5, gen=gen))
-    vpe = torch.relu(h16(B * Nv, H, scale=0.5, gen=gen))
+    vis = torch.relu(h16(B * Nv, H, scale=0.15, gen=gen))
+    vpe = torch.relu(h16(B * Nv, H, scale=0.15, gen=gen))
     rows, cols = list(range(B * Nv)), list(range(H))
     mv, mp = drop_mult_ref(p, seed, s_vis, rows, cols), drop_mult_ref(p, seed, s_vpe, rows, cols)
     vis, vpe = (vis.float() * mv).half(), (vpe.float() * mp).half()                 # post-ReLU, post-dropout forward outputs
-    pooled = torch.tanh(h16(B, H, gen=gen).float()).half()
+    pooled = torch.tanh(h16(B, H, gen=gen).float() * 0.3).half()
     vmp = torch.stack([torch.randperm(Nv, generator=torch.Generator().manual_seed(10 + b))[:Pm] + 1 for b in range(B)]).to(DEV)
     probs = torch.empty(B, Pm, Pm, device=DEV)
     sample, loss = torch.empty(B, device=DEV), torch.empty(1, device=DEV)
     K.pretext_fwd(vis, vpe, pooled, vmp, probs, sample, loss, B, Nv, Pm, H)
-    # reference: fp32 autograd over the same rounding points
-    v32 = vis.float().view(B, Nv, H).clone().requires_grad_(True)
-    e32 = vpe.float().view(B, Nv, H).clone().requires_grad_(True)
-    q32 = pooled.float().clone().requires_grad_(True)
+    # forward reference: fp64 sums over the same rounding points (A and sim rounded to fp16, :1124, :1126).  The kernel sums in fp32, so
+    # a similarity that lands within ~1e-6 relative of an fp16 rounding boundary may round the other way (1 fp16 ulp of that entry):
+    # the bounds below admit a handful of such flips, nothing more
     idx = (vmp - 1).unsqueeze(-1).expand(-1, -1, H)
-    Vm, Em = torch.gather(v32, 1, idx), torch.gather(e32, 1, idx)
-    A = Em + q32.unsqueeze(1)
-    A = A + (A.half().float() - A).detach()                                         # fp16 rounding of the in-place add (:1124), straight-through
-    sim = A @ Vm.transpose(1, 2)
-    sim = sim + (sim.half().float() - sim).detach()                                 # the half matmul's output (:1126)
+    Vm = torch.gather(vis.double().view(B, Nv, H), 1, idx)
+    A = (torch.gather(vpe.float().view(B, Nv, H), 1, idx) + pooled.float().unsqueeze(1)).half().double()
+    sim = (A @ Vm.transpose(1, 2)).half().double()
+    ulp = float(sim.abs().max()) * 2.0 ** -10
     ls = torch.log_softmax(sim, dim=-1)
     ref_loss = torch.stack([-ls[b].diag().mean() for b in range(B)]).mean()
-    assert abs(float(loss) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss)) + 1e-6
-    assert rel(probs, torch.softmax(sim, -1).detach()) < 1e-5
+    assert abs(float(loss) - float(ref_loss)) <= 2e-6 * abs(float(ref_loss)) + 4 * ulp / (B * Pm), (float(loss), float(ref_loss), ulp)
+    pd = (probs.double() - torch.softmax(sim, -1)).abs()
+    assert float(pd.max()) <= 1.2 * ulp + 1e-6 and float((pd > 1e-6).double().mean()) < 0.02, (float(pd.max()), ulp)
+    assert float((probs.sum(-1) - 1).abs().max()) < 1e-5
+    # backward reference: the closed form on the kernel's own probabilities (isolates the backward kernel from forward flips)
     g = 4096.0
-    (ref_loss * g).backward()
+    dsim = (probs.double() - torch.eye(Pm, device=DEV, dtype=torch.double)) * (g / (B * Pm))
+    dA, dV = dsim @ Vm, dsim.transpose(1, 2) @ A
     d_vis = torch.full((B * Nv, H), 3.0, device=DEV, dtype=torch.half)
     d_vpe = torch.full((B * Nv, H), 3.0, device=DEV, dtype=torch.half)
     dpool = torch.empty(B, H, device=DEV, dtype=torch.half)
@@ -850,12 +852,26 @@ def test_pretext_fwd_bwd(B, Nv, Pm, H, p, gen):
     masked.scatter_(1, vmp - 1, True)
     masked = masked.view(-1)
     assert float((d_vis[~masked].float() - 3.0).abs().max()) == 0.0 and float((d_vpe[~masked].float() - 3.0).abs().max()) == 0.0
-    want_v = (v32.grad.view(B * Nv, H) * (vis.float() > 0) * mv)[masked]
-    want_e = (e32.grad.view(B * Nv, H) * (vpe.float() > 0) * mp)[masked]
-    assert rel(d_vis[masked].float(), want_v) < 2e-3                                # fp16 output rounding
-    assert rel(d_vpe[masked].float(), want_e) < 2e-3
-    want_pool = q32.grad * (1.0 - pooled.float() ** 2)
-    assert rel(dpool.float(), want_pool) < 2e-3
+    full_v = torch.zeros(B, Nv, H, device=DEV, dtype=torch.double).scatter_(1, idx, dV).view(B * Nv, H)
+    full_e = torch.zeros(B, Nv, H, device=DEV, dtype=torch.double).scatter_(1, idx, dA).view(B * Nv, H)
+    want_v = (full_v * (vis.float() > 0) * mv)[masked]
+    want_e = (full_e * (vpe.float() > 0) * mp)[masked]
+    assert rel(d_vis[masked].float(), want_v) < 1e-3                                # fp16 output rounding only
+    assert rel(d_vpe[masked].float(), want_e) < 1e-3
+    want_pool = dA.sum(1) * (1.0 - pooled.double() ** 2)
+    assert rel(dpool.float(), want_pool) < 1e-3
+    # and the closed form IS the gradient: torch autograd of the oracle's loss (fp32, straight-through fp16 roundings) agrees
+    v32 = vis.float().view(B, Nv, H).clone().requires_grad_(True)
+    e32 = vpe.float().view(B, Nv, H).clone().requires_grad_(True)
+    q32 = pooled.float().clone().requires_grad_(True)
+    A32 = torch.gather(e32, 1, idx) + q32.unsqueeze(1)
+    A32 = A32 + (A32.half().float() - A32).detach()
+    s32 = A32 @ torch.gather(v32, 1, idx).transpose(1, 2)
+    s32 = s32 + (s32.half().float() - s32).detach()
+    l32 = torch.log_softmax(s32, dim=-1)
+    (torch.stack([-l32[b].diag().mean() for b in range(B)]).mean() * g).backward()
+    assert rel((v32.grad.view(B * Nv, H) * (vis.float() > 0) * mv)[masked], want_v) < 0.1 * (1 + 20 * ulp)      # loose: forward flips allowed
+    assert rel(q32.grad * (1.0 - pooled.float() ** 2), want_pool) < 0.1 * (1 + 20 * ulp)
     # bitwise reproducible
     d2, e2, p2 = torch.empty_like(d_vis), torch.empty_like(d_vpe), torch.empty_like(dpool)
     K.pretext_bwd(vis, vpe, pooled, vmp, probs, torch.full((1,), g, device=DEV), d2, e2, p2, B, Nv, Pm, H, drop_p=p, seed=seed,
