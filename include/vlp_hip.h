@@ -191,7 +191,9 @@ int vlp_attn_bwd(const vlp_attn_bwd_args* a, void* stream);
 
 /* int64 [B,L,L] 0/1 (seq2seq_loader.py:292-304) -> uint8 [B,L,Lp]: 1 attend, 0 masked, 2 for the padding
  * columns >= L (excluded from the softmax). */
-/* out_t (optional, [B,Lp,Lp]): out_t[b][key][q] = the same flag, 2 wherever key >= L or q >= L (used by vlp_attn_bwd). */
+/* out_t (optional, [B,Lp,Lp]): the key-major copy used by vlp_attn_bwd -- row `key` holds the flags of all queries, 2 wherever key >= L
+ * or q >= L.  ABI 3: inside a row the byte of query q = 16 t + 4 g + e sits at g * (Lp / 4) + 4 t + e (the order in which a lane of the
+ * backward kernel consumes them: its words are consecutive); treat the buffer as opaque, produced here and by vlp_mask_build only. */
 int vlp_mask_pack(const int64_t* mask, uint8_t* out, uint8_t* out_t, int32_t B, int32_t L, int32_t Lp, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

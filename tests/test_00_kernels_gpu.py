@@ -444,6 +444,25 @@ def test_attention_fwd_bwd(B, L, Nv, heads, gen):
                 os.environ.pop("VLP_ATTN_SKIP", None)
         for x, y in zip(*outs):
             assert torch.equal(x, y)
+    # the one-kernel backward (default) against the two-kernel form it replaces (VLP_ATTN_BWD=split): dV is accumulated in the same
+    # orientation and order from the same probabilities -> bit-identical; dK and dQ see delta = rowsum(dO * O) summed in another lane
+    # order, and dQ comes from dS^T blocks produced by the key-owner orientation: equal up to fp16 rounding
+    for pdrop in (0.0, 0.2):
+        outs = []
+        for mode in ("one", "split", "xch"):         # default (whole dS^T in LDS at L <= 192) | two kernels | exchange-tile form
+            os.environ["VLP_ATTN_BWD"] = mode
+            try:
+                c2, l2 = torch.zeros_like(ctx), torch.zeros_like(lse)
+                d2, dl2 = torch.zeros_like(dqkv), torch.zeros_like(delta)
+                K.attn_fwd(qkv, mb, c2, l2, B, L, heads, 0.125, dropout_p=pdrop, seed=11, rng_stream=3)
+                K.attn_bwd(qkv, mb, mt, c2, dctx, l2, d2, dl2, B, L, heads, 0.125, dropout_p=pdrop, seed=11, rng_stream=3)
+                outs.append(d2.view(B * L, 3, H))
+            finally:
+                os.environ.pop("VLP_ATTN_BWD", None)
+        assert torch.equal(outs[0][:, 2], outs[1][:, 2])                                   # dV: same probabilities, same order
+        assert rel(outs[0][:, 1].float(), outs[1][:, 1].float()) < 2e-3                     # dK: delta is summed in another lane order
+        assert rel(outs[0][:, 0].float(), outs[1][:, 0].float()) < 2e-3
+        assert torch.equal(outs[0], outs[2])                                                # the two one-kernel forms: same chains everywhere
 
 
 def test_attention_dropout_exact_mask(gen):

@@ -141,6 +141,13 @@ DEVFN f16x8 tr_frag(const f16* tile, int r_first, int r_second, int col0, int g,
 #define LOG2E_F 1.4426950408889634f
 #define LN2_F 0.6931471805599453f
 #define MASK_C1 (10000.0f * LOG2E_F)
+// Key-major mask copy (out_t of vlp_mask_pack / vlp_mask_build, backward only): row `key` holds Lp bytes, one per query, in LANE
+// ORDER: the byte of query q = 16 t + 4 g + e sits at g * (Lp / 4) + 4 t + e.  A lane of the key-owner backward kernels (key column
+// li, row group g) wants the words (4 queries 16 t + 4g .. +3) of ALL query tiles t: they are CONSECUTIVE in this order (48 bytes at
+// L = 167: three 16-byte loads, and a wave covers its 16 key rows exactly once) -- in plain query order they were 12 scattered
+// 4-byte gathers per lane, the slowest loads of the one-kernel backward's prologue.
+DEVFN int maskt_pos(int q, int Lp) { return ((q >> 2) & 3) * (Lp >> 2) + ((q >> 4) << 2) + (q & 3); }
+DEVFN int maskt_query(int pos, int Lp) { const int gsz = Lp >> 2, g = pos / gsz, rem = pos - g * gsz; return ((rem >> 2) << 4) + 4 * g + (rem & 3); }
 // 4 mask bytes of one row at columns key0..key0+3, branch-free (the address is clamped into the row; columns past the row read as 2)
 DEVFN uint32_t mask_word(const uint8_t* mrow, int key0, int Lp) {
     const uint32_t w = *reinterpret_cast<const uint32_t*>(mrow + min(key0, Lp - 4));
@@ -502,9 +509,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT >= 8 ? 4 : 2)) void attn
         }
         // mask bytes of this key for queries 16*qt + 4g .. +3 (rows >= L / keys >= L hold 2 = excluded); the words of the
         // next query-tile pair are fetched one iteration ahead
-        const uint8_t* mtr = p.mask_t + ((int64_t)b * p.Lp + min(key, p.Lp - 1)) * p.Lp + 4 * g;
+        const uint8_t* mtr = p.mask_t + ((int64_t)b * p.Lp + min(key, p.Lp - 1)) * p.Lp + g * (p.Lp >> 2);      // lane order, see maskt_pos
         auto mload = [&](int qt) -> uint32_t {       // branch-free: clamp the address, select afterwards
-            const uint32_t w = *reinterpret_cast<const uint32_t*>(mtr + min(16 * qt, p.Lp - 16));
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(mtr + min(4 * qt, (p.Lp >> 2) - 4));
             return (qt * 16 < p.Lp) ? w : 0x02020202u;
         };
         uint32_t mcur[2] = {mload(0), mload(1)};
@@ -588,6 +595,523 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT >= 8 ? 4 : 2)) void attn
             }
         }
     }
+}
+
+// =================================================================================================
+// backward, ONE kernel (round 4): dQ, dK, dV and delta in a single pass over the head.
+// The two kernels above each recompute S, P (one v_exp per element), the dropout hash and dP, in opposite orientations: the VALU work
+// that bounds both of them is done twice and Q|K|V + dO are read twice from HBM (233 MB per layer where one pass needs ~135 MB).
+// Here the score recomputation runs ONCE, in the key-owner orientation of the dK/dV kernel: wave w owns key tiles 2w, 2w+1 (column per
+// lane), walks the query-tile pairs u and keeps dK, dV of its keys in registers.  dQ needs the contraction over KEYS, i.e. across the
+// waves: every wave drops its dS^T block (fp16, 16 keys x 32 queries) into an LDS exchange tile [LP keys][32 queries]; after ONE
+// workgroup barrier per query pair the dQ^T tiles of that pair (2 query tiles x 4 head-dim tiles, each K^T . dS^T over all keys: NT/2
+// MFMAs) are computed by the LAST waves of the workgroup -- under the seq2seq mask those own the caption keys, whose blocks are mostly
+// dead, so the dQ duty fills their idle time -- from K^T fragments they hold in registers (K passes through the exchange tile once, in
+// the prologue).  The exchange tile is double buffered: step u + 1 writes the other half while the duty waves still read step u, so the
+// single barrier per step also frees the half that step u + 2 will write.  dQ is summed in a fixed key order by one wave per tile:
+// deterministic, no atomics.  delta = rowsum(dO * O) is computed while Q / dO are staged (8 lanes per row).
+// LDS at L = 167: Q 24 KB + dO 24 KB + exchange 24 KB + row statistics 2.3 KB = 74.3 KB -> two workgroups of 6 waves per CU.
+// =================================================================================================
+DEVFN int swz_ds(int r) { return (((r >> 2) & 1) << 2) | (((r >> 1) & 1) << 1) | ((r >> 3) & 1); }
+// exchange tile: [keys][32 queries] fp16, 64-byte rows = 8 pieces of 4 queries; piece pc of row r sits at piece pc ^ swz_ds(r):
+// the 8-byte writes of a 16-key tile and the transpose reads of the duty waves (8 rows x one aligned group of 4 pieces) are conflict free
+DEVFN f16x8 tr_frag_ds(const f16* buf, int r_first, int r_second, int col0, int g, int li) {
+    const int ra = r_first + 4 * g + (li >> 2), rb = r_second + 4 * g + (li >> 2);
+    const int pc = (col0 >> 2) + (li & 3);
+    const u32x2 a = __builtin_bit_cast(u32x2, lds_tr_read(buf + ra * 32 + ((pc ^ swz_ds(ra)) << 2)));
+    const u32x2 b = __builtin_bit_cast(u32x2, lds_tr_read(buf + rb * 32 + ((pc ^ swz_ds(rb)) << 2)));
+    return words_f16x8(a[0], a[1], b[0], b[1]);
+}
+// KPW = key tiles per wave.  1 (NT <= 12): NT waves, ONE workgroup per CU (12 waves at L = 167 = 3 per SIMD, <= 168 VGPRs, no spills):
+// with two key tiles per wave the dK / dV accumulators (64 registers) + both tiles' K / V rows + the duty's K^T fragments need ~200
+// registers, and the 6-wave form spilled the K / V row fragments (scratch reloads inside the loop: 128 us per layer against 83 us for
+// the two-kernel form at B = 64).  2 at NT = 16 (L > 192: 8 waves, 256-register budget).
+template <int NT, int KPW>
+__global__ __launch_bounds__((NT / KPW) * 64, KPW == 2 ? 2 : 3) void attn_bwd_one_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int LP = NT * 16, NP = NT / 2, NW = NT / KPW, NTHR = NW * 64;
+    constexpr int DW = NW < 4 ? NW : 4;             // duty waves (the last DW of the workgroup), 8 / DW dQ tiles each per step
+    constexpr int DT = 8 / DW;
+    f16* Qs = reinterpret_cast<f16*>(smem_raw);     // [LP][64] swizzled
+    f16* dOs = Qs + LP * HD;                        // [LP][64] swizzled
+    f16* xch = dOs + LP * HD;                       // exchange: 2 x [LP][32]  (= one [LP][64] tile: K passes through it in the prologue)
+    float* lse_s = reinterpret_cast<float*>(xch + LP * HD);    // [LP] lse * log2(e)
+    float* dl_s = lse_s + LP;                                  // [LP] delta
+    uint32_t* rk_s = reinterpret_cast<uint32_t*>(dl_s + LP);   // [LP] dropout row keys of the queries
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int b = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
+    const int L = p.L;
+    const f16* qbase = p.qkv + (int64_t)b * L * p.ld_qkv + h * HD;
+    const f16* kbase = qbase + p.H;
+    const f16* vbase = qbase + 2 * p.H;
+    const f16* dobase = p.dctx + (int64_t)b * L * p.ld_dctx + h * HD;
+    const f16* obase = p.ctx + (int64_t)b * L * p.ld_ctx + h * HD;
+
+    // ---- prologue: Q, dO -> LDS (all loads in flight first), delta from the dO / O pieces on the way, K -> exchange tile ---------------
+    {
+        constexpr int IT = (LP * 8 + NTHR - 1) / NTHR;
+        const __amdgpu_buffer_rsrc_t rq = rows_rsrc(qbase, p.ld_qkv, L), rdo = rows_rsrc(dobase, p.ld_dctx, L), ro = rows_rsrc(obase, p.ld_ctx, L),
+                                     rkk = rows_rsrc(kbase, p.ld_qkv, L);
+        u32x4 vq[IT], vd[IT], vo[IT], vk[IT];
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int idx = tid + i * NTHR, r = idx >> 3, c = idx & 7;
+            vq[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, (r * (int)p.ld_qkv + c * 8) * 2, 0, 0);
+            vd[i] = __builtin_amdgcn_raw_buffer_load_b128(rdo, (r * (int)p.ld_dctx + c * 8) * 2, 0, 0);
+            vo[i] = __builtin_amdgcn_raw_buffer_load_b128(ro, (r * (int)p.ld_ctx + c * 8) * 2, 0, 0);
+            vk[i] = __builtin_amdgcn_raw_buffer_load_b128(rkk, (r * (int)p.ld_qkv + c * 8) * 2, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int idx = tid + i * NTHR, r = idx >> 3, c = idx & 7;
+            const f16x8 d8 = __builtin_bit_cast(f16x8, vd[i]), o8 = __builtin_bit_cast(f16x8, vo[i]);
+            float dl = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl = fmaf((float)d8[e], (float)o8[e], dl);
+            dl += __shfl_xor(dl, 1, 64);                  // the 8 lanes of a row are consecutive (c = idx & 7)
+            dl += __shfl_xor(dl, 2, 64);
+            dl += __shfl_xor(dl, 4, 64);
+            if (idx < LP * 8) {
+                const int off = r * HD + ((c ^ swzk(r)) << 3);
+                *reinterpret_cast<u32x4*>(Qs + off) = vq[i];
+                *reinterpret_cast<u32x4*>(dOs + off) = vd[i];
+                *reinterpret_cast<u32x4*>(xch + off) = vk[i];
+                if (c == 0) dl_s[r] = dl;
+            }
+        }
+    }
+    for (int i = tid; i < LP; i += NTHR) {
+        const int64_t stat = ((int64_t)b * p.heads + h) * L + min(i, L - 1);
+        lse_s[i] = p.lse[stat] * LOG2E_F;
+        rk_s[i] = p.drop.thresh ? drop_rowkey(p.drop, (uint64_t)stat) : 0u;      // dropout element = (row (b, h, q), col key)
+    }
+    // this wave's keys (B operands of the score / dP recomputation), straight from HBM / L2: key = (KPW wid + j) * 16 + li
+    f16x8 kf[KPW][2], vf[KPW][2];
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) {
+        const int kc = min((KPW * wid + j) * 16 + li, L - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            kf[j][ks] = ld8(kbase + (int64_t)kc * p.ld_qkv + ks * 32 + g * 8);
+            vf[j][ks] = ld8(vbase + (int64_t)kc * p.ld_qkv + ks * 32 + g * 8);
+        }
+    }
+    __syncthreads();
+    // duty waves: K^T fragments of their head-dim tiles for every key pair, kept in registers for the whole kernel
+    const int dwi = wid - (NW - DW);                // >= 0 on duty waves
+    f16x8 ktf[DT > 2 ? 2 : 1][NP];                  // d-tiles handled by this wave: n = dwi (+ DW if DW == 2)
+    constexpr int NDT = DW == 4 ? 1 : 2;            // distinct d-tiles per duty wave (DW = 4: one d-tile, both query tiles; DW = 2: two d-tiles)
+    if (dwi >= 0) {
+#pragma unroll
+        for (int dn = 0; dn < NDT; ++dn)
+#pragma unroll
+            for (int kp = 0; kp < NP; ++kp) ktf[dn][kp] = tr_frag(xch, 32 * kp, 32 * kp + 16, 16 * (dwi + dn * DW), g, li);
+    }
+    __syncthreads();                                // K has been read out of the exchange tile: it now carries dS^T blocks
+
+    const int nkt = (L + 15) / 16;
+    const uint8_t* mtr[KPW];
+    uint32_t keyphi[KPW], kodd[KPW];
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) {
+        const int key = (KPW * wid + j) * 16 + li;
+        mtr[j] = p.mask_t + ((int64_t)b * p.Lp + min(key, p.Lp - 1)) * p.Lp + g * (p.Lp >> 2);      // lane order, see maskt_pos
+        keyphi[j] = ((uint32_t)key >> 1) * VLP_PHI;
+        kodd[j] = (uint32_t)key & 1u;
+    }
+    auto mload = [&](int j, int qt) -> uint32_t {       // 4 mask bytes of this lane's key j for queries 16 qt + 4g .. +3; branch-free
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(mtr[j] + min(4 * qt, (p.Lp >> 2) - 4));
+        return ((KPW * wid + j) * 16 < p.Lp && qt * 16 < p.Lp) ? w : 0x02020202u;
+    };
+    uint32_t mcur[KPW][2];
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) { mcur[j][0] = mload(j, 0); mcur[j][1] = mload(j, 1); }
+    const float sc2 = p.scale * LOG2E_F;
+    f32x4 dk[KPW][4], dv[KPW][4];
+#pragma unroll
+    for (int j = 0; j < KPW; ++j)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { dk[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+#pragma unroll 1
+    for (int u = 0; u < NP; ++u) {               // query tile pair (2u, 2u+1)
+        int gq = g;                              // opaque copy: keeps address math inside the loop (no LICM + spills)
+        asm volatile("" : "+v"(gq));
+        f16* xb = xch + (u & 1) * (LP * 32);
+        uint32_t mnext[KPW][2];
+#pragma unroll
+        for (int j = 0; j < KPW; ++j) {
+            mnext[j][0] = mnext[j][1] = 0x02020202u;
+            if (u + 1 < NP) { mnext[j][0] = mload(j, 2 * u + 2); mnext[j][1] = mload(j, 2 * u + 3); }
+        }
+#pragma unroll
+        for (int j = 0; j < KPW; ++j) {          // this wave's key tile(s)
+            const int kt = KPW * wid + j;
+            uint32_t pdw[4], dsw[4];             // B operands (rows = queries (pair slots), col = key) as packed words
+            bool pair_live = false;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int qt = 2 * u + half;
+                bool dead = kt >= nkt;
+                if (!dead && p.skip) {
+                    // dead block: no (query, key) pair of it is attended AND all its queries have an attended key somewhere -> P = 0 exactly
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 16 + 4 * gq);
+                    const bool need = ANY_ATTEND(mcur[j][half]) || fminf(fminf(l4[0], l4[1]), fminf(l4[2], l4[3])) < -7000.f;
+                    dead = !__any(need);
+                }
+                // the block's row of the exchange tile: key row kt * 16 + li, piece = queries 16 half + 4g .. +3
+                const int xr = kt * 16 + li;
+                uint32_t* xdst = reinterpret_cast<uint32_t*>(xb + xr * 32 + (((half * 4 + gq) ^ swz_ds(xr)) << 2));
+                if (dead) {
+                    pdw[2 * half] = pdw[2 * half + 1] = 0u;
+                    dsw[2 * half] = dsw[2 * half + 1] = 0u;
+                    *reinterpret_cast<u32x2*>(xdst) = (u32x2){0u, 0u};
+                    continue;
+                }
+                pair_live = true;
+                // S tile: rows = queries 16qt + 4g + reg, col = key.  A = Q rows (LDS), B = K rows (registers)
+                const int qa = qt * 16 + li;
+                f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int off = qa * HD + (((ks * 4 + gq) ^ swzk(qa)) << 3);
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld8(Qs + off), kf[j][ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld8(dOs + off), vf[j][ks], dp, 0, 0, 0);
+                }
+                const int q0 = qt * 16 + 4 * gq;
+                const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_s + q0);
+                const f32x4 dl4 = *reinterpret_cast<const f32x4*>(dl_s + q0);
+                const u32x4 rk4 = *reinterpret_cast<const u32x4*>(rk_s + q0);
+                float ma[4];
+                mask4w(mcur[j][half], qt * 16 + 16 <= L && kt * 16 + 16 <= L, -MASK_C1, ma);
+                float pd4[4], ds4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, ma[r] - lse4[r]));     // excluded (padding) -> exp2(-inf) = 0
+                    float mult = 1.f;
+                    if (p.drop.thresh) mult = drop_mult_h(p.drop, mix32(rk4[r] + keyphi[j]), kodd[j]);
+                    pd4[r] = pr * mult;
+                    ds4[r] = pr * (dp[r] * mult - dl4[r]) * p.scale;
+                }
+                pdw[2 * half] = pack_f16x2(pd4[0], pd4[1]);
+                pdw[2 * half + 1] = pack_f16x2(pd4[2], pd4[3]);
+                dsw[2 * half] = pack_f16x2(ds4[0], ds4[1]);
+                dsw[2 * half + 1] = pack_f16x2(ds4[2], ds4[3]);
+                *reinterpret_cast<u32x2*>(xdst) = (u32x2){dsw[2 * half], dsw[2 * half + 1]};      // dS^T block for the dQ duty
+            }
+            // dV^T += dO^T . Pd ; dK^T += Q^T . dS   (rows = head-dim, col = key); transposed operands by ds_read_b64_tr_b16
+            if (pair_live) {
+                const f16x8 pdf = words_f16x8(pdw[0], pdw[1], pdw[2], pdw[3]), dsf = words_f16x8(dsw[0], dsw[1], dsw[2], dsw[3]);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    dv[j][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(dOs, 32 * u, 32 * u + 16, 16 * n, gq, li), pdf, dv[j][n], 0, 0, 0);
+                    dk[j][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(Qs, 32 * u, 32 * u + 16, 16 * n, gq, li), dsf, dk[j][n], 0, 0, 0);
+                }
+            }
+            mcur[j][0] = mnext[j][0];
+            mcur[j][1] = mnext[j][1];
+        }
+        // every wave's dS^T blocks of pair u are in xb; the other half is free for step u + 1.  LDS writes only: a __syncthreads() would
+        // also wait (vmcnt(0)) for the duty waves' dQ stores of the previous step and for the mask words just requested
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (dwi >= 0) {                          // dQ duty: tiles (qh, n) of this pair
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                const int qh = DW == 4 ? t : (t & 1);
+                const int dn = DW == 4 ? 0 : (t >> 1);
+                const int n = dwi + dn * DW;
+                f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kp = 0; kp < NP; ++kp)
+                    o = __builtin_amdgcn_mfma_f32_16x16x32_f16(ktf[dn][kp], tr_frag_ds(xb, 32 * kp, 32 * kp + 16, 16 * qh, gq, li), o, 0, 0, 0);
+                const int q = (2 * u + qh) * 16 + li;
+                if (q < L) {
+                    const f16x4 ov = (f16x4){(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
+                    st4_out<VLP_SS_ATTN>(p.dqkv + ((int64_t)b * L + q) * p.ld_dqkv + h * HD + n * 16 + 4 * gq, ov);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) {
+        const int key = (KPW * wid + j) * 16 + li;
+        if (key < L) {
+            f16* drow = p.dqkv + ((int64_t)b * L + key) * p.ld_dqkv + h * HD;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const f16x4 kv = (f16x4){(f16)dk[j][n][0], (f16)dk[j][n][1], (f16)dk[j][n][2], (f16)dk[j][n][3]};
+                const f16x4 vv = (f16x4){(f16)dv[j][n][0], (f16)dv[j][n][1], (f16)dv[j][n][2], (f16)dv[j][n][3]};
+                st4_out<VLP_SS_ATTN>(drow + p.H + n * 16 + 4 * g, kv);
+                st4_out<VLP_SS_ATTN>(drow + 2 * p.H + n * 16 + 4 * g, vv);
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// backward, one kernel, NO per-step barriers (L <= 192): the whole dS^T of the head lives in LDS.
+// Measured with the exchange-tile form above at L = 167, B = 64 (tools/attn_lab.py, round 4): 73 us per layer against 80 us for the two
+// kernels -- one workgroup per CU runs 25 us of which the six step barriers expose every wave's two-block latency chain six times.  With one
+// workgroup per CU the 160 KB of LDS are free anyway: Q, dO, K (24 KB each) and dS^T [LP keys][LP queries] fp16 (72 KB) = 146 KB.
+// Phase 1: wave w owns key tile w (column per lane) and walks ALL query tiles without synchronisation (dK, dV in registers, its dS^T
+// rows into LDS); ONE barrier; phase 2: the NT waves share the dQ^T tiles (query tile x head-dim tile), each K^T . dS^T over all keys with
+// both operands read through ds_read_b64_tr_b16 -- no K^T fragments parked in registers.  Deterministic (one wave per output tile, fixed
+// key order).
+// =================================================================================================
+DEVFN int swz_dsf(int r) { return (((r >> 1) & 3) << 2) | (((r >> 3) & 1) << 1) | (r & 1); }
+// dS^T tile: [LP keys][LP queries] fp16, rows of LP / 4 pieces (4 queries = 8 bytes); piece pc of row r at pc ^ swz_dsf(r) (the XOR stays
+// inside an aligned group of 16 pieces): the 8-byte block writes of a key tile and the transpose reads of phase 2 are conflict free
+template <int LP>
+DEVFN f16x8 tr_frag_dsf(const f16* buf, int r_first, int r_second, int col0, int g, int li) {
+    const int ra = r_first + 4 * g + (li >> 2), rb = r_second + 4 * g + (li >> 2);
+    const int pc = (col0 >> 2) + (li & 3);
+    const u32x2 a = __builtin_bit_cast(u32x2, lds_tr_read(buf + ra * LP + ((pc ^ swz_dsf(ra)) << 2)));
+    const u32x2 b = __builtin_bit_cast(u32x2, lds_tr_read(buf + rb * LP + ((pc ^ swz_dsf(rb)) << 2)));
+    return words_f16x8(a[0], a[1], b[0], b[1]);
+}
+// DROP (compile time): dropout on the probabilities.  The phase-1 loop is straight-line code per query pair: a phase trace of the first
+// version (tools/attn_bwd_trace.py: 4 250 cycles per pair for ~500 instructions, 31 s_waitcnt) showed it latency-bound on (a) the next
+// pair's mask words, fetched inside the loop behind scalar branches and waited for with vmcnt(0) -- all NT words of the lane's key are
+// loaded before the loop now --, and (b) a dozen small basic blocks from the run-time dropout / interior-tile switches.
+template <int NT, bool DROP>     // NT = LP / 16 key tiles = waves of the workgroup (4, 8, 12)
+__global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int LP = NT * 16, NP = NT / 2, NTHR = NT * 64;
+    f16* Qs = reinterpret_cast<f16*>(smem_raw);     // [LP][64] swizzled
+    f16* dOs = Qs + LP * HD;                        // [LP][64] swizzled
+    f16* Ks = dOs + LP * HD;                        // [LP][64] swizzled
+    f16* dSs = Ks + LP * HD;                        // [LP][LP] piece-swizzled
+    float* lse_s = reinterpret_cast<float*>(dSs + LP * LP);    // [LP] lse * log2(e)
+    float* dl_s = lse_s + LP;                                  // [LP] delta
+    uint32_t* rk_s = reinterpret_cast<uint32_t*>(dl_s + LP);   // [LP] dropout row keys of the queries
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int b = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
+    const int L = p.L;
+    const f16* qbase = p.qkv + (int64_t)b * L * p.ld_qkv + h * HD;
+    const f16* kbase = qbase + p.H;
+    const f16* vbase = qbase + 2 * p.H;
+    const f16* dobase = p.dctx + (int64_t)b * L * p.ld_dctx + h * HD;
+    const f16* obase = p.ctx + (int64_t)b * L * p.ld_ctx + h * HD;
+
+    TRACE(0);
+    // ---- prologue: EVERY global load of the workgroup is issued before the first one is consumed (one memory round trip, not four: the
+    // first build staged, then fetched lse, then the V rows, then the mask words behind scalar branches -- 18 000 cycles of the 39 000 a
+    // workgroup takes).  Q, dO, K -> LDS; delta from the dO / O pieces on the way.
+    const int kt = wid;
+    const int key = kt * 16 + li;
+    constexpr int IT = (LP * 8 + NTHR - 1) / NTHR;
+    constexpr int ST = (LP + NTHR - 1) / NTHR;           // row statistics per thread (1 unless the workgroup has fewer threads than rows)
+    u32x4 vq[IT], vd[IT], vo[IT], vk[IT];
+    float lse_v[ST];
+    f16x8 kf[2], vf[2];
+    uint32_t mw[NT];                                      // mask bytes of this lane's key for ALL queries (word t = queries 16 t + 4g .. +3)
+    {
+        const __amdgpu_buffer_rsrc_t rq = rows_rsrc(qbase, p.ld_qkv, L), rdo = rows_rsrc(dobase, p.ld_dctx, L), ro = rows_rsrc(obase, p.ld_ctx, L),
+                                     rkk = rows_rsrc(kbase, p.ld_qkv, L);
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int idx = tid + i * NTHR, r = idx >> 3, c = idx & 7;
+            vq[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, (r * (int)p.ld_qkv + c * 8) * 2, 0, 0);
+            vd[i] = __builtin_amdgcn_raw_buffer_load_b128(rdo, (r * (int)p.ld_dctx + c * 8) * 2, 0, 0);
+            vo[i] = __builtin_amdgcn_raw_buffer_load_b128(ro, (r * (int)p.ld_ctx + c * 8) * 2, 0, 0);
+            vk[i] = __builtin_amdgcn_raw_buffer_load_b128(rkk, (r * (int)p.ld_qkv + c * 8) * 2, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < ST; ++i) lse_v[i] = p.lse[((int64_t)b * p.heads + h) * L + min(tid + i * NTHR, L - 1)];
+        const int kc = min(key, L - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) vf[ks] = ld8(vbase + (int64_t)kc * p.ld_qkv + ks * 32 + g * 8);
+        // unconditional loads from a clamped address + a bitwise select: a `cond ? *ptr : pad` lets the compiler sink every load into its
+        // own scalar branch
+        __builtin_amdgcn_sched_barrier(0);        // the mask words are the youngest loads: the staging writes above must not queue behind them
+        const uint8_t* mtr = p.mask_t + ((int64_t)b * p.Lp + min(key, p.Lp - 1)) * p.Lp + g * (p.Lp >> 2);      // lane order (maskt_pos): words t = 0 .. Lp/16 - 1 are consecutive
+        if (NT % 4 == 0 && p.Lp == LP && ((uintptr_t)p.mask_t & 15) == 0) {      // (L = 167: three 16-byte loads per lane)
+#pragma unroll
+            for (int t4 = 0; t4 < NT / 4; ++t4) {
+                const u32x4 w4 = *reinterpret_cast<const u32x4*>(mtr + 16 * t4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mw[4 * t4 + e] = w4[e];
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const uint32_t w = *reinterpret_cast<const uint32_t*>(mtr + min(4 * t, (p.Lp >> 2) - 4));
+                const uint32_t keep = (kt * 16 < p.Lp && t * 16 < p.Lp) ? 0xffffffffu : 0u;       // rows >= Lp / keys >= Lp: 2 = excluded
+                mw[t] = (w & keep) | (0x02020202u & ~keep);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int idx = tid + i * NTHR, r = idx >> 3, c = idx & 7;
+            const f16x8 d8 = __builtin_bit_cast(f16x8, vd[i]), o8 = __builtin_bit_cast(f16x8, vo[i]);
+            float dl = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl = fmaf((float)d8[e], (float)o8[e], dl);
+            dl += __shfl_xor(dl, 1, 64);                  // the 8 lanes of a row are consecutive (c = idx & 7)
+            dl += __shfl_xor(dl, 2, 64);
+            dl += __shfl_xor(dl, 4, 64);
+            if (idx < LP * 8) {
+                const int off = r * HD + ((c ^ swzk(r)) << 3);
+                *reinterpret_cast<u32x4*>(Qs + off) = vq[i];
+                *reinterpret_cast<u32x4*>(dOs + off) = vd[i];
+                *reinterpret_cast<u32x4*>(Ks + off) = vk[i];
+                if (c == 0) dl_s[r] = dl;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < ST; ++i) {
+            const int r = tid + i * NTHR;
+            if (r < LP) {
+                lse_s[r] = lse_v[i] * LOG2E_F;
+                rk_s[r] = p.drop.thresh ? drop_rowkey(p.drop, (uint64_t)(((int64_t)b * p.heads + h) * L + min(r, L - 1))) : 0u;   // dropout element = (row (b, h, q), col key)
+            }
+        }
+    }
+    TRACE(1);
+    // staging barrier on the LDS writes only: the mask words (12 small gathers per lane, the youngest loads in the queue) and the V rows stay
+    // in flight across it and are waited for at their first use -- a __syncthreads() drains them too (vmcnt(0): +8 000 cycles per workgroup
+    // in the phase trace)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    TRACE(2);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) kf[ks] = ld8(Ks + key * HD + (((ks * 4 + g) ^ swzk(key)) << 3));
+
+    // ---- phase 1: this wave's key tile against every query tile ------------------------------------------------------------------------
+    const int nkt = (L + 15) / 16;
+    const uint32_t keyphi = ((uint32_t)key >> 1) * VLP_PHI, kodd = (uint32_t)key & 1u;
+    const float sc2 = p.scale * LOG2E_F;
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) { dk[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    f16* xrow = dSs + key * LP;                  // this lane's dS^T row
+    const int xsw = swz_dsf(key);
+
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {               // query tile pair (2u, 2u+1); unrolled: mw[] stays in registers, addresses fold into offsets
+        uint32_t pdw[4], dsw[4];                 // B operands (rows = queries (pair slots), col = key) as packed words
+        // dead blocks (P = 0 exactly: no (query, key) pair attended AND every query has an attended key somewhere): the PAIR is skipped when
+        // both of its blocks are dead; a single dead block of a live pair is simply computed -- its probabilities come out as exact zeros
+        // (exp2 of -14 000)
+        bool pair_live = kt < nkt;
+        if (pair_live && p.skip) {
+            bool need = false;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + (2 * u + half) * 16 + 4 * g);
+                need = need || ANY_ATTEND(mw[2 * u + half]) || fminf(fminf(l4[0], l4[1]), fminf(l4[2], l4[3])) < -7000.f;
+            }
+            pair_live = __any(need);
+        }
+        uint32_t* xdst[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) xdst[half] = reinterpret_cast<uint32_t*>(xrow + ((((2 * u + half) * 4 + g) ^ xsw) << 2));   // piece = queries 16 qt + 4g .. +3
+        if (!pair_live) {
+            *reinterpret_cast<u32x2*>(xdst[0]) = (u32x2){0u, 0u};
+            *reinterpret_cast<u32x2*>(xdst[1]) = (u32x2){0u, 0u};
+            continue;
+        }
+        // S / dP tiles of both blocks: rows = queries 16qt + 4g + reg, col = key.  A = Q / dO rows (LDS), B = K / V rows (registers)
+        f32x4 s[2], dp[2];
+        f32x4 lse4[2], dl4[2];
+        u32x4 rk4[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int qa = (2 * u + half) * 16 + li;
+            s[half] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dp[half] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int off = qa * HD + (((ks * 4 + g) ^ swzk(qa)) << 3);
+                s[half] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld8(Qs + off), kf[ks], s[half], 0, 0, 0);
+                dp[half] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld8(dOs + off), vf[ks], dp[half], 0, 0, 0);
+            }
+            const int q0 = (2 * u + half) * 16 + 4 * g;
+            lse4[half] = *reinterpret_cast<const f32x4*>(lse_s + q0);
+            dl4[half] = *reinterpret_cast<const f32x4*>(dl_s + q0);
+            if (DROP) rk4[half] = *reinterpret_cast<const u32x4*>(rk_s + q0);
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const uint32_t w = mw[2 * u + half];
+            float pd4[4], ds4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // additive mask term in the log2 domain, branch-free: byte 1 -> 0, 0 -> -10000 log2 e, 2 (padding row / column) -> -inf
+                const uint32_t byte = (w >> (8 * r)) & 0xffu;
+                const float ma = byte == 2u ? -INFINITY : fmaf((float)byte, MASK_C1, -MASK_C1);
+                const float pr = __builtin_amdgcn_exp2f(fmaf(s[half][r], sc2, ma - lse4[half][r]));     // excluded -> exp2(-inf) = 0
+                float mult = 1.f;
+                if (DROP) mult = drop_mult_h(p.drop, mix32(rk4[half][r] + keyphi), kodd);
+                pd4[r] = pr * mult;
+                ds4[r] = pr * (dp[half][r] * mult - dl4[half][r]) * p.scale;
+            }
+            pdw[2 * half] = pack_f16x2(pd4[0], pd4[1]);
+            pdw[2 * half + 1] = pack_f16x2(pd4[2], pd4[3]);
+            dsw[2 * half] = pack_f16x2(ds4[0], ds4[1]);
+            dsw[2 * half + 1] = pack_f16x2(ds4[2], ds4[3]);
+            *reinterpret_cast<u32x2*>(xdst[half]) = (u32x2){dsw[2 * half], dsw[2 * half + 1]};      // dS^T block for phase 2
+        }
+        // dV^T += dO^T . Pd ; dK^T += Q^T . dS   (rows = head-dim, col = key); transposed operands by ds_read_b64_tr_b16
+        {
+            const f16x8 pdf = words_f16x8(pdw[0], pdw[1], pdw[2], pdw[3]), dsf = words_f16x8(dsw[0], dsw[1], dsw[2], dsw[3]);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                dv[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(dOs, 32 * u, 32 * u + 16, 16 * n, g, li), pdf, dv[n], 0, 0, 0);
+                dk[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(Qs, 32 * u, 32 * u + 16, 16 * n, g, li), dsf, dk[n], 0, 0, 0);
+            }
+        }
+        if (u == 0) TRACE(3);
+    }
+    TRACE(4);
+#ifdef VLP_ATTN_TRACE
+    if (wid == NT - 2 && lane == 0 && blockIdx.x < 4096) g_attn_trace[blockIdx.x * 8 + 7] = __builtin_readcyclecounter();     // a caption-key wave
+#endif
+    if (key < L) {
+        f16* drow = p.dqkv + ((int64_t)b * L + key) * p.ld_dqkv + h * HD;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const f16x4 kv = (f16x4){(f16)dk[n][0], (f16)dk[n][1], (f16)dk[n][2], (f16)dk[n][3]};
+            const f16x4 vv = (f16x4){(f16)dv[n][0], (f16)dv[n][1], (f16)dv[n][2], (f16)dv[n][3]};
+            st4_out<VLP_SS_ATTN>(drow + p.H + n * 16 + 4 * g, kv);
+            st4_out<VLP_SS_ATTN>(drow + 2 * p.H + n * 16 + 4 * g, vv);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (LDS writes only: the dK / dV stores above stay in flight across the barrier)
+    __builtin_amdgcn_s_barrier();
+    TRACE(5);
+
+    // ---- phase 2: dQ^T tiles (rows = head-dim 16 n + 4g + reg, col = query), K^T . dS^T over all keys ---------------------------------
+    // (two tiles of a wave in flight at once: the NT/2 MFMAs of a tile form one dependent chain)
+    const int nqt = (L + 15) / 16;
+    for (int t = wid; t < nqt * 4; t += 2 * NT) {
+        const int t1 = t + NT;
+        const bool two = t1 < nqt * 4;
+        const int qt0 = t >> 2, n0 = t & 3, qt1 = two ? (t1 >> 2) : qt0, n1 = two ? (t1 & 3) : n0;
+        f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kp = 0; kp < NP; ++kp) {
+            o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(Ks, 32 * kp, 32 * kp + 16, 16 * n0, g, li),
+                                                        tr_frag_dsf<LP>(dSs, 32 * kp, 32 * kp + 16, 16 * qt0, g, li), o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(Ks, 32 * kp, 32 * kp + 16, 16 * n1, g, li),
+                                                        tr_frag_dsf<LP>(dSs, 32 * kp, 32 * kp + 16, 16 * qt1, g, li), o1, 0, 0, 0);
+        }
+        const int q0 = qt0 * 16 + li, q1 = qt1 * 16 + li;
+        if (q0 < L) {
+            const f16x4 ov = (f16x4){(f16)o0[0], (f16)o0[1], (f16)o0[2], (f16)o0[3]};
+            st4_out<VLP_SS_ATTN>(p.dqkv + ((int64_t)b * L + q0) * p.ld_dqkv + h * HD + n0 * 16 + 4 * g, ov);
+        }
+        if (two && q1 < L) {
+            const f16x4 ov = (f16x4){(f16)o1[0], (f16)o1[1], (f16)o1[2], (f16)o1[3]};
+            st4_out<VLP_SS_ATTN>(p.dqkv + ((int64_t)b * L + q1) * p.ld_dqkv + h * HD + n1 * 16 + 4 * g, ov);
+        }
+    }
+    TRACE(6);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -711,6 +1235,38 @@ extern "C" int vlp_attn_bwd(const vlp_attn_bwd_args* a, void* stream) {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<NT_>, grid, block, smem_dq, s, p);                                     \
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<NT_, NW_>), grid, dim3((NW_) * 64), smem_dkv, s, p);                   \
     } while (0)
+    // one kernel for dQ, dK, dV (default since round 4); VLP_ATTN_BWD=split runs the two-kernel form (A/B runs, and the reference the
+    // merged kernel was validated against)
+    const char* bwd_env = getenv("VLP_ATTN_BWD");         // read at every launch so that tests can toggle it
+    const bool split = bwd_env && bwd_env[0] == 's';
+    if (!split) {
+        const size_t smem_one = (size_t)3 * LP * HD * 2 + (size_t)3 * LP * 4;
+#define LAUNCH_ONE(NT_, KPW_)                                                                                           \
+    do {                                                                                                             \
+        VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)attn_bwd_one_kernel<NT_, KPW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_one)); \
+        hipLaunchKernelGGL((attn_bwd_one_kernel<NT_, KPW_>), grid, dim3((NT_) / (KPW_) * 64), smem_one, s, p);       \
+    } while (0)
+        const bool xch = bwd_env && bwd_env[0] == 'x';        // VLP_ATTN_BWD=xch: the exchange-tile form at every L (A/B runs)
+        const size_t smem_full = (size_t)3 * LP * HD * 2 + (size_t)LP * LP * 2 + (size_t)3 * LP * 4;
+#define LAUNCH_FULL(NT_)                                                                                             \
+    do {                                                                                                             \
+        if (p.drop.thresh) {                                                                                         \
+            VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)attn_bwd_full_kernel<NT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_full)); \
+            hipLaunchKernelGGL((attn_bwd_full_kernel<NT_, true>), grid, dim3((NT_) * 64), smem_full, s, p);          \
+        } else {                                                                                                     \
+            VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)attn_bwd_full_kernel<NT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_full)); \
+            hipLaunchKernelGGL((attn_bwd_full_kernel<NT_, false>), grid, dim3((NT_) * 64), smem_full, s, p);         \
+        }                                                                                                            \
+    } while (0)
+        if (LP == 64) { if (xch) LAUNCH_ONE(4, 1); else LAUNCH_FULL(4); }
+        else if (LP == 128) { if (xch) LAUNCH_ONE(8, 1); else LAUNCH_FULL(8); }
+        else if (LP == 192) { if (xch) LAUNCH_ONE(12, 1); else LAUNCH_FULL(12); }
+        else LAUNCH_ONE(16, 2);                               // L > 192: dS^T (128 KB) does not fit beside Q, dO, K
+#undef LAUNCH_FULL
+#undef LAUNCH_ONE
+        VLP_CHECK_LAUNCH("vlp_attn_bwd");
+        return VLP_OK;
+    }
     if (LP == 64) LAUNCH_BWD(4, 8); else if (LP == 128) LAUNCH_BWD(8, 8);
     else if (LP == 192) { if (nw12 == 4) LAUNCH_BWD(12, 4); else LAUNCH_BWD(12, 8); }
     else LAUNCH_BWD(16, 8);
@@ -720,7 +1276,7 @@ extern "C" int vlp_attn_bwd(const vlp_attn_bwd_args* a, void* stream) {
 }
 
 // int64 [B,L,L] -> uint8 [B,L,Lp]  (1 attend, 0 masked, 2 = padding column) and, optionally, the key-major copy
-// [B,Lp,Lp] (out_t[b][key][q]; 2 wherever key >= L or q >= L)
+// [B,Lp,Lp] (row `key`, one byte per query in the lane order of maskt_pos; 2 wherever key >= L or q >= L)
 __global__ void mask_pack_kernel(const int64_t* mask, uint8_t* out, uint8_t* out_t, int L, int Lp, int B) {
     const int64_t n1 = (int64_t)B * L * Lp, n2 = out_t ? (int64_t)B * Lp * Lp : 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (int64_t)gridDim.x * blockDim.x) {
@@ -730,7 +1286,7 @@ __global__ void mask_pack_kernel(const int64_t* mask, uint8_t* out, uint8_t* out
             out[i] = c < L ? (mask[r * L + c] != 0 ? 1 : 0) : 2;
         } else {
             const int64_t j = i - n1;
-            const int q = (int)(j % Lp);
+            const int q = maskt_query((int)(j % Lp), Lp);           // key-major rows in lane order (maskt_pos)
             const int key = (int)((j / Lp) % Lp);
             const int64_t b = j / ((int64_t)Lp * Lp);
             out_t[j] = (q < L && key < L) ? (mask[(b * L + q) * L + key] != 0 ? 1 : 0) : 2;
@@ -791,7 +1347,7 @@ __global__ void mask_build_kernel(const int32_t* st, const int32_t* en, const in
             dst = out + i;
         } else {
             const int64_t j = i - n1;
-            q = (int)(j % Lp);
+            q = maskt_query((int)(j % Lp), Lp);                     // key-major rows in lane order (maskt_pos)
             k = (int)((j / Lp) % Lp);
             b = j / ((int64_t)Lp * Lp);
             dst = out_t + j;
