@@ -122,6 +122,10 @@ __global__ __launch_bounds__(LN_THREADS, NC <= 3 ? 6 : 4) void layernorm_fwd_hw_
     }
 }
 
+// (Round 4, measured and not kept: a software-pipelined form -- several pairs per wave, the next pair's row requested before the current one
+// is reduced and stored, so that reads and writes of different iterations overlap -- is SLOWER at every grid size: 12.4 us at one pair per
+// wave (7 spilled registers at the 80-register budget of 6 waves per SIMD), 13.0 / 13.5 / 15.4 / 17.1 us at 2 / 3 / 4 / 5.2 pairs per wave,
+// profiles/r04_layernorm_lab.txt.  One pair per wave with every wave resident at once stays the forward.)
 // one row per wave up to this many blocks (VLP_LN_BLOCKS overrides for A/B runs)
 static int ln_fwd_blocks(int M) {
     static int cap = 0;
@@ -327,7 +331,12 @@ static int lnb_blocks(int M) {
         if (cap < 1 || cap > LNB_BLOCKS) cap = LNB_BLOCKS;
     }
     const int blocks = cdiv(M, LNB_WAVES);
-    return blocks > cap ? cap : blocks;
+    if (blocks <= cap) return blocks;
+    // every wave the SAME number of rows: with the cap alone a wave walks M / (cap * 8) = 2.6 rows at M = 10 688 -- 61 % of the waves do
+    // three, the rest two, and the kernel ends when the three-row waves do.  R = ceil(rows per wave) rows for (almost) all of them:
+    // 446 blocks instead of 512 at M = 10 688: 14.8 -> 14.1 us plain, 18.4 -> 17.3 us with the dropped twin (profiles/r04_layernorm_lab.txt)
+    const int R = cdiv(M, cap * LNB_WAVES);
+    return cdiv(M, R * LNB_WAVES);
 }
 
 extern "C" int64_t vlp_layernorm_bwd_workspace_bytes(int32_t H) {
