@@ -285,7 +285,10 @@ def main():
                                       "fwd+bwd+FP16 FusedAdam, dropout 0.1, dynamic loss scale" % (shape_name, args.layers, args.max_len_b, args.max_len_b + 103, args.batch),
                           "global_batch": world * args.batch, "parallelism": "dp%d" % world, "final_loss": round(loss, 4),
                           "loss_scale": opt.cur_scale, "skipped_steps": opt.skipped_steps,
-                          "rccl_ranks": dist.get_world_size() if use_dist else 1, "rank_param_checksums_equal": ranks_equal},
+                          "rccl_ranks": dist.get_world_size() if use_dist else 1, "rank_param_checksums_equal": ranks_equal,
+                          # "sharded" (VLP_DDP_MODE=sharded, N > 1): reduce-scatter, Adam on 1/N of the state per rank, parameter all-gather
+                          "optimizer": "sharded" if getattr(eng, "shard_plan", None) is not None else "replicated",
+                          "param_checksum": [float(eng.flat[k].float().sum()) for k in ("decay", "nodecay")] + [float(eng.flat["decay"].float().abs().sum())]},
                "roofline": roof}
         if os.environ.get("VLP_DEBUG_TUNE") == "1":  # noqa
             from vlp_amd.engine import Engine

@@ -456,6 +456,9 @@ int vlp_bce_loss_bwd(const void* logits, int64_t ld, const void* labels_f32, int
  * check + grad norm of apex FP16_Optimizer._compute_grad_norm).  partial = f32 scratch [2048].
  */
 int vlp_sumsq(const void* g_f16, int64_t n, float* out2, float* partial, void* stream);
+/* ABI 3: the same over another range, ADDED to out2 (sum += , flag = max): the sharded optimizer step (vlp_amd/distributed.py ShardPlan)
+ * sums over the chunks a rank owns; launches of one stream run in order, so the total is reproducible. */
+int vlp_sumsq_acc(const void* g_f16, int64_t n, float* out2, float* partial, void* stream);
 
 /* apex fused_adam_cuda.adam as called by FusedAdam.step (run_img2txt_dist.py:411-420):
  *   g = g16 / (*combined_scale); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;

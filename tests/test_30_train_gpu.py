@@ -353,7 +353,7 @@ def test_entry_script_synthetic(tmp_path):
     assert os.path.exists(os.path.join(out2, "model.1.bin"))
 
 
-@pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])
+@pytest.mark.parametrize("mode", ["allreduce", "rs_ag", "sharded"])
 def test_bench_through_torchrun_and_rccl_world1(mode):
     """The launch line the driver uses for N > 1, with N = 1: RCCL process group, parameter broadcast, bucketed
     ReduceOp.AVG all-reduce hooks fired from the fused backward (mode rs_ag: reduce_scatter_tensor + all_gather_into_tensor on RCCL,
@@ -363,7 +363,7 @@ def test_bench_through_torchrun_and_rccl_world1(mode):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29517" if mode == "allreduce" else "29523", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2",
+           "--master-port", {"allreduce": "29517", "rs_ag": "29523", "sharded": "29525"}[mode], os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2",
            "--layers", "2", "--batch", "8", "--force-dist", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, VLP_DDP_MODE=mode))
     assert r.returncode == 0, r.stderr[-2000:]
@@ -371,9 +371,13 @@ def test_bench_through_torchrun_and_rccl_world1(mode):
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["final_loss"] == out["config"]["final_loss"]
     assert out["config"]["rccl_ranks"] == 1 and out["config"]["rank_param_checksums_equal"] is True
+    assert out["config"]["optimizer"] == ("sharded" if mode == "sharded" else "replicated")
 
 
-@pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])
+_WORLD2_CHECKSUMS = {}
+
+
+@pytest.mark.parametrize("mode", ["allreduce", "rs_ag", "sharded"])
 def test_bench_world2_on_one_gpu_real_engine_ddp_hooks(mode):
     """The N > 1 path of bench.py / run_img2txt_dist.py with the REAL engine: two ranks (sharing this box's single GPU, backend gloo
     because RCCL refuses two ranks on one device) drive DistributedDataParallel -- parameter broadcast, grouped wgrads announcing
@@ -384,7 +388,7 @@ def test_bench_world2_on_one_gpu_real_engine_ddp_hooks(mode):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29519" if mode == "allreduce" else "29521", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--layers", "3",
+           "--master-port", {"allreduce": "29519", "rs_ag": "29521", "sharded": "29527"}[mode], os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--layers", "3",
            "--batch", "16", "--no-cpu-baseline"]
     env = dict(os.environ, VLP_BENCH_SHARE_GPU="1", VLP_DIST_BACKEND="gloo", VLP_BENCH_CHECK_RANKS="1", VLP_DDP_MODE=mode)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
@@ -393,3 +397,12 @@ def test_bench_world2_on_one_gpu_real_engine_ddp_hooks(mode):
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2 and out["config"]["global_batch"] == 32
     assert out["value"] > 0 and out["config"]["final_loss"] == out["config"]["final_loss"]
+    # the SHARDED optimizer step (each rank updates its half of master / m / v from its reduce-scattered gradient chunk, clip norm by a
+    # 4-float all-reduce, parameters all-gathered) must leave the parameters the replicated rs_ag run leaves: the per-element update is
+    # the same kernel on the same reduced gradient; only the global gradient norm is summed in another order (two partial sums), which
+    # moves the clip factor by an ulp -- the three checksums agree to 1e-6 relative, and the ranks agree with each other bit for bit
+    assert out["config"]["optimizer"] == ("sharded" if mode == "sharded" else "replicated")
+    _WORLD2_CHECKSUMS[mode] = out["config"]["param_checksum"]
+    if "rs_ag" in _WORLD2_CHECKSUMS and "sharded" in _WORLD2_CHECKSUMS:
+        for a, b in zip(_WORLD2_CHECKSUMS["rs_ag"], _WORLD2_CHECKSUMS["sharded"]):
+            assert abs(a - b) <= 1e-6 * abs(a) + 1e-3, _WORLD2_CHECKSUMS

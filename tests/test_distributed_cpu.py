@@ -195,6 +195,19 @@ def _ddp_worker(rank, world, init_file, mode, q):
             dist.all_reduce(want_d)
             dist.all_reduce(want_n)
             eng.backward(gd, gn)
+            if mode == "sharded":
+                # reduce-scatter only: this rank's chunk of every bucket (and of the tail) holds the mean, and the plan the optimizer
+                # will use says exactly which elements those are
+                plan = eng.shard_plan
+                assert plan is not None and plan.world == world and plan.rank == rank
+                if step < 2:
+                    for lo, hi in plan.owned("decay"):
+                        assert torch.allclose(eng.gflat["decay"][lo:hi], want_d[lo:hi] / world, atol=1e-6)
+                    lo, hi = plan.owned("nodecay")[0]
+                    assert torch.allclose(eng.gflat["nodecay"][lo:hi], want_n[lo:hi] / world, atol=1e-6)
+                    assert sum(hi - lo for lo, hi in plan.owned("decay")) * world == 4096
+                continue
+            assert getattr(eng, "shard_plan", None) is None
             if step < 2:
                 assert torch.allclose(eng.gflat["decay"], want_d / world, atol=1e-6)
                 assert torch.allclose(eng.gflat["nodecay"], want_n / world, atol=1e-6)
@@ -236,6 +249,102 @@ def test_ddp_hook_wiring_world2_gloo_allreduce():
 
 def test_ddp_hook_wiring_world2_gloo_reduce_scatter_all_gather():
     _run_world2(_ddp_worker, "rs_ag")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# sharded optimizer step (VLP_DDP_MODE=sharded): partitioning, norm exchange, parameter all-gather -- with a torch stand-in
+# for the fused Adam kernel (per element the product runs the same kernel on an element range; it has no CPU form)
+# ---------------------------------------------------------------------------------------------------------------------
+def _adam_range(p32, m, v, g16, p16, lo, hi, combined, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, decay=0.01):
+    g = g16[lo:hi].float() / combined
+    m[lo:hi].mul_(b1).add_(g, alpha=1 - b1)
+    v[lo:hi].mul_(b2).add_(g * g, alpha=1 - b2)
+    p32[lo:hi].sub_(lr * (m[lo:hi] / (torch.sqrt(v[lo:hi]) + eps) + decay * p32[lo:hi]))
+    p16[lo:hi].copy_(p32[lo:hi].half())
+
+
+def _sharded_worker(rank, world, init_file, q):
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    try:
+        from vlp_amd.distributed import ShardPlan, owned_chunk
+        n_main, n_tail = 8192, 512
+        slices = [(0, 1024), (1024, 3072), (3072, 6144), (6144, 8192)]
+        scale = 1024.0
+        for clip_active in (False, True):
+            g = torch.Generator().manual_seed(7)
+            p16 = [(torch.randn(n, generator=g) * 0.05).half() for n in (n_main, n_tail)]          # identical parameters on every rank
+            gl = torch.Generator().manual_seed(100 + rank)
+            amp = (30.0 if clip_active else 0.002) * scale
+            grads = [(torch.randn(n, generator=gl) * amp / (n ** 0.5)).half() for n in (n_main, n_tail)]
+            runs = {}
+            for mode in ("rs_ag", "sharded"):
+                gm, gt = grads[0].clone(), grads[1].clone()
+                pm, pt = p16[0].clone(), p16[1].clone()
+                state = [[t.float(), torch.zeros(t.numel()), torch.zeros(t.numel())] for t in (pm, pt)]      # master, m, v
+                red = GradReducer(gm, slices, gt, None, bucket_cap_mb=0.008, mode=mode)
+                assert len(red.buckets) >= 2
+                for i in range(len(slices)):
+                    red.bucket_ready(i)
+                red.finish()
+                if mode == "rs_ag":                    # replicated step: every rank, whole buffers
+                    stats = torch.tensor([float((gm.float() ** 2).sum()), 0.0, float((gt.float() ** 2).sum()), 0.0])
+                    ranges = {"decay": [(0, n_main)], "nodecay": [(0, n_tail)]}
+                else:
+                    plan = ShardPlan(red.buckets, n_tail, slices, world, rank)
+                    # ownership: the chunks tile every bucket exactly once over the ranks
+                    for (lo, hi), (olo, ohi) in zip(red.buckets, plan.owned_main):
+                        assert (olo, ohi) == owned_chunk(lo, hi, world, rank) and (ohi - olo) * world == hi - lo
+                    assert all(plan.buckets[plan.bucket_of_slice[i]][0] <= lo and hi <= plan.buckets[plan.bucket_of_slice[i]][1]
+                               for i, (lo, hi) in enumerate(slices))
+                    ranges = {"decay": plan.owned("decay"), "nodecay": plan.owned("nodecay")}
+                    stats = torch.tensor([sum(float((gm[lo:hi].float() ** 2).sum()) for lo, hi in ranges["decay"]), 0.0,
+                                          sum(float((gt[lo:hi].float() ** 2).sum()) for lo, hi in ranges["nodecay"]), 0.0])
+                    plan.exchange_norms(stats)
+                for gi, (key, gbuf, pbuf) in enumerate((("decay", gm, pm), ("nodecay", gt, pt))):
+                    norm = float(stats[2 * gi]) ** 0.5
+                    clip = (norm / scale + 1e-6) / 1.0
+                    assert (clip > 1) == clip_active, (clip, clip_active)
+                    combined = clip * scale if clip > 1 else scale
+                    for lo, hi in ranges[key]:
+                        _adam_range(state[gi][0], state[gi][1], state[gi][2], gbuf, pbuf, lo, hi, combined)
+                if mode == "sharded":
+                    works = plan.gather_params(pm, pt)
+                    assert set(works) == {"nodecay"} | set(range(len(red.buckets)))
+                    plan.gather_state([state[0][0], state[0][1], state[0][2]], [state[1][0], state[1][1], state[1][2]])
+                runs[mode] = (pm, pt, state)
+            for a, b in zip(runs["rs_ag"][:2], runs["sharded"][:2]):
+                if clip_active:        # the global norm is summed in another order: the clip factor may move by an ulp
+                    assert torch.allclose(a.float(), b.float(), rtol=2e-3, atol=1e-6)
+                else:                  # clip inactive: bit-identical parameters
+                    assert torch.equal(a, b)
+            if not clip_active:
+                for sa, sb in zip(runs["rs_ag"][2], runs["sharded"][2]):
+                    for ta, tb in zip(sa, sb):
+                        assert torch.equal(ta, tb)      # gathered master / m / v = the replicated state
+            # every rank holds the same parameters after the sharded step
+            both = [torch.zeros_like(runs["sharded"][0]) for _ in range(world)]
+            dist.all_gather(both, runs["sharded"][0])
+            assert torch.equal(both[0], both[1])
+        # divisibility is checked at construction, not discovered per step
+        try:
+            GradReducer(torch.zeros(6146), [(0, 3073), (3073, 6146)], torch.zeros(7), None, bucket_cap_mb=0.001, mode="sharded")
+            raise AssertionError("expected ValueError")
+        except ValueError:
+            pass
+        q.put((rank, "ok"))
+    except Exception as e:   # pragma: no cover
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_optimizer_step_world2_gloo():
+    _run_world2(_sharded_worker)
+
+
+def test_ddp_hook_wiring_world2_gloo_sharded():
+    _run_world2(_ddp_worker, "sharded")
 
 
 def test_bench_self_spawn_for_n_gpus(monkeypatch):

@@ -184,6 +184,7 @@ SYMBOLS = {
     "vlp_bce_loss_fwd": (C.c_int, [vp, i64, vp, i64, i32, i32, vp, vp]),
     "vlp_bce_loss_bwd": (C.c_int, [vp, i64, vp, i64, i32, i32, vp, vp, i64, vp]),
     "vlp_sumsq": (C.c_int, [vp, i64, vp, vp, vp]),
+    "vlp_sumsq_acc": (C.c_int, [vp, i64, vp, vp, vp]),
     "vlp_fused_adam": (C.c_int, [C.POINTER(FusedAdamArgs), vp]),
     "vlp_adam_hyper": (C.c_int, [vp, vp, vp, f32, f32, vp, vp]),
     "vlp_loss_scale_update": (C.c_int, [vp, vp, vp]),
@@ -590,9 +591,10 @@ def bce_loss_bwd(logits, ld, labels, ldl, B, N, grad_scale, dlogits, ldd):
     _check(load().vlp_bce_loss_bwd(ptr(logits), ld, ptr(labels), ldl, B, N, ptr(grad_scale), ptr(dlogits), ldd, stream_ptr()))
 
 
-def sumsq(g16, n, out2, partial):
+def sumsq(g16, n, out2, partial, accumulate=False):
     _req_cuda(g16, out2, partial)
-    _check(load().vlp_sumsq(ptr(g16), n, ptr(out2), ptr(partial), stream_ptr()))
+    fn = load().vlp_sumsq_acc if accumulate else load().vlp_sumsq
+    _check(fn(ptr(g16), n, ptr(out2), ptr(partial), stream_ptr()))
 
 
 def adam_hyper(sumsq2, any_overflow, scale_state, max_grad_norm, step_size, hyper3):

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const f16* __restrict__ g, i
         partial[SQ_BLOCKS + blockIdx.x] = fmaxf(fmaxf(shb[0], shb[1]), fmaxf(shb[2], shb[3]));
     }
 }
-__global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ out2) {
+__global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ out2, int accumulate) {
     __shared__ float sh[4], shb[4];
     float s = 0.f, bad = 0.f;
     for (int i = threadIdx.x; i < nblocks; i += blockDim.x) { s += partial[i]; bad = fmaxf(bad, partial[SQ_BLOCKS + i]); }
@@ -53,11 +53,16 @@ __global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* __restri
         const float tot = sh[0] + sh[1] + sh[2] + sh[3];
         float b = fmaxf(fmaxf(shb[0], shb[1]), fmaxf(shb[2], shb[3]));
         if (!(tot <= 3.0e38f)) b = 1.f;   // the fp32 norm itself overflowed
-        out2[0] = tot;
-        out2[1] = b;
+        out2[0] = accumulate ? out2[0] + tot : tot;
+        out2[1] = accumulate ? fmaxf(out2[1], b) : b;
     }
 }
-extern "C" int vlp_sumsq(const void* g, int64_t n, float* out2, float* partial, void* stream) {
+static int sumsq_launch(const void* g, int64_t n, float* out2, float* partial, int accumulate, void* stream);
+extern "C" int vlp_sumsq(const void* g, int64_t n, float* out2, float* partial, void* stream) { return sumsq_launch(g, n, out2, partial, 0, stream); }
+// out2 += (sum of squares, flag) of another range: the sharded optimizer step sums over the chunks a rank owns (launches of one stream run
+// in order, so the sum has a fixed order: reproducible)
+extern "C" int vlp_sumsq_acc(const void* g, int64_t n, float* out2, float* partial, void* stream) { return sumsq_launch(g, n, out2, partial, 1, stream); }
+static int sumsq_launch(const void* g, int64_t n, float* out2, float* partial, int accumulate, void* stream) {
     VLP_CHECK_ARG(g && out2 && partial && n > 0 && (uintptr_t)g % 16 == 0, "vlp_sumsq: bad args (partial must hold 2048 floats)");
     VLP_ENTER(g, "vlp_sumsq");
     int blocks = (int)((n / 8 + 255) / 256);
@@ -66,7 +71,7 @@ extern "C" int vlp_sumsq(const void* g, int64_t n, float* out2, float* partial, 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, s, (const f16*)g, n, partial);
     VLP_CHECK_LAUNCH("vlp_sumsq");
-    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, s, partial, blocks, out2);
+    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, s, partial, blocks, out2, accumulate);
     VLP_CHECK_LAUNCH("vlp_sumsq(finish)");
     return VLP_OK;
 }

@@ -20,6 +20,13 @@ autograd graph, so the reducer lives here instead:
     section 5 / 8e: on point-to-point xGMI a direct reduce-scatter/all-gather uses all 7 links of a GPU, a ring is bound by one);
     same result up to fp16 summation order.  No scaling curve has been measured yet (the driver owns the 8-GPU runs), so
     all-reduce stays the default.
+  * `VLP_DDP_MODE=sharded` (opt-in, round 4): reduce-scatter ONLY -- rank r keeps the mean of chunk r of every bucket -- and the
+    optimizer step is sharded over the ranks (`ShardPlan`, used by FP16_Optimizer_State): each rank runs the grad-norm partial and the
+    fused Adam update on its 1/W of master / m / v (1.39 GB of state and 0.62 ms of HBM-bound update per step shrink by W), the clip
+    norm and the overflow flag are ONE 4-float all-reduce, and the updated fp16 PARAMETERS are all-gathered bucket by bucket (the same
+    bytes as the gradient all-gather they replace) with per-bucket waits in the next forward.  The update arithmetic per element is the
+    unsharded kernel's; parameters are bit-identical to the unsharded rs_ag run whenever the clip is inactive (the global norm is
+    summed in another order).  Unmeasured on more than one GPU (world 2 over gloo on CPU and on one GPU, world 1 over RCCL).
 """
 import os
 
@@ -56,37 +63,48 @@ class GradReducer(object):
         mode: "allreduce" (default) | "rs_ag" (env VLP_DDP_MODE)."""
         self.flat_main, self.flat_tail, self.pg = flat_main, flat_tail, process_group
         self.mode = mode or os.environ.get("VLP_DDP_MODE", "allreduce")
-        if self.mode not in ("allreduce", "rs_ag"):
-            raise ValueError("VLP_DDP_MODE must be 'allreduce' or 'rs_ag', got %r" % self.mode)
+        if self.mode not in ("allreduce", "rs_ag", "sharded"):
+            raise ValueError("VLP_DDP_MODE must be 'allreduce', 'rs_ag' or 'sharded', got %r" % self.mode)
         self.world = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
         cap = int(bucket_cap_mb * 1024 * 1024 / flat_main.element_size())
         self.buckets, self.fire_at = coalesce_buckets(slices, cap)
+        if self.mode != "allreduce":
+            # every bucket (and the tail) is cut into `world` equal chunks: checked HERE, not discovered per step (the engine lays
+            # parameters out on 64-element boundaries, so any power-of-two world up to 64 divides)
+            sizes = [hi - lo for lo, hi in self.buckets] + ([flat_tail.numel()] if flat_tail is not None else [])
+            bad = [n for n in sizes if n % self.world]
+            if bad:
+                raise ValueError("VLP_DDP_MODE=%s: bucket sizes %r are not divisible by the world size %d" % (self.mode, bad, self.world))
         self._avg = dist.get_backend(process_group) == "nccl"
         self._work = []
 
     def _reduce(self, t):
-        if self.mode == "rs_ag" and t.numel() % self.world == 0:      # (also with one rank: the same RCCL calls, a path check)
-            self._reduce_rs_ag(t)
+        if self.mode != "allreduce":                 # (also with one rank: the same RCCL calls, a path check)
+            self._reduce_rs_ag(t, gather=self.mode == "rs_ag")
         elif self._avg:
             self._work.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.pg, async_op=True), None))
         else:
             self._work.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), t))
 
-    def _reduce_rs_ag(self, t):
+    def _reduce_rs_ag(self, t, gather=True):
         """Bucket = W equal chunks; rank r ends up owning the mean of chunk r (reduce-scatter, in place on its own chunk), then
-        every rank gathers all chunks (all-gather, in place).  Both collectives are asynchronous on RCCL's stream; the all-gather
-        is ordered after the reduce-scatter by that stream."""
-        W, r = self.world, dist.get_rank(self.pg)
+        (gather=True) every rank gathers all chunks (all-gather, in place).  Both collectives are asynchronous on RCCL's stream; the
+        all-gather is ordered after the reduce-scatter by that stream.  gather=False (sharded optimizer): the other chunks are left
+        as they are -- nobody reads them, the owner of each chunk updates its parameters from it."""
+        W, r = self.world, self.rank
         chunks = t.view(W, -1)
         if self._avg:
             self._work.append((dist.reduce_scatter_tensor(chunks[r], t, op=dist.ReduceOp.AVG, group=self.pg, async_op=True), None))
-            self._work.append((dist.all_gather_into_tensor(t, chunks[r], group=self.pg, async_op=True), None))
+            if gather:
+                self._work.append((dist.all_gather_into_tensor(t, chunks[r], group=self.pg, async_op=True), None))
         else:
             # gloo (CPU tests) has no reduce-scatter: W rooted reductions are the same data movement, then scale the owned chunk
             for dst in range(W):
                 dist.reduce(chunks[dst], dst=dist.get_global_rank(self.pg, dst) if self.pg is not None else dst, op=dist.ReduceOp.SUM, group=self.pg)
             chunks[r].div_(W)
-            dist.all_gather_into_tensor(t, chunks[r].clone(), group=self.pg)
+            if gather:
+                dist.all_gather_into_tensor(t, chunks[r].clone(), group=self.pg)
 
     def bucket_ready(self, slice_index):
         b = self.fire_at.get(slice_index)
@@ -102,6 +120,67 @@ class GradReducer(object):
             if t is not None:
                 t.div_(self.world)
         self._work = []
+
+
+def owned_chunk(lo, hi, world, rank):
+    """Element range of chunk `rank` of the bucket [lo, hi) cut into `world` equal chunks."""
+    n = (hi - lo) // world
+    return lo + rank * n, lo + (rank + 1) * n
+
+
+class ShardPlan(object):
+    """Who owns what in the sharded optimizer step (VLP_DDP_MODE=sharded).  Pure bookkeeping over element ranges -- it runs on CPU
+    tensors over gloo exactly as on the GPU over RCCL, so the partitioning, the norm exchange and the parameter all-gather are
+    covered by the world-2 CPU tests with a torch stand-in for the update kernel."""
+
+    def __init__(self, buckets, tail_numel, slices, world, rank, process_group=None):
+        """buckets: coalesced [(lo, hi)] of the main (decay) buffer in completion order; tail_numel: size of the no-decay buffer;
+        slices: the engine's ready-slices (to map `wait_params(slice index)` of the next forward onto a bucket)."""
+        self.buckets, self.world, self.rank, self.pg = list(buckets), world, rank, process_group
+        self.tail = (0, tail_numel)
+        self.owned_main = [owned_chunk(lo, hi, world, rank) for lo, hi in self.buckets]
+        self.owned_tail = owned_chunk(0, tail_numel, world, rank)
+        self.bucket_of_slice = {}
+        for i, (lo, hi) in enumerate(slices):
+            self.bucket_of_slice[i] = [b for b, (blo, bhi) in enumerate(self.buckets) if blo <= lo and hi <= bhi][0]
+
+    def owned(self, key):
+        """[(lo, hi)] owned by this rank in the flat buffer `key` ("decay" | "nodecay")."""
+        return list(self.owned_main) if key == "decay" else [self.owned_tail]
+
+    def exchange_norms(self, stats):
+        """stats: f32 [2 * groups] = (sum of squares, overflow flag) per param group over the OWNED ranges, in place -> the same over
+        all ranks (flags add up: > 0 means some rank saw inf / nan).  One small all-reduce per step."""
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.pg)
+        return stats
+
+    def gather_params(self, flat_main, flat_tail):
+        """All-gather the updated parameter chunks, bucket by bucket in the order the next forward reads them (no-decay buffer first,
+        then the LAST bucket -- embeddings / region projections -- down to bucket 0, the task head).  Returns {"nodecay" | bucket:
+        work-or-None}; the engine waits per bucket (Engine.wait_params)."""
+        works = {}
+        nccl = dist.get_backend(self.pg) == "nccl"
+
+        def gather(t):
+            chunks = t.view(self.world, -1)
+            if nccl:
+                return dist.all_gather_into_tensor(t, chunks[self.rank], group=self.pg, async_op=True)
+            dist.all_gather_into_tensor(t, chunks[self.rank].clone(), group=self.pg)      # gloo: no in-place aliasing
+            return None
+        works["nodecay"] = gather(flat_tail)
+        for b in reversed(range(len(self.buckets))):
+            lo, hi = self.buckets[b]
+            works[b] = gather(flat_main[lo:hi])
+        return works
+
+    def gather_state(self, tensors_main, tensors_tail):
+        """Checkpointing: every rank's fp32 master / m / v are only current on its own chunks -- gather them (blocking; rare)."""
+        for t in tensors_main:
+            for lo, hi in self.buckets:
+                sl = t[lo:hi]
+                dist.all_gather_into_tensor(sl, sl.view(self.world, -1)[self.rank].clone(), group=self.pg)
+        for t in tensors_tail:
+            dist.all_gather_into_tensor(t, t.view(self.world, -1)[self.rank].clone(), group=self.pg)
 
 
 class DistributedDataParallel(nn.Module):
@@ -121,6 +200,11 @@ class DistributedDataParallel(nn.Module):
         self.reducer = GradReducer(eng.gflat["decay"], eng.buckets, eng.gflat["nodecay"], process_group, bucket_cap_mb)
         eng.grad_ready_hook = self.reducer.bucket_ready
         eng.post_backward_hook = self.reducer.finish
+        # sharded optimizer step: the optimizer (FP16_Optimizer_State) finds the plan on the engine
+        eng.shard_plan = None
+        if self.reducer.mode == "sharded":
+            eng.shard_plan = ShardPlan(self.reducer.buckets, eng.gflat["nodecay"].numel(), eng.buckets, self.reducer.world, self.reducer.rank,
+                                       process_group)
 
     def forward(self, *inputs, **kwargs):
         return self.module(*inputs, **kwargs)

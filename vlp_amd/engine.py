@@ -87,6 +87,8 @@ class Engine(object):
         self._opt_stream = None           # optimizer stream of the pipelined FusedAdam step (optimization_fp16._step_pipelined)
         self._param_events = None         # {"nodecay" | bucket index: event} of the last pipelined optimizer step, consumed by forward
         self._params_done = None          # event behind its last chunk
+        self.shard_plan = None            # vlp_amd.distributed.ShardPlan when the optimizer step is sharded over the ranks (VLP_DDP_MODE=sharded)
+        self._param_works = None          # {"nodecay" | reducer bucket: collective work} of the last sharded step's parameter all-gather
         self._side = None                 # second HIP stream for the layer wgrads (created on first use)
         self._side_busy = False           # True while backward may have work queued on it
         self._prof_ctr = 0
@@ -229,6 +231,19 @@ class Engine(object):
     def wait_params(self, key=None, host=False):
         """Make the current stream (host=True: the calling thread) wait until the optimizer stream has written parameter chunk `key`
         ("nodecay" or a bucket index); key=None: all of them (also orders the optimizer's reads of the gradient buffers before later work)."""
+        if self._param_works is not None:          # sharded step: parameter chunks arrive by all-gather, one collective per bucket
+            works = self._param_works
+            if key is None:
+                for w in works.values():
+                    if w is not None:
+                        w.wait()                   # (RCCL: the current stream waits; no host sync)
+                self._param_works = None
+            else:
+                k = key if key == "nodecay" else self.shard_plan.bucket_of_slice[key]
+                w = works.get(k)
+                if w is not None:
+                    w.wait()
+                    works[k] = None
         if self._params_done is None:
             return
         if key is None:
@@ -1020,6 +1035,9 @@ class Engine(object):
         p, pa = st.p_drop
         M, Mv = B * L, B * Nv
         beta = 1 if self.grads_dirty else 0
+        if beta and self.shard_plan is not None:
+            raise RuntimeError("vlp_amd: VLP_DDP_MODE=sharded keeps only this rank's chunk of the reduced gradient, so gradients cannot be "
+                               "accumulated over several backward passes (--gradient_accumulation_steps > 1); use allreduce or rs_ag")
         img, input_ids, token_type_ids, masked_pos = st.batch
         self.wait_params()           # the optimizer stream has read the previous gradients and written every parameter
         if getattr(self, "_shadow_ev", None) is not None:

@@ -179,8 +179,47 @@ class FP16_Optimizer_State(object):
     def zero_grad(self, set_grads_to_None=True):
         self.engine.zero_grad()
 
+    def _step_sharded(self, plan):
+        """The optimizer step sharded over the data-parallel ranks (vlp_amd.distributed.ShardPlan, VLP_DDP_MODE=sharded).  After the
+        reduce-scatter rank r holds the mean gradient of chunk r of every bucket: it squares-and-sums those chunks, the per-group
+        (sum, overflow) pairs of all ranks meet in ONE 4-float all-reduce (so every rank derives the same clip factor and the same
+        skip decision), it runs the fused Adam kernel on its chunks of master / m / v only, and the updated fp16 parameters are
+        all-gathered bucket by bucket (the bytes of the gradient all-gather this replaces); the next forward waits per bucket.  Per
+        element the arithmetic is the unsharded kernel's."""
+        eng = self.engine
+        eng.wait_params()
+        for i, key in enumerate(self._group_key):
+            first = True
+            for lo, hi in plan.owned(key):
+                K.sumsq(eng.gflat[key][lo:hi], hi - lo, self._sumsq[i], self._partial, accumulate=not first)
+                first = False
+        stats = torch.cat(self._sumsq)                      # [sum0, flag0, sum1, flag1]
+        plan.exchange_norms(stats)
+        for i in range(len(self._group_key)):
+            self._sumsq[i].copy_(stats[2 * i:2 * i + 2])
+        torch.maximum(self._sumsq[0][1:2], self._sumsq[1][1:2], out=self._ovf)
+        for i, key in enumerate(self._group_key):
+            g = self.param_groups[i]
+            K.adam_hyper(self._sumsq[i], self._ovf, self._scale_state, g["max_grad_norm"], self._step_size(g), self._hyper[i])
+            for lo, hi in plan.owned(key):
+                self._adam_range(i, key, lo, hi)
+        K.loss_scale_update(self._scale_state, self._ovf)
+        eng._param_works = plan.gather_params(eng.flat["decay"], eng.flat["nodecay"])
+
+    def _gather_sharded_state(self):
+        """Before a checkpoint: master / m / v are current only on this rank's chunks."""
+        plan = getattr(self.engine, "shard_plan", None)
+        if plan is None:
+            return
+        self.engine.wait_params()
+        i_d, i_nd = self._group_key.index("decay"), self._group_key.index("nodecay")
+        plan.gather_state([self.fp32_groups_flat[i_d], self._m[i_d], self._v[i_d]], [self.fp32_groups_flat[i_nd], self._m[i_nd], self._v[i_nd]])
+
     def step(self, closure=None):
         eng = self.engine
+        plan = getattr(eng, "shard_plan", None)
+        if plan is not None:
+            return self._step_sharded(plan)
         if self.pipeline_with_forward:
             return self._step_pipelined()
         eng.wait_params()                        # a previous pipelined step may still be writing
@@ -245,6 +284,7 @@ class FP16_Optimizer_State(object):
 
     # ---- checkpointing (optimization_fp16.py:17-80) ----------------------------------------------------------
     def state_dict(self):
+        self._gather_sharded_state()
         self._sync()
         sd = {"dynamic_loss_scale": self.dynamic_loss_scale, "cur_scale": self.cur_scale, "cur_iter": self.cur_iter}
         if self.dynamic_loss_scale:
@@ -287,6 +327,7 @@ class FP16_Optimizer_State(object):
         is a torch Optimizer whose param groups each hold ONE parameter -- the group's flat fp32 master -- so
         optimizer_state_dict = {state: {gid: {step, exp_avg, exp_avg_sq}}, param_groups: [{..., params: [gid]}]} with dense flat tensors in
         the caller's parameter order, and fp32_groups_flat likewise.  An optim.N.bin saved from this dict loads into the reference."""
+        self._gather_sharded_state()
         self._sync()
         sd = {"dynamic_loss_scale": self.dynamic_loss_scale, "cur_scale": self.cur_scale, "cur_iter": self.cur_iter}
         if self.dynamic_loss_scale:
