@@ -201,6 +201,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
     __syncthreads();
     TRACE(2);
 
+    // (Round 4, measured and not kept: requesting the Q fragments + mask words of the wave's NEXT query tile while the current one is
+    // computed -- 149 instead of 108 VGPRs, same 3 workgroups per CU -- 36.5 us against 34.3 us at B = 64, tools/attn_lab.py.)
     const int nqt = (Lq + 15) / 16;
     for (int qt = wid; qt < nqt; qt += NW) {
         const int q = qt * 16 + li;             // this lane's query (column of every transposed tile)
