@@ -122,13 +122,30 @@ def cpu_baseline_worker(seconds_budget, threads, B=16):
         ref_equiv = round(B * n / dt * d["reference_over_port"], 3)
     except Exception:      # noqa: BLE001
         pass
-    return {"value": round(B * n / dt, 3), "unit": "samples/s", "cores": threads, "kind": "port", "reference_code": False, "batch": B,
-            "reference_equivalent_value": ref_equiv,      # value x (reference / port speed ratio measured in the build container); derived, not timed here
-            "sample": "%d steps of B=%d, L=167, 12 layers, fp32 fwd+bwd+BertAdam (oracle/vlp_oracle.py), %d of %d host threads%s"
-                      % (n, B, threads, os.cpu_count() or 1, tie)}
+    out = {"value": round(B * n / dt, 3), "unit": "samples/s", "cores": threads, "kind": "port", "reference_code": False, "batch": B,
+           "reference_equivalent_value": ref_equiv,      # value x (reference / port speed ratio measured in the build container); derived, not timed here
+           "sample": "%d steps of B=%d, L=167, 12 layers, fp32 fwd+bwd+BertAdam (oracle/vlp_oracle.py), %d of %d host threads%s"
+                     % (n, B, threads, os.cpu_count() or 1, tie)}
+    # BASELINE.md section 3 also names B = 64 (the GPU workload's own batch): one warm-up + one timed step of the same port, same threads
+    # (a step is ~8 s of CPU work at this size; bounded so that the default bench.py run still finishes within minutes)
+    try:
+        batch = S.make_batch(64, max_len_b=64, vocab_size=28996, max_pred=3, seed=1234)
+        t0 = time.time()
+        step()
+        w64 = time.time() - t0
+        if w64 < 20.0:
+            t0 = time.time()
+            step()
+            d64, kind64 = time.time() - t0, "1 timed step after 1 warm-up"
+        else:
+            d64, kind64 = w64, "the first step (no warm-up: it alone took %.0f s)" % w64
+        out["b64"] = {"value": round(64 / d64, 3), "unit": "samples/s", "batch": 64, "cores": threads, "sample": kind64}
+    except Exception as e:      # noqa: BLE001
+        out["b64"] = {"value": None, "sample": "failed: %r" % (e,)}
+    return out
 
 
-def cpu_baseline(seconds_budget=25.0, hard_timeout=150.0):
+def cpu_baseline(seconds_budget=20.0, hard_timeout=200.0):
     """Runs the worker in a fresh process (no HIP context, bounded wall time)."""
     import subprocess
     threads = min(os.cpu_count() or 1, 32)
