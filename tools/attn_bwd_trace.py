@@ -32,6 +32,8 @@ for i, n in enumerate(names):
     d = t[:, i + 1] - t[:, i]
     print("%-44s median %7d  p10 %7d  p90 %7d ticks" % (n, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
 d = t[:, 7] - t[:, 2]
-print("%-44s median %7d  p10 %7d  p90 %7d ticks" % ("phase 1 of wave NT-2 (caption keys)", np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
+for w in range(12):          # workgroup b recorded the end of phase 1 of its wave b % 12 (key tile w)
+    dw = d[np.arange(len(d)) % 12 == w]
+    print("phase 1 of the wave owning key tile %2d        median %7d  p10 %7d  p90 %7d ticks" % (w, np.median(dw), np.percentile(dw, 10), np.percentile(dw, 90)))
 tot = t[:, 6] - t[:, 0]
 print("%-44s median %7d  p10 %7d  p90 %7d ticks" % ("whole workgroup (wave 0)", np.median(tot), np.percentile(tot, 10), np.percentile(tot, 90)))

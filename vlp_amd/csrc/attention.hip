@@ -969,7 +969,8 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
         for (int i = 0; i < ST; ++i) {
             const int r = tid + i * NTHR;
             if (r < LP) {
-                lse_s[r] = lse_v[i] * LOG2E_F;
+                // padding rows (r >= L): +inf, so that every probability of the row comes out as exp2(-inf) = 0 without a per-element test
+                lse_s[r] = r < L ? lse_v[i] * LOG2E_F : INFINITY;
                 rk_s[r] = p.drop.thresh ? drop_rowkey(p.drop, (uint64_t)(((int64_t)b * p.heads + h) * L + min(r, L - 1))) : 0u;   // dropout element = (row (b, h, q), col key)
             }
         }
@@ -988,6 +989,12 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
     const int nkt = (L + 15) / 16;
     const uint32_t keyphi = ((uint32_t)key >> 1) * VLP_PHI, kodd = (uint32_t)key & 1u;
     const float sc2 = p.scale * LOG2E_F;
+    // additive mask term in the log2 domain WITHOUT a per-element padding test: byte b in {0, 1} -> b * C1 + kmbase with kmbase = -C1 for a
+    // real key; a padding key (>= L) has kmbase = -inf, a padding query row has lse = +inf (above): their byte is 2, and 2 C1 - inf = -inf /
+    // C1 - (+inf) = -inf -- every excluded probability is exp2(-inf) = 0 and multiplies finite numbers only (dO, Q rows >= L are zero)
+    const float kmbase = key < L ? -MASK_C1 : -INFINITY;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));      // pairs of elements: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (the phase is VALU-issue bound)
+    const f32x2 sc2v = (f32x2){sc2, sc2}, c1v = (f32x2){MASK_C1, MASK_C1}, kbv = (f32x2){kmbase, kmbase}, scv = (f32x2){p.scale, p.scale};
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) { dk[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -1021,7 +1028,7 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
         // S / dP tiles of both blocks: rows = queries 16qt + 4g + reg, col = key.  A = Q / dO rows (LDS), B = K / V rows (registers)
         f32x4 s[2], dp[2];
         f32x4 lse4[2], dl4[2];
-        u32x4 rk4[2];
+        u32x2 rk2[2];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int qa = (2 * u + half) * 16 + li;
@@ -1036,22 +1043,41 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
             const int q0 = (2 * u + half) * 16 + 4 * g;
             lse4[half] = *reinterpret_cast<const f32x4*>(lse_s + q0);
             dl4[half] = *reinterpret_cast<const f32x4*>(dl_s + q0);
-            if (DROP) rk4[half] = *reinterpret_cast<const u32x4*>(rk_s + q0);
+            // dropout: the hash of (query row, key PAIR) serves both keys of the pair (low / high 16 bits), and the two keys of a pair sit in
+            // ADJACENT lanes here: the even-key lane hashes rows q0, q0 + 1, the odd-key lane rows q0 + 2, q0 + 3, and they swap (DPP quad_perm)
+            // the 16-bit halves the other one needs -- 2 hashes per lane and block instead of 4 identical pairs of them
+            if (DROP) rk2[half] = *reinterpret_cast<const u32x2*>(rk_s + q0 + 2 * (int)kodd);
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const uint32_t w = mw[2 * u + half];
             float pd4[4], ds4[4];
+            f32x2 multp[2] = {(f32x2){1.f, 1.f}, (f32x2){1.f, 1.f}};      // dropout multipliers of the element pairs (r = 0, 1) and (r = 2, 3)
+            if (DROP) {
+                const uint32_t h0 = mix32(rk2[half][0] + keyphi), h1 = mix32(rk2[half][1] + keyphi);
+                const uint32_t sh_mine = 16u * kodd, sh_other = 16u - sh_mine;         // my key's half of a hash / my neighbour's
+                const uint32_t m0 = __builtin_amdgcn_ubfe(h0, sh_mine, 16u), m1 = __builtin_amdgcn_ubfe(h1, sh_mine, 16u);
+                const uint32_t o0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)__builtin_amdgcn_ubfe(h0, sh_other, 16u), 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
+                const uint32_t o1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)__builtin_amdgcn_ubfe(h1, sh_other, 16u), 0xB1, 0xF, 0xF, true);
+                const f32x2 mine = (f32x2){m0 < p.drop.thresh ? 0.f : p.drop.scale, m1 < p.drop.thresh ? 0.f : p.drop.scale};
+                const f32x2 other = (f32x2){o0 < p.drop.thresh ? 0.f : p.drop.scale, o1 < p.drop.thresh ? 0.f : p.drop.scale};
+                multp[0] = kodd ? other : mine;           // rows q0, q0 + 1 were hashed by the even-key lane
+                multp[1] = kodd ? mine : other;
+            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // additive mask term in the log2 domain, branch-free: byte 1 -> 0, 0 -> -10000 log2 e, 2 (padding row / column) -> -inf
-                const uint32_t byte = (w >> (8 * r)) & 0xffu;
-                const float ma = byte == 2u ? -INFINITY : fmaf((float)byte, MASK_C1, -MASK_C1);
-                const float pr = __builtin_amdgcn_exp2f(fmaf(s[half][r], sc2, ma - lse4[half][r]));     // excluded -> exp2(-inf) = 0
-                float mult = 1.f;
-                if (DROP) mult = drop_mult_h(p.drop, mix32(rk4[half][r] + keyphi), kodd);
-                pd4[r] = pr * mult;
-                ds4[r] = pr * (dp[half][r] * mult - dl4[half][r]) * p.scale;
+            for (int jp = 0; jp < 2; ++jp) {         // element pairs (r = 2 jp, 2 jp + 1)
+                const int r0 = 2 * jp, r1 = 2 * jp + 1;
+                const f32x2 bytes = (f32x2){(float)((w >> (8 * r0)) & 0xffu), (float)((w >> (8 * r1)) & 0xffu)};      // v_cvt_f32_ubyteN
+                const f32x2 ma = bytes * c1v + kbv;
+                const f32x2 sv = (f32x2){s[half][r0], s[half][r1]};
+                const f32x2 arg = sv * sc2v + (ma - (f32x2){lse4[half][r0], lse4[half][r1]});
+                const f32x2 pr = (f32x2){__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+                const f32x2 mult = multp[jp];
+                const f32x2 pd = pr * mult;
+                const f32x2 t = (f32x2){dp[half][r0], dp[half][r1]} * mult - (f32x2){dl4[half][r0], dl4[half][r1]};
+                const f32x2 ds = (pr * t) * scv;
+                pd4[r0] = pd[0]; pd4[r1] = pd[1];
+                ds4[r0] = ds[0]; ds4[r1] = ds[1];
             }
             pdw[2 * half] = pack_f16x2(pd4[0], pd4[1]);
             pdw[2 * half + 1] = pack_f16x2(pd4[2], pd4[3]);
@@ -1072,7 +1098,7 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
     }
     TRACE(4);
 #ifdef VLP_ATTN_TRACE
-    if (wid == NT - 2 && lane == 0 && blockIdx.x < 4096) g_attn_trace[blockIdx.x * 8 + 7] = __builtin_readcyclecounter();     // a caption-key wave
+    if (wid == (int)(blockIdx.x % NT) && lane == 0 && blockIdx.x < 4096) g_attn_trace[blockIdx.x * 8 + 7] = __builtin_readcyclecounter();     // end of phase 1 of wave blockIdx % NT
 #endif
     if (key < L) {
         f16* drow = p.dqkv + ((int64_t)b * L + key) * p.ld_dqkv + h * HD;
