@@ -463,6 +463,18 @@ def test_attention_fwd_bwd(B, L, Nv, heads, gen):
         assert rel(outs[0][:, 1].float(), outs[1][:, 1].float()) < 2e-3                     # dK: delta is summed in another lane order
         assert rel(outs[0][:, 0].float(), outs[1][:, 0].float()) < 2e-3
         assert torch.equal(outs[0], outs[2])                                                # the two one-kernel forms: same chains everywhere
+        # the default kernel is PERSISTENT (one workgroup per CU walks several (batch, head) items, the next item's Q / dO prefetched into
+        # registers): with 5 workgroups every one of them walks several items here; one workgroup per item (grid 0) must give the same bits
+        for cap in ("5", "0"):
+            os.environ["VLP_ATTN_BWD_GRID"] = cap
+            try:
+                c2, l2 = torch.zeros_like(ctx), torch.zeros_like(lse)
+                d2, dl2 = torch.zeros_like(dqkv), torch.zeros_like(delta)
+                K.attn_fwd(qkv, mb, c2, l2, B, L, heads, 0.125, dropout_p=pdrop, seed=11, rng_stream=3)
+                K.attn_bwd(qkv, mb, mt, c2, dctx, l2, d2, dl2, B, L, heads, 0.125, dropout_p=pdrop, seed=11, rng_stream=3)
+                assert torch.equal(d2.view(B * L, 3, H), outs[0]), cap
+            finally:
+                os.environ.pop("VLP_ATTN_BWD_GRID", None)
 
 
 def test_attention_dropout_exact_mask(gen):

@@ -891,37 +891,55 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
     uint32_t* rk_s = reinterpret_cast<uint32_t*>(dl_s + LP);   // [LP] dropout row keys of the queries
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, li = lane & 15;
-    const int b = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
+    const int g0 = lane >> 4, li0 = lane & 15;
     const int L = p.L;
-    const f16* qbase = p.qkv + (int64_t)b * L * p.ld_qkv + h * HD;
-    const f16* kbase = qbase + p.H;
-    const f16* vbase = qbase + 2 * p.H;
-    const f16* dobase = p.dctx + (int64_t)b * L * p.ld_dctx + h * HD;
-    const f16* obase = p.ctx + (int64_t)b * L * p.ld_ctx + h * HD;
-
-    TRACE(0);
-    // ---- prologue: EVERY global load of the workgroup is issued before the first one is consumed (one memory round trip, not four: the
-    // first build staged, then fetched lse, then the V rows, then the mask words behind scalar branches -- 18 000 cycles of the 39 000 a
-    // workgroup takes).  Q, dO, K -> LDS; delta from the dO / O pieces on the way.
+    const int nitems = p.B * p.heads;
     const int kt = wid;
-    const int key = kt * 16 + li;
+    const int key = kt * 16 + li0;
     constexpr int IT = (LP * 8 + NTHR - 1) / NTHR;
     constexpr int ST = (LP + NTHR - 1) / NTHR;           // row statistics per thread (1 unless the workgroup has fewer threads than rows)
-    u32x4 vq[IT], vd[IT], vo[IT], vk[IT];
-    float lse_v[ST];
-    f16x8 kf[2], vf[2];
-    uint32_t mw[NT];                                      // mask bytes of this lane's key for ALL queries (word t = queries 16 t + 4g .. +3)
-    {
-        const __amdgpu_buffer_rsrc_t rq = rows_rsrc(qbase, p.ld_qkv, L), rdo = rows_rsrc(dobase, p.ld_dctx, L), ro = rows_rsrc(obase, p.ld_ctx, L),
-                                     rkk = rows_rsrc(kbase, p.ld_qkv, L);
+    // PERSISTENT over (batch, head) items: item, item + gridDim.x, ... (the launcher starts one workgroup per CU).  With one workgroup per CU
+    // nothing else hides an item's load prologue (Q, dO, K, O: 96 KB per item, ~7 us per round when every CU loads at once; 45 % of a
+    // workgroup's time in the phase trace of the one-item form).  The NEXT item's Q and dO tiles are requested into registers (vq / vd) right
+    // after the current item's have been written to LDS, travel under its two compute phases, and are stored when phase 2 has released the LDS.
+    // (Q and dO only: with all four tiles -- 32 more registers per lane across both compute phases -- the NT = 12 instantiation spilled 120
+    // registers at the 168-register budget of 3 waves per SIMD; K and O are requested at the head of their item, with the V rows, lse and mask words)
+    u32x4 vq[IT], vd[IT];
+    auto request_tiles = [&](int it) {
+        const int b_ = it / p.heads, h_ = it % p.heads;
+        const __amdgpu_buffer_rsrc_t rq = rows_rsrc(p.qkv + (int64_t)b_ * L * p.ld_qkv + h_ * HD, p.ld_qkv, L),
+                                     rdo = rows_rsrc(p.dctx + (int64_t)b_ * L * p.ld_dctx + h_ * HD, p.ld_dctx, L);
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             const int idx = tid + i * NTHR, r = idx >> 3, c = idx & 7;
             vq[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, (r * (int)p.ld_qkv + c * 8) * 2, 0, 0);
             vd[i] = __builtin_amdgcn_raw_buffer_load_b128(rdo, (r * (int)p.ld_dctx + c * 8) * 2, 0, 0);
-            vo[i] = __builtin_amdgcn_raw_buffer_load_b128(ro, (r * (int)p.ld_ctx + c * 8) * 2, 0, 0);
+        }
+    };
+    if ((int)blockIdx.x < nitems) request_tiles(blockIdx.x);
+#pragma unroll 1
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int b = item / p.heads, h = item % p.heads;
+    int g = g0, li = li0;                    // opaque per-item copies: the LDS address math of the unrolled pair loop is item-invariant, and hoisted
+    asm volatile("" : "+v"(g), "+v"(li));    // out of the item loop it would occupy ~60 registers across both phases (spills at the 168-register budget)
+    const f16* vbase = p.qkv + (int64_t)b * L * p.ld_qkv + h * HD + 2 * p.H;
+
+    if (item == (int)blockIdx.x) TRACE(0);
+    // ---- prologue: EVERY global load of the item is issued before the first one is consumed (one memory round trip, not four: the
+    // first build staged, then fetched lse, then the V rows, then the mask words behind scalar branches -- 18 000 cycles of the 39 000 a
+    // workgroup takes).  Q, dO, K -> LDS; delta from the dO / O pieces on the way.
+    float lse_v[ST];
+    f16x8 kf[2], vf[2];
+    uint32_t mw[NT];                                      // mask bytes of this lane's key for ALL queries (word t = queries 16 t + 4g .. +3)
+    u32x4 vo[IT], vk[IT];
+    {
+        const __amdgpu_buffer_rsrc_t ro = rows_rsrc(p.ctx + (int64_t)b * L * p.ld_ctx + h * HD, p.ld_ctx, L),
+                                     rkk = rows_rsrc(p.qkv + (int64_t)b * L * p.ld_qkv + h * HD + p.H, p.ld_qkv, L);
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int idx = tid + i * NTHR, r = idx >> 3, c = idx & 7;
             vk[i] = __builtin_amdgcn_raw_buffer_load_b128(rkk, (r * (int)p.ld_qkv + c * 8) * 2, 0, 0);
+            vo[i] = __builtin_amdgcn_raw_buffer_load_b128(ro, (r * (int)p.ld_ctx + c * 8) * 2, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < ST; ++i) lse_v[i] = p.lse[((int64_t)b * p.heads + h) * L + min(tid + i * NTHR, L - 1)];
@@ -975,15 +993,16 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
             }
         }
     }
-    TRACE(1);
+    if (item == (int)blockIdx.x) TRACE(1);
     // staging barrier on the LDS writes only: the mask words (12 small gathers per lane, the youngest loads in the queue) and the V rows stay
     // in flight across it and are waited for at their first use -- a __syncthreads() drains them too (vmcnt(0): +8 000 cycles per workgroup
     // in the phase trace)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    TRACE(2);
+    if (item == (int)blockIdx.x) TRACE(2);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) kf[ks] = ld8(Ks + key * HD + (((ks * 4 + g) ^ swzk(key)) << 3));
+    if (item + (int)gridDim.x < nitems) request_tiles(item + gridDim.x);        // the staging registers are free again: next item's tiles
 
     // ---- phase 1: this wave's key tile against every query tile ------------------------------------------------------------------------
     const int nkt = (L + 15) / 16;
@@ -1040,6 +1059,9 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
                 s[half] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld8(Qs + off), kf[ks], s[half], 0, 0, 0);
                 dp[half] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld8(dOs + off), vf[ks], dp[half], 0, 0, 0);
             }
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
             const int q0 = (2 * u + half) * 16 + 4 * g;
             lse4[half] = *reinterpret_cast<const f32x4*>(lse_s + q0);
             dl4[half] = *reinterpret_cast<const f32x4*>(dl_s + q0);
@@ -1047,9 +1069,6 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
             // ADJACENT lanes here: the even-key lane hashes rows q0, q0 + 1, the odd-key lane rows q0 + 2, q0 + 3, and they swap (DPP quad_perm)
             // the 16-bit halves the other one needs -- 2 hashes per lane and block instead of 4 identical pairs of them
             if (DROP) rk2[half] = *reinterpret_cast<const u32x2*>(rk_s + q0 + 2 * (int)kodd);
-        }
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
             const uint32_t w = mw[2 * u + half];
             float pd4[4], ds4[4];
             f32x2 multp[2] = {(f32x2){1.f, 1.f}, (f32x2){1.f, 1.f}};      // dropout multipliers of the element pairs (r = 0, 1) and (r = 2, 3)
@@ -1094,11 +1113,11 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
                 dk[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(Qs, 32 * u, 32 * u + 16, 16 * n, g, li), dsf, dk[n], 0, 0, 0);
             }
         }
-        if (u == 0) TRACE(3);
+        if (u == 0 && item == (int)blockIdx.x) TRACE(3);
     }
-    TRACE(4);
+    if (item == (int)blockIdx.x) TRACE(4);
 #ifdef VLP_ATTN_TRACE
-    if (wid == (int)(blockIdx.x % NT) && lane == 0 && blockIdx.x < 4096) g_attn_trace[blockIdx.x * 8 + 7] = __builtin_readcyclecounter();     // end of phase 1 of wave blockIdx % NT
+    if (item == (int)blockIdx.x && wid == (int)(blockIdx.x % NT) && lane == 0 && blockIdx.x < 4096) g_attn_trace[blockIdx.x * 8 + 7] = __builtin_readcyclecounter();     // end of phase 1 of wave blockIdx % NT
 #endif
     if (key < L) {
         f16* drow = p.dqkv + ((int64_t)b * L + key) * p.ld_dqkv + h * HD;
@@ -1112,7 +1131,7 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (LDS writes only: the dK / dV stores above stay in flight across the barrier)
     __builtin_amdgcn_s_barrier();
-    TRACE(5);
+    if (item == (int)blockIdx.x) TRACE(5);
 
     // ---- phase 2: dQ^T tiles (rows = head-dim 16 n + 4g + reg, col = query), K^T . dS^T over all keys ---------------------------------
     // (two tiles of a wave in flight at once: the NT/2 MFMAs of a tile form one dependent chain)
@@ -1139,7 +1158,11 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
             st4_out<VLP_SS_ATTN>(p.dqkv + ((int64_t)b * L + q1) * p.ld_dqkv + h * HD + n1 * 16 + 4 * g, ov);
         }
     }
-    TRACE(6);
+    if (item == (int)blockIdx.x) TRACE(6);
+    // the next item's staging writes may only start when every wave has finished reading this item's tiles (phase 2: K and dS^T)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    }      // item loop
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1276,14 +1299,20 @@ extern "C" int vlp_attn_bwd(const vlp_attn_bwd_args* a, void* stream) {
     } while (0)
         const bool xch = bwd_env && bwd_env[0] == 'x';        // VLP_ATTN_BWD=xch: the exchange-tile form at every L (A/B runs)
         const size_t smem_full = (size_t)3 * LP * HD * 2 + (size_t)LP * LP * 2 + (size_t)3 * LP * 4;
+        // persistent grid of the whole-dS^T kernel: one workgroup per CU walks items b*heads + h = blockIdx, + grid, ... (the next item's
+        // tiles prefetched into registers); VLP_ATTN_BWD_GRID=0 launches one workgroup per item instead (A/B runs)
+        static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n; }();
+        const char* ge = getenv("VLP_ATTN_BWD_GRID");
+        const int gcap = ge ? atoi(ge) : ncu;
+        const dim3 pgrid((gcap > 0 && gcap < a->B * a->heads) ? gcap : a->B * a->heads);
 #define LAUNCH_FULL(NT_)                                                                                             \
     do {                                                                                                             \
         if (p.drop.thresh) {                                                                                         \
             VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)attn_bwd_full_kernel<NT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_full)); \
-            hipLaunchKernelGGL((attn_bwd_full_kernel<NT_, true>), grid, dim3((NT_) * 64), smem_full, s, p);          \
+            hipLaunchKernelGGL((attn_bwd_full_kernel<NT_, true>), pgrid, dim3((NT_) * 64), smem_full, s, p);         \
         } else {                                                                                                     \
             VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)attn_bwd_full_kernel<NT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_full)); \
-            hipLaunchKernelGGL((attn_bwd_full_kernel<NT_, false>), grid, dim3((NT_) * 64), smem_full, s, p);         \
+            hipLaunchKernelGGL((attn_bwd_full_kernel<NT_, false>), pgrid, dim3((NT_) * 64), smem_full, s, p);        \
         }                                                                                                            \
     } while (0)
         if (LP == 64) { if (xch) LAUNCH_ONE(4, 1); else LAUNCH_FULL(4); }
