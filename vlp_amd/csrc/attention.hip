@@ -1012,8 +1012,10 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
     // real key; a padding key (>= L) has kmbase = -inf, a padding query row has lse = +inf (above): their byte is 2, and 2 C1 - inf = -inf /
     // C1 - (+inf) = -inf -- every excluded probability is exp2(-inf) = 0 and multiplies finite numbers only (dO, Q rows >= L are zero)
     const float kmbase = key < L ? -MASK_C1 : -INFINITY;
-    typedef float f32x2 __attribute__((ext_vector_type(2)));      // pairs of elements: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (the phase is VALU-issue bound)
-    const f32x2 sc2v = (f32x2){sc2, sc2}, c1v = (f32x2){MASK_C1, MASK_C1}, kbv = (f32x2){kmbase, kmbase}, scv = (f32x2){p.scale, p.scale};
+    // (Packed fp32 pair arithmetic -- v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on element pairs -- was measured for this block and is a wash:
+    // 54.2 - 54.5 us against 54.0 - 55.4 us per layer; in the FFN-up GEMM epilogue the packed erf / gelu' pair was 17 % SLOWER than the scalar
+    // form (89 vs 76 us per launch).  The guide prices v_pk_* above two scalar ops on this chip; kept scalar.)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) { dk[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -1084,19 +1086,12 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
                 multp[1] = kodd ? mine : other;
             }
 #pragma unroll
-            for (int jp = 0; jp < 2; ++jp) {         // element pairs (r = 2 jp, 2 jp + 1)
-                const int r0 = 2 * jp, r1 = 2 * jp + 1;
-                const f32x2 bytes = (f32x2){(float)((w >> (8 * r0)) & 0xffu), (float)((w >> (8 * r1)) & 0xffu)};      // v_cvt_f32_ubyteN
-                const f32x2 ma = bytes * c1v + kbv;
-                const f32x2 sv = (f32x2){s[half][r0], s[half][r1]};
-                const f32x2 arg = sv * sc2v + (ma - (f32x2){lse4[half][r0], lse4[half][r1]});
-                const f32x2 pr = (f32x2){__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
-                const f32x2 mult = multp[jp];
-                const f32x2 pd = pr * mult;
-                const f32x2 t = (f32x2){dp[half][r0], dp[half][r1]} * mult - (f32x2){dl4[half][r0], dl4[half][r1]};
-                const f32x2 ds = (pr * t) * scv;
-                pd4[r0] = pd[0]; pd4[r1] = pd[1];
-                ds4[r0] = ds[0]; ds4[r1] = ds[1];
+            for (int r = 0; r < 4; ++r) {
+                const float ma = fmaf((float)((w >> (8 * r)) & 0xffu), MASK_C1, kmbase);          // v_cvt_f32_ubyteN + one FMA
+                const float pr = __builtin_amdgcn_exp2f(fmaf(s[half][r], sc2, ma - lse4[half][r]));
+                const float mult = multp[r >> 1][r & 1];
+                pd4[r] = pr * mult;
+                ds4[r] = pr * (dp[half][r] * mult - dl4[half][r]) * p.scale;
             }
             pdw[2 * half] = pack_f16x2(pd4[0], pd4[1]);
             pdw[2 * half + 1] = pack_f16x2(pd4[2], pd4[3]);
