@@ -80,11 +80,16 @@ typedef struct {
                                             128x128 / 128x64 / 64x64 wave tiles, fragments read one or two k16 steps ahead of their MFMAs, LDS-transposed epilogue
                                             with whole-line stores; cfg table in that file).  They carry the bias / ReLU / multiplier / dropout / residual and
                                             save-grad GeLU epilogues; a call that needs erf / tanh in the epilogue runs on the rings (27 / 29) instead.
-                                            Every variant computes the same result (up to the fp32 summation order). */
+                                            256 (+ 8 = XCD-aware run order): persistent k-stream kernel (gemm_nt_ps.hip): one workgroup per CU walks a contiguous
+                                            run of 256x128 tiles through one never-draining 3-stage ring and stores a finished tile in slices behind the next
+                                            tile's k tiles; bias / save-grad GeLU / plain-multiplier epilogues on N % 128 == 0, N <= 8192, K > 512 -- anything
+                                            else runs on the rings (27 / 29) instead (`VLP_NT_PS_GRID` caps the workgroups of a launch: investigation).
+                                            Every variant computes the same result (bit-identical on gfx950: profiles/r04_nt_variant_identity.json). */
 } vlp_gemm_nt_args;
 int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream);
 /* The variant the calling thread's last vlp_gemm_nt launched after its fallbacks (a wave-pipelined variant without the requested
- * epilogue, or with operands beyond 32-bit offsets, runs on the rings 27 / 29); -1 before the first call. */
+ * epilogue, or with operands beyond 32-bit offsets, and a persistent variant outside its epilogues / shapes, run on the rings 27 / 29);
+ * -1 before the first call. */
 int vlp_gemm_nt_resolved_variant(void);
 /* Split-K form for skinny problems (incremental decoding, M = 128..640 rows: only N/128 output tiles): the k range is cut into `splits`
  * slices computed by separate workgroups into an fp32 workspace of vlp_gemm_nt_splitk_workspace_bytes(M, N, splits) bytes; a second

@@ -150,6 +150,75 @@ def test_gemm_nt_variant_identity(gen):
         assert same["27_vs_77"] == NT_FAMILIES_BIT_IDENTICAL and same["29_vs_73"] == NT_FAMILIES_BIT_IDENTICAL, (same, ulp)
 
 
+@pytest.mark.parametrize("M,N,K,cap", [(1000, 512, 640, 5), (1000, 512, 640, 0), (700, 384, 1024, 2), (2085, 2304, 768, 7), (10688, 3072, 768, 0), (10688, 2304, 768, 0),
+                                         (10688, 768, 3072, 0), (10688, 3072, 768, 100)])
+@pytest.mark.parametrize("epi", ["bias", "plain", "sg", "mul"])
+def test_gemm_nt_persistent_stream(M, N, K, cap, epi, gen, monkeypatch):
+    """gemm_nt_ps.hip (variant 256 / 264): one workgroup per CU walks a run of 256x128 tiles as one k stream and stores a finished tile in
+    slices behind the next tile's k tiles.  Its three epilogues must be BIT-identical to the ring kernels' (same MFMA chain, same epilogue
+    arithmetic), whatever the run length (`VLP_NT_PS_GRID` caps the workgroups of the launch: runs of 1 .. 17 tiles, ragged last run,
+    ragged last row tile), and repeated launches must agree (deferred stores + LDS-DMA ring share the vmcnt counter)."""
+    Kd = K
+    from vlp_amd import _lib as K
+    if cap:
+        monkeypatch.setenv("VLP_NT_PS_GRID", str(cap))
+    else:
+        monkeypatch.delenv("VLP_NT_PS_GRID", raising=False)
+    x, w = h16(M, Kd, gen=gen), h16(N, Kd, scale=0.05, gen=gen)
+    kw = {}
+    if epi in ("bias", "sg"):
+        kw["bias"] = h16(N, scale=0.5, gen=gen)
+    if epi == "mul":
+        kw.update(mul_src=h16(M, N, gen=gen), mul_mode=K.MUL_PLAIN)
+
+    def run(variant):
+        y = torch.full((M, N), 7.0, device=DEV, dtype=torch.half)
+        pre = torch.full((M, N), 5.0, device=DEV, dtype=torch.half) if epi == "sg" else None
+        if epi == "sg":
+            K.gemm_nt(x, w, y, M, N, Kd, act=K.ACT_GELU_SAVE_GRAD, preact=pre, variant=variant, **kw)
+        else:
+            K.gemm_nt(x, w, y, M, N, Kd, variant=variant, **kw)
+        return y, pre, K.gemm_nt_resolved_variant()
+
+    y_ref, pre_ref, rv = run(29 if N > 1024 else 27)
+    for variant in (256, 264):
+        first = None
+        for it in range(3):
+            y, pre, rv = run(variant)
+            assert rv == variant, (variant, rv)
+            assert torch.equal(y, y_ref), "variant %d run %d: Y differs from the ring (max abs %g)" % (variant, it, float((y.float() - y_ref.float()).abs().max()))
+            if epi == "sg":
+                assert torch.equal(pre, pre_ref), "variant %d run %d: stored derivative differs" % (variant, it)
+    z = x.float() @ w.float().t()
+    if "bias" in kw:
+        z = z + kw["bias"].float()
+    if epi == "sg":
+        z = torch.nn.functional.gelu(z.half().float())
+    if epi == "mul":
+        z = z * kw["mul_src"].float()
+    assert rel(y_ref.float(), z) < 2e-3
+
+
+def test_gemm_nt_persistent_stream_fallbacks(gen):
+    """What the persistent kernel does not carry runs on a ring, and the launcher says so."""
+    M, N, Kd = 600, 256, 640
+    x, w = h16(M, Kd, gen=gen), h16(N, Kd, scale=0.05, gen=gen)
+    y = torch.empty(M, N, device=DEV, dtype=torch.half)
+    K.gemm_nt(x, w, y, M, N, Kd, variant=264, residual=h16(M, N, gen=gen))
+    assert K.gemm_nt_resolved_variant() == 27
+    K.gemm_nt(x, w, y, M, N, Kd, variant=264, act=K.ACT_GELU)
+    assert K.gemm_nt_resolved_variant() == 27
+    K.gemm_nt(x, w, y, M, N, Kd, variant=264, dropout_p=0.1, seed=3)
+    assert K.gemm_nt_resolved_variant() == 27
+    K.gemm_nt(x[:, :512], w[:, :512], y, M, N, 512, ldx=Kd, ldw=Kd, variant=264)          # 8 k tiles: no room for the eight store slices
+    assert K.gemm_nt_resolved_variant() == 27
+    y2 = torch.empty(M, 1000, device=DEV, dtype=torch.half)
+    K.gemm_nt(x, h16(1000, Kd, scale=0.05, gen=gen), y2, M, 1000, Kd, variant=264)        # N % 128 != 0
+    assert K.gemm_nt_resolved_variant() == 27
+    K.gemm_nt(x, w, y, M, N, Kd, variant=264)
+    assert K.gemm_nt_resolved_variant() == 264
+
+
 NT_FAMILIES_BIT_IDENTICAL = True      # measured in round 4 (profiles/r04_nt_variant_identity.json): one 16x16x32 MFMA rounds like two 32x32x16 k16 steps
 
 

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 BUILD = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libvlp_hip.so")
-SOURCES = ["api.cpp", "gemm_nt.hip", "gemm_nt_ph.hip", "gemm_nt_k32.hip", "gemm_nt_wp.hip", "gemm_nt_splitk.hip", "gemm_tn.hip", "attention.hip", "layernorm.hip", "elementwise.hip", "loss.hip", "adam.hip", "pretext.hip"]
+SOURCES = ["api.cpp", "gemm_nt.hip", "gemm_nt_ph.hip", "gemm_nt_k32.hip", "gemm_nt_wp.hip", "gemm_nt_ps.hip", "gemm_nt_splitk.hip", "gemm_tn.hip", "attention.hip", "layernorm.hip", "elementwise.hip", "loss.hip", "adam.hip", "pretext.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-Wno-unused-result", "-ffp-contract=fast"]
 

@@ -32,6 +32,10 @@ int vlp_gemm_nt_k32_launch(GemmNtParams& p, bool sg, hipStream_t s);
 // wave-pipelined kernels (gemm_nt_wp.hip): cfg 0..7, see the table there; p.xcd_remap honoured
 int vlp_gemm_nt_wp_launch(GemmNtParams& p, int cfg, bool sg, hipStream_t s);
 
+// persistent k-stream kernel (gemm_nt_ps.hip): 256x128 tiles, one workgroup per CU walks a run of tiles, deferred output stores; p.xcd_remap honoured
+bool vlp_gemm_nt_ps_eligible(const GemmNtParams& p, bool sg);
+int vlp_gemm_nt_ps_launch(GemmNtParams& p, bool sg, hipStream_t s);
+
 // argument validation + parameter block of vlp_gemm_nt (shared by the split-K entry point)
 int vlp_gemm_nt_fill_params(const vlp_gemm_nt_args* a, GemmNtParams& p);
 // split-K kernels (gemm_nt_splitk.hip)

@@ -398,6 +398,8 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
     do { if (sg) LAUNCH_NT_(3, BMT, BNT, NSV, true, NSV); else LAUNCH_NT_(3, BMT, BNT, NSV, false, NSV); } while (0)
     const bool sg = a->act == VLP_ACT_GELU_SAVE_GRAD;
     int variant = a->variant;
+    // the persistent k-stream kernel carries three epilogues on N % 128 == 0, K > 512: anything else runs on the rings
+    if ((variant & 256) && !vlp_gemm_nt_ps_eligible(p, sg)) variant = (a->N > 1024) ? 29 : 27;
     // the wave-pipelined family carries the light epilogues + save-grad GeLU; anything else (erf / tanh in the epilogue) runs on the rings
     if ((variant & 64) && !sg && !nt_epilogue_is_light(p)) variant = (a->N > 1024) ? 29 : 27;
     // the phased kernels (6, 7) do not instantiate the save-grad epilogue: same fallback instead of an error for a table / override entry
@@ -410,6 +412,12 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
                       "vlp_gemm_nt: VLP_ACT_GELU_SAVE_GRAD fuses bias + gelu + derivative only (no residual / multiplier / dropout)");
     }
     p.xcd_remap = (variant & 8) ? 1 : 0;
+    if (variant & 256) {         // persistent k-stream kernel (gemm_nt_ps.hip): 256 (+ 8 = XCD-aware run order)
+        const int rc = vlp_gemm_nt_ps_launch(p, sg, s);
+        if (rc != VLP_OK) return rc;
+        VLP_CHECK_LAUNCH("vlp_gemm_nt");
+        return VLP_OK;
+    }
     if (variant & 64) {          // wave-pipelined family (gemm_nt_wp.hip): 64 + cfg (+ 8 = XCD-aware tile order)
         const int rc = vlp_gemm_nt_wp_launch(p, (variant & 7) + ((variant & 128) ? 8 : 0), sg, s);
         if (rc != VLP_OK) return rc;

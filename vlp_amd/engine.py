@@ -47,7 +47,7 @@ class _State(object):
 
 class Engine(object):
     GEMM_NT_VARIANT = None   # None -> vlp_amd.tuning (committed table, else shape heuristic; timing search only with VLP_AUTOTUNE=1); or force an int
-    NT_CANDIDATES = (1, 2, 4, 5, 9, 10, 11, 12, 13, 27, 29, 73, 77)   # LDS-DMA variants (+8 = XCD-aware tile order, +16 = ring, 64 + cfg = wave-pipelined); see include/vlp_hip.h
+    NT_CANDIDATES = (1, 2, 4, 5, 9, 10, 11, 12, 13, 27, 29, 73, 77, 264)   # LDS-DMA variants (+8 = XCD-aware tile order, +16 = ring, 64 + cfg = wave-pipelined, 256 = persistent k stream); see include/vlp_hip.h
     NT_CANDIDATES_SKINNY = (1, 2, 9, 10, 11, 17)      # M <= 1024 (decoding, LM head): few workgroups, latency-bound -> also the 4-stage ring
     GEMM_TN_VARIANT = 2      # ds_read_b64_tr_b16 fragment reads + LDS-DMA staging
     # weight-gradient GEMMs of the encoder layers on a second HIP stream, concurrent with the dgrad chain (the wgrad grids are a single
