@@ -289,7 +289,7 @@ def main():
             # process): the newest profiles/rNN_pmc_traffic.json, produced by tools/gpu_pmc_bench.sh on the same command -- quoted
             # only if it was measured on the kernel sources of this build (otherwise null + the reason in `traffic_source`).
             traffic, traffic_src = committed_traffic()
-            roof = {"bound": "mfma", "kernel": "vlp_gemm_nt (gemm_nt_kernel + gemm_nt_wp_kernel: all forward + dgrad GEMMs; every %dth launch bracketed by HIP events in a second, un-timed pass over the same steps)" % eng.PROF_EVERY, "achieved": round(achieved, 1),
+            roof = {"bound": "mfma", "kernel": "vlp_gemm_nt (gemm_nt_kernel + gemm_nt_wp_kernel + gemm_nt_ps_kernel: all forward + dgrad GEMMs; every %dth launch bracketed by HIP events in a second, un-timed pass over the same steps)" % eng.PROF_EVERY, "achieved": round(achieved, 1),
                     "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launches_per_step": len(prof) * eng.PROF_EVERY // max(args.steps, 1), "sampled_launches": len(prof),
                     "avg_launch_us": round(sum(ms) / len(ms) * 1e3, 2),

@@ -124,8 +124,13 @@ int64_t vlp_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K);
 int vlp_gemm_tn(const vlp_gemm_tn_args* a, void* stream);
 /* Several weight gradients in ONE launch (1..8 problems; the four Linears of a BertLayer: modeling.py:270-272, 314, 341, 354).
  * Every 128x128 output tile of every problem is one workgroup that walks that problem's WHOLE contraction: no split-M slabs, no
- * reduce launches (`workspace`, `splits`, `variant` of the entries are ignored); `beta` and `bias_out` as in vlp_gemm_tn. */
+ * reduce launches (`splits`, `variant` of the entries are ignored); `beta` and `bias_out` as in vlp_gemm_tn.
+ * Stream-K form (VLP_TN_GROUP_MODE=5): with list[0].workspace / workspace_bytes >= vlp_gemm_tn_grouped_workspace_bytes(tiles) (tiles =
+ * sum over the problems of ceil(N/128) * ceil(K/128); must be a multiple of 6, one M for all problems) the tiles are taken six at a
+ * time and their contraction is dealt to seven workgroups in equal runs: every tile is cut once, its two fp32 partial chains meet
+ * through the workspace (flags reset by a hipMemsetAsync ahead of the launch); without a workspace the launch runs in the plain form. */
 int vlp_gemm_tn_grouped(const vlp_gemm_tn_args* list, int32_t count, void* stream);
+int64_t vlp_gemm_tn_grouped_workspace_bytes(int32_t tiles);
 
 /* out[n] (+)= sum_m A[m,n]  -- bias gradients (autograd SumBackward of the broadcast bias add). */
 typedef struct {

@@ -414,6 +414,66 @@ def test_gemm_tn_grouped(gen):
         K.gemm_tn_grouped([tuple(probs[0])] * 9)
 
 
+@pytest.mark.parametrize("M", [10688, 1000, 64 * 14 + 5])
+def test_gemm_tn_grouped_stream_k(M, gen, monkeypatch):
+    """Stream-K form of the grouped launch (VLP_TN_GROUP_MODE=5, gemm_tn_grouped_sk_kernel): six tiles are dealt to seven workgroups in equal
+    runs of contraction stages, every tile is cut once and its two fp32 chains meet through the workspace.  Against the plain grouped
+    launch: equal up to the fp32 summation order (two chains instead of one), bias gradients included; repeated launches bit-identical
+    (the hand-off is deterministic); beta = 1 accumulates; without a workspace, or with a tile count that is not a multiple of 6, the
+    launcher runs the plain form (bit-identical to it)."""
+    shapes = [(256, 384), (768, 768), (384, 128)]           # 6 + 36 + 3 = 45 tiles -> pad with a fourth problem to a multiple of 6
+    shapes.append((384, 128))                                # 48 tiles = 8 groups, 56 workgroups
+    def make():
+        probs = []
+        g2 = torch.Generator(device=DEV); g2.manual_seed(99)
+        for i, (N, Kd) in enumerate(shapes):
+            a, b = h16(M, N, scale=0.3, gen=g2), h16(M, Kd, scale=0.3, gen=g2)
+            probs.append([a, b, h16(N, Kd, gen=g2), M, N, Kd, 0, h16(N, gen=g2) if i != 2 else None])
+        return probs
+    tiles = sum((N // 128) * (Kd // 128) for N, Kd in shapes)
+    assert tiles % 6 == 0
+    wsk = torch.empty(K.gemm_tn_grouped_workspace_bytes(tiles), device=DEV, dtype=torch.uint8)
+    monkeypatch.setenv("VLP_TN_GROUP_MODE", "0")
+    plain = make()
+    K.gemm_tn_grouped([tuple(q) for q in plain])
+    monkeypatch.setenv("VLP_TN_GROUP_MODE", "5")
+    runs = []
+    for rep in range(3):
+        sk = make()
+        wsk.fill_(0xFF if rep == 1 else 0)                   # stale partials / flags from another launch must not matter
+        K.gemm_tn_grouped([tuple(q) for q in sk], workspace=wsk)
+        runs.append(sk)
+    for q0, q1, q2, qp in zip(runs[0], runs[1], runs[2], plain):
+        assert torch.equal(q0[2], q1[2]) and torch.equal(q0[2], q2[2])
+        ref = q0[0].float().t() @ q0[1].float()
+        assert rel(q0[2].float(), ref) < 1.5e-3
+        assert rel(q0[2].float(), qp[2].float()) < 1.5e-3
+        if q0[7] is not None:
+            assert torch.equal(q0[7], q1[7])
+            col = q0[0].float().sum(0)
+            assert float((q0[7].float() - col).abs().max()) < 2e-3 * float(col.abs().max()) + 1e-2
+    if M >= 64 * 14:
+        assert any(not torch.equal(q0[2], qp[2]) for q0, qp in zip(runs[0], plain)), "two chains per tile should differ from one chain in the last bit somewhere"
+    # beta = 1
+    acc = make()
+    for q, q0 in zip(acc, runs[0]):
+        q[2].copy_(q0[2]); q[6] = 1
+        if q[7] is not None:
+            q[7].copy_(q0[7])
+    K.gemm_tn_grouped([tuple(q) for q in acc], workspace=wsk)
+    for q, q0 in zip(acc, runs[0]):
+        assert rel(q[2].float(), 2 * q0[2].float()) < 2e-3
+    # fallbacks: no workspace / tile count not a multiple of 6 -> the plain kernel, bit for bit
+    nows = make()
+    K.gemm_tn_grouped([tuple(q) for q in nows])
+    odd = make()[:3]
+    K.gemm_tn_grouped([tuple(q) for q in odd], workspace=wsk)
+    for q, qp in zip(nows, plain):
+        assert torch.equal(q[2], qp[2])
+    for q, qp in zip(odd, plain):
+        assert torch.equal(q[2], qp[2])
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_gemm_tn_asymmetric(variant):
     """dY = I-like selector against an asymmetric X: dW[n,k] must equal X[n,k] for n < M."""

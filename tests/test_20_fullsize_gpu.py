@@ -307,7 +307,9 @@ def test_full_size_logits_under_every_nt_variant():
             # the last GEMM of the forward is the tied decoder (plain epilogue + bias): the launcher must have run the forced variant
             # there (vlp_gemm_nt_resolved_variant: what ran after the launcher's fallbacks)
             ran[v] = K.gemm_nt_resolved_variant()
-            assert ran[v] == v, (v, ran[v])
+            # (the persistent k-stream kernel carries N % 128 == 0 only: the 28 996-column decoder must report its ring fallback; the
+            # encoder's QKV / FFN GEMMs of this forward did run on it: tests/test_00 asserts the resolved variant per epilogue)
+            assert ran[v] == (29 if v & 256 else v), (v, ran[v])
             rep[v] = _relmax(m.last_mlm_logits.float().reshape(t.shape), t)
             assert rep[v] <= yard + 1e-3, (v, rep, yard)
             assert abs(float(losses[0]) - float(truth["mlm_loss"])) <= 2e-3 * float(truth["mlm_loss"]), v

@@ -19,7 +19,7 @@ cut = ids[int(len(ids) * 0.5)]
 
 def group(name):
     n = name.split("(")[0]
-    if "gemm_nt_wp_kernel" in n:          # the wave-pipelined family is part of the dominant "vlp_gemm_nt" group
+    if "gemm_nt_wp_kernel" in n or "gemm_nt_ps_kernel" in n:          # the wave-pipelined and persistent families are part of the dominant "vlp_gemm_nt" group
         return "gemm_nt_kernel"
     for key in ("gemm_nt_kernel", "gemm_tn_grouped_kernel", "gemm_tn_glds_kernel", "attn_fwd_kernel", "attn_bwd_full_kernel", "attn_bwd_one_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel",
                 "fused_adam_kernel", "layernorm_fwd_kernel", "layernorm_bwd_kernel"):

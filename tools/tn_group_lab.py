@@ -27,9 +27,12 @@ def main():
         sets.append([(r(M, n), r(M, k), torch.empty(n, k, device=DEV, dtype=torch.half), torch.empty(n, device=DEV, dtype=torch.half)) for n, k in shapes])
     i = [0]
 
+    tiles = sum((n // 128) * (k // 128) for n, k in shapes)
+    wsk = torch.empty(K.gemm_tn_grouped_workspace_bytes(tiles), device=DEV, dtype=torch.uint8)      # stream-K form (mode 5)
+
     def f():
         s = sets[i[0] % ROT]
-        K.gemm_tn_grouped([(a, b, c, M, a.shape[1], b.shape[1], 0, bias) for a, b, c, bias in s])
+        K.gemm_tn_grouped([(a, b, c, M, a.shape[1], b.shape[1], 0, bias) for a, b, c, bias in s], workspace=wsk)
         i[0] += 1
 
     for _ in range(3):

@@ -145,6 +145,7 @@ SYMBOLS = {
     "vlp_gemm_tn_workspace_bytes": (i64, [i32, i32, i32]),
     "vlp_gemm_tn": (C.c_int, [C.POINTER(GemmTnArgs), vp]),
     "vlp_gemm_tn_grouped": (C.c_int, [C.POINTER(GemmTnArgs), i32, vp]),
+    "vlp_gemm_tn_grouped_workspace_bytes": (i64, [i32]),
     "vlp_colsum_workspace_bytes": (i64, [i32, i32]),
     "vlp_colsum": (C.c_int, [C.POINTER(ColsumArgs), vp]),
     "vlp_attn_fwd": (C.c_int, [C.POINTER(AttnFwdArgs), vp]),
@@ -333,12 +334,21 @@ def gemm_tn(a_, b_, c_, M, N, K, lda=None, ldb=None, ldc=None, beta=0, workspace
     _check(load().vlp_gemm_tn(C.byref(a), stream_ptr()))
 
 
-def gemm_tn_grouped(problems):
-    """problems: list of dicts / tuples (a, b, c, M, N, K, beta, bias_out) -- several wgrads in one launch (vlp_gemm_tn_grouped)."""
+def gemm_tn_grouped_workspace_bytes(tiles):
+    return int(load().vlp_gemm_tn_grouped_workspace_bytes(tiles))
+
+
+def gemm_tn_grouped(problems, workspace=None):
+    """problems: list of tuples (a, b, c, M, N, K, beta, bias_out) -- several wgrads in one launch (vlp_gemm_tn_grouped); `workspace`
+    (gemm_tn_grouped_workspace_bytes) lets the launcher use its stream-K form."""
     arr = (GemmTnArgs * len(problems))()
     for i, (a_, b_, c_, M, N, K, beta, bias_out) in enumerate(problems):
         _req_cuda(a_, b_, c_, bias_out)
-        arr[i] = GemmTnArgs(ptr(a_), a_.stride(0), ptr(b_), b_.stride(0), ptr(c_), c_.stride(0), M, N, K, beta, None, 0, 0, 0, ptr(bias_out))
+        w = workspace if i == 0 else None
+        if w is not None:
+            _req_cuda(w)
+        arr[i] = GemmTnArgs(ptr(a_), a_.stride(0), ptr(b_), b_.stride(0), ptr(c_), c_.stride(0), M, N, K, beta, ptr(w),
+                            (w.numel() * w.element_size()) if w is not None else 0, 0, 0, ptr(bias_out))
     _check(load().vlp_gemm_tn_grouped(arr, len(problems), stream_ptr()))
 
 

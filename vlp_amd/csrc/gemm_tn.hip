@@ -218,8 +218,15 @@ DEVFN int tn_swz(int r) { return ((r & 3) | (((r >> 3) & 1) << 2)) << 1; }
 // inside the problem p (after any XCD remap): shared by the single-problem kernel and the grouped launch below.
 // NS = LDS stages of the ring (NS - 2 stages stay in flight across a stage's barrier), BM_T = contraction rows per stage (64 or 32: with 32 rows a
 // 128x128 tile fits FOUR stages in the 64 KiB that let two workgroups share a CU)
-template <int BN_T, int BK_T, int NS = 2, int BM_T = TN_BM>
-DEVFN void tn_glds_tile(const GemmTnParams& p, int bid, f16* smem) {
+// SK (segments of the balanced grouped launch, gemm_tn_grouped_sk_kernel): the workgroup computes the contraction rows [sk_m_begin, sk_m_end) of
+// the tile only and either WRITES its fp32 accumulators to `sk_part` (the kernel publishes `sk_flag` later), or -- the tile's finisher -- waits
+// for the flag, ADDS the partner's partial (own chain + partner's chain, in that order: deterministic) and runs the ordinary epilogue.
+#define TN_SK_WRITE 1
+#define TN_SK_FINAL 2
+#define TN_SK_SLOTS 20       // f32x4 per thread in a partial: 16 accumulator tiles + 4 bias tiles
+template <int BN_T, int BK_T, int NS = 2, int BM_T = TN_BM, bool SK = false>
+DEVFN void tn_glds_tile(const GemmTnParams& p, int bid, f16* smem, int sk_m_begin = 0, int sk_m_end = 0, int sk_role = 0, float* sk_part = nullptr,
+                        int* sk_flag = nullptr) {
     constexpr int WK_ = BK_T / 64;
     constexpr int T = (BN_T / 64) * WK_ * 64;            // threads
     constexpr int ATILE = BM_T * BN_T, BTILE = BM_T * BK_T;   // halfs
@@ -244,8 +251,8 @@ DEVFN void tn_glds_tile(const GemmTnParams& p, int bid, f16* smem) {
     }
     const int n0 = ntile * BN_T;
     const int k0 = ktile * BK_T;
-    const int m_begin = split * p.rows_per_split;
-    const int m_end = min(p.M, m_begin + p.rows_per_split);
+    const int m_begin = SK ? sk_m_begin : split * p.rows_per_split;
+    const int m_end = SK ? sk_m_end : min(p.M, m_begin + p.rows_per_split);
     const int nstages = (m_end - m_begin + BM_T - 1) / BM_T;
 
     // staging: pass i covers tile rows ARP*i .. ; thread -> (row = ARP*i + tid/ACH, physical chunk = tid%ACH).  The swizzle acts on
@@ -368,6 +375,36 @@ DEVFN void tn_glds_tile(const GemmTnParams& p, int bid, f16* smem) {
         }
     }
 
+    if (SK) {
+        // lane-linear partial image: slot i of thread tid at f32x4 index i * T + tid (16-byte stores / loads, fully coalesced)
+        f32x4* part = reinterpret_cast<f32x4*>(sk_part) + tid;
+        if (sk_role == TN_SK_WRITE) {
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tk = 0; tk < 4; ++tk) part[(tn * 4 + tk) * T] = acc[tn][tk];
+            if (do_bias) {
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) part[(16 + tn) * T] = bacc[tn];
+            }
+            __syncthreads();       // every wave is done with the LDS stages before the next segment's prologue refills them; the kernel publishes once
+            return;
+        }
+        // finisher: the group's tail workgroup publishes all six partials at its end, about when the main workgroups end; poll relaxed, acquire once
+        if (tid == 0) {
+            while (__hip_atomic_load(sk_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int tk = 0; tk < 4; ++tk) acc[tn][tk] += part[(tn * 4 + tk) * T];
+        if (do_bias) {
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) bacc[tn] += part[(16 + tn) * T];
+        }
+    }
     // epilogue: lane owns row n (per tn) and, per tk, 4 consecutive k at k0 + wk*64 + 16*tk + 4*g
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
@@ -425,6 +462,7 @@ struct TnGroupEntry {
 struct TnGroupParams {
     TnGroupEntry e[TN_GROUP_MAX];
     int count, total_tiles, xcd_remap;
+    int nst, tail;           // balanced form: contraction stages (of 64 rows) per tile, the same for every problem of the group; stages of the tail cohort
 };
 
 template <int BN_T, int BK_T, int NS, int BM_T>
@@ -443,6 +481,55 @@ __global__ __launch_bounds__((BN_T / 64) * (BK_T / 64) * 64, 2) void gemm_tn_gro
     p.M = e.M; p.N = e.N; p.K = e.K; p.beta = e.beta; p.splits = 1; p.rows_per_split = (e.M + TN_BM - 1) / TN_BM * TN_BM;
     p.tiles_k = e.tiles_k; p.tiles_n = 0; p.xcd_remap = 0; p.split_major = 0;
     tn_glds_tile<BN_T, BK_T, NS, BM_T>(p, bid - e.tile_begin, reinterpret_cast<f16*>(smem_raw));
+}
+
+// Balanced form of the grouped launch ("tail cohort").  432 equal tiles on 2 x 256 workgroup slots leave 80 CUs with one workgroup instead
+// of two.  Here the tiles are taken six at a time by SEVEN workgroups: six "main" workgroups walk the first nst - tail contraction stages of
+// one tile each -- all main workgroups of the launch sweep the contraction rows in step, which is what keeps every operand block a one-time
+// HBM read (a plain stream-K deal of equal contiguous runs was built first: correct, and 18 % SLOWER than the unbalanced launch, because runs
+// that start at seven different row offsets read every operand block at seven different times: profiles/r04_grouped_wgrad_balanced.txt) --
+// and the seventh walks the LAST `tail` stages of all six tiles, one after the other, and leaves six fp32 partials in `part` (80 KB per tile).
+// It publishes them with ONE agent-scope release at its end; a main workgroup then adds its tile's partial (own chain + tail chain: deterministic)
+// and runs the ordinary epilogue.  `tail` is chosen so that 6 * (tail + restart cost) ~ nst - tail.
+template <int BN_T, int BK_T, int NS, int BM_T>
+__global__ __launch_bounds__((BN_T / 64) * (BK_T / 64) * 64, 2) void gemm_tn_grouped_sk_kernel(TnGroupParams gp, float* part, int* flags) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int T = (BN_T / 64) * (BK_T / 64) * 64;
+    int u = blockIdx.x;
+    if (gp.xcd_remap) u = tn_xcd_remap(u, gridDim.x);     // a group's seven workgroups stay on one XCD when the grid is a multiple of 56
+    const int grp = u / 7, j = u % 7;
+    const int nst = gp.nst, cut = gp.nst - gp.tail;
+    const int nseg = (j < 6) ? 1 : 6;
+    for (int seg = 0; seg < nseg; ++seg) {
+        const int tile = 6 * grp + ((j < 6) ? j : seg);
+        int ei = 0;
+#pragma unroll
+        for (int i = 1; i < TN_GROUP_MAX; ++i)
+            if (i < gp.count && tile >= gp.e[i].tile_begin) ei = i;
+        const TnGroupEntry& e = gp.e[ei];
+        GemmTnParams p;
+        p.A = e.A; p.lda = e.lda; p.B = e.B; p.ldb = e.ldb; p.C = e.C; p.ldc = e.ldc;
+        p.slab = nullptr; p.bias_slab = nullptr; p.bias_out = e.bias_out;
+        p.M = e.M; p.N = e.N; p.K = e.K; p.beta = e.beta; p.splits = 1; p.rows_per_split = 0;
+        p.tiles_k = e.tiles_k; p.tiles_n = 0; p.xcd_remap = 0; p.split_major = 0;
+        if (j < 6)
+            tn_glds_tile<BN_T, BK_T, NS, BM_T, true>(p, tile - e.tile_begin, reinterpret_cast<f16*>(smem_raw), 0, cut * BM_T, TN_SK_FINAL,
+                                                       part + (int64_t)tile * (TN_SK_SLOTS * T * 4), flags + grp);
+        else
+            tn_glds_tile<BN_T, BK_T, NS, BM_T, true>(p, tile - e.tile_begin, reinterpret_cast<f16*>(smem_raw), cut * BM_T, min(e.M, nst * BM_T), TN_SK_WRITE,
+                                                       part + (int64_t)tile * (TN_SK_SLOTS * T * 4), flags + grp);
+    }
+    if (j == 6) {
+        // publish (cdna_hip_programming.md, in-launch hand-off): every wave's stores waited for, workgroup barrier, ONE agent-scope release by
+        // one lane, then the flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(flags + grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // out[n,k] = (beta ? out : 0) + sum_s slab[s][n][k]; the tail of the grid reduces the fused bias partials [s][N]
@@ -571,6 +658,13 @@ extern "C" int vlp_gemm_tn(const vlp_gemm_tn_args* a, void* stream) {
     return VLP_OK;
 }
 
+#define TN_GROUP_DEFAULT_MODE 0
+// workspace of the stream-K grouped launch (VLP_TN_GROUP_MODE=5) for `tiles` 128x128 output tiles over all problems: one fp32 partial
+// (16 accumulator + 4 bias f32x4 per thread) and one flag per tile
+extern "C" int64_t vlp_gemm_tn_grouped_workspace_bytes(int32_t tiles) {
+    return (int64_t)tiles * TN_SK_SLOTS * 256 * 16 + (int64_t)((tiles + 63) / 64 * 64) * (int64_t)sizeof(int);
+}
+
 static int tn_check_one(const vlp_gemm_tn_args* a) {
     VLP_CHECK_ARG(a->A && a->B && a->C, "vlp_gemm_tn: null operand");
     VLP_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "vlp_gemm_tn: bad shape");
@@ -588,8 +682,10 @@ extern "C" int vlp_gemm_tn_grouped(const vlp_gemm_tn_args* list, int32_t count, 
     // tile shape / ring depth of the grouped launch: 0 = 128x128 tiles, 2 stages (two 4-wave workgroups per CU); 1 = 256x128, 2 stages;
     // 2 = 256x128, 3 stages; 3 = 128x256, 3 stages (8-wave workgroups, one per CU); 4 = 128x128, FOUR stages of 32 contraction rows (same 64 KiB:
     // two workgroups per CU, three stages in flight).  VLP_TN_GROUP_MODE overrides (A/B runs).
-    static int mode = -1;
-    if (mode < 0) { const char* e = getenv("VLP_TN_GROUP_MODE"); mode = e ? atoi(e) : 0; if (mode < 0 || mode > 4) mode = 0; }
+    int mode = TN_GROUP_DEFAULT_MODE;      // read per launch (a getenv: ~100 ns): tests and A/B runs switch it inside one process
+    if (const char* e = getenv("VLP_TN_GROUP_MODE")) { mode = atoi(e); if (mode < 0 || mode > 5) mode = 0; }
+    // 5 = stream-K form of mode 0 (gemm_tn_grouped_sk_kernel): needs list[0].workspace (vlp_gemm_tn_grouped_workspace_bytes), a tile count that is a
+    // multiple of 6, one M for all problems and >= 14 stages; otherwise the launch runs as mode 0
     const int bn = (mode == 0 || mode >= 3) ? 128 : 256, bk = mode == 3 ? 256 : 128;
     TnGroupParams gp;
     int tiles = 0;
@@ -613,7 +709,26 @@ extern "C" int vlp_gemm_tn_grouped(const vlp_gemm_tn_args* list, int32_t count, 
         VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<BNT, BKT, NSV, BMV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                                                            \
         hipLaunchKernelGGL((gemm_tn_grouped_kernel<BNT, BKT, NSV, BMV>), dim3(tiles), dim3(((BNT) / 64) * ((BKT) / 64) * 64), smem, (hipStream_t)stream, gp); \
     } while (0)
-    if (mode == 0) LAUNCH_TN_GROUP(128, 128, 2, 64);
+    bool sk = (mode == 5);
+    if (sk) {
+        const int64_t need = vlp_gemm_tn_grouped_workspace_bytes(tiles);
+        sk = tiles % 6 == 0 && list[0].workspace != nullptr && list[0].workspace_bytes >= need && (uintptr_t)list[0].workspace % 16 == 0 && cdiv(list[0].M, 64) >= 14;
+        for (int i = 1; i < count && sk; ++i) sk = list[i].M == list[0].M;
+    }
+    if (sk) {
+        float* part = (float*)list[0].workspace;
+        int* flags = (int*)((char*)list[0].workspace + (int64_t)tiles * TN_SK_SLOTS * 256 * 16);
+        gp.nst = cdiv(list[0].M, 64);
+        // tail stages: 6 * (tail + r) = nst - tail with r ~ 3 stages of restart cost per segment (ring prologue + partial stores)
+        gp.tail = (gp.nst - 18) / 7;
+        if (const char* e = getenv("VLP_TN_SK_TAIL")) { const int v = atoi(e); if (v >= 1 && v < gp.nst) gp.tail = v; }
+        if (gp.tail < 1) gp.tail = 1;
+        if (hipMemsetAsync(flags, 0, (size_t)tiles * sizeof(int), (hipStream_t)stream) != hipSuccess)
+            return vlp_set_error(VLP_ERR_HIP, "vlp_gemm_tn_grouped: hipMemsetAsync(flags): %s", hipGetErrorString(hipGetLastError()));
+        const size_t smem = (size_t)2 * 64 * (128 + 128) * sizeof(f16);
+        VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm_tn_grouped_sk_kernel<128, 128, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((gemm_tn_grouped_sk_kernel<128, 128, 2, 64>), dim3(tiles / 6 * 7), dim3(256), smem, (hipStream_t)stream, gp, part, flags);
+    } else if (mode == 0 || mode == 5) LAUNCH_TN_GROUP(128, 128, 2, 64);
     else if (mode == 1) LAUNCH_TN_GROUP(256, 128, 2, 64);
     else if (mode == 2) LAUNCH_TN_GROUP(256, 128, 3, 64);
     else if (mode == 3) LAUNCH_TN_GROUP(128, 256, 3, 64);

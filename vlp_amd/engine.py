@@ -317,6 +317,10 @@ class Engine(object):
                        for _ in range(2)]
         tn_bytes = max(K.gemm_tn_workspace_bytes(M, I, H), K.gemm_tn_workspace_bytes(Mv, 2048, 2048), K.gemm_tn_workspace_bytes(M, 3 * H, H))
         ws["tn_ws"] = torch.empty(tn_bytes, device=dev, dtype=torch.uint8)
+        # stream-K form of the per-layer grouped wgrad (csrc/gemm_tn.hip): one fp32 partial + flag per 128x128 output tile of a layer's four
+        # weight gradients; used by the side-stream launches only (serialized in that stream)
+        lt = (H // 128) * (I // 128) * 2 + (3 * H // 128) * (H // 128) + (H // 128) * (H // 128) if H % 128 == 0 and I % 128 == 0 else 0
+        ws["tn_sk_ws"] = torch.empty(K.gemm_tn_grouped_workspace_bytes(lt), device=dev, dtype=torch.uint8) if lt and lt % 6 == 0 else None
         ws["cs_ws"] = torch.empty(max(K.colsum_workspace_bytes(M, I), K.colsum_workspace_bytes(B * max(P, 1), Vp)), device=dev, dtype=torch.uint8)
         ws["ln_ws"] = torch.empty(K.layernorm_bwd_workspace_bytes(max(H, 8)), device=dev, dtype=torch.uint8)
         # one private partials slot per encoder / embedding LayerNorm: their dgamma / dbeta second stages run as ONE launch at the
@@ -1186,7 +1190,8 @@ class Engine(object):
                         (dy2, a["g"], self.G(Ln + "output.dense.weight"), M, H, I, beta, self.G(Ln + "output.dense.bias")),
                         (ds["dz"], a["x1"], self.G(Ln + "intermediate.dense.weight"), M, I, H, beta, self.G(Ln + "intermediate.dense.bias")),
                         (dqkv, x_in, self.G(Ln + "attention.self.query.weight"), M, 3 * H, H, beta, self.G(Ln + "attention.self.query.bias")),
-                        (dy1, a["ctx"], self.G(Ln + "attention.output.dense.weight"), M, H, H, beta, self.G(Ln + "attention.output.dense.bias"))])
+                        (dy1, a["ctx"], self.G(Ln + "attention.output.dense.weight"), M, H, H, beta, self.G(Ln + "attention.output.dense.bias"))],
+                        workspace=ws["tn_sk_ws"])
                 else:
                     self._tn(dqkv, x_in, self.G(Ln + "attention.self.query.weight"), M, 3 * H, H, ws, beta,
                              bias=self.G(Ln + "attention.self.query.bias"))     # packed [3H, H] gradient
