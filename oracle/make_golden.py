@@ -242,7 +242,8 @@ def loader_raw_inputs(seed, Nv=100):
     return bbox, cls, feat, tokens
 
 
-def run_reference_loader_case(mode, n_tokens, seed, max_len_b=20, Nv=100, always_truncate_tail=True, trunc_seg="b", max_pred=3, mask_prob=0.15):
+def run_reference_loader_case(mode, n_tokens, seed, max_len_b=20, Nv=100, always_truncate_tail=True, trunc_seg="b", max_pred=3, mask_prob=0.15,
+                              mask_image_regions=False, vis_mask_prob=0.25):
     """Runs the UNMODIFIED Preprocess4Seq2seq.__call__ on the synthetic raw arrays, served by the in-memory h5py of ref_loader."""
     import random
     L = ref_loader.load_reference_loader()
@@ -255,8 +256,10 @@ def run_reference_loader_case(mode, n_tokens, seed, max_len_b=20, Nv=100, always
     idx = {w: i for i, w in enumerate(vocab)}
     proc = L.Preprocess4Seq2seq(max_pred, mask_prob, vocab, lambda toks: [idx[t] for t in toks], max_len=Nv + max_len_b + 3, new_segment_ids=True,
                                 truncate_config={"max_len_b": max_len_b, "trunc_seg": trunc_seg, "always_truncate_tail": always_truncate_tail}, mode=mode,
-                                len_vis_input=Nv, enable_butd=True, region_bbox_file="bbox.h5", region_det_file_prefix="det")
+                                len_vis_input=Nv, enable_butd=True, region_bbox_file="bbox.h5", region_det_file_prefix="det",
+                                mask_image_regions=mask_image_regions, vis_mask_prob=vis_mask_prob)
     random.seed(seed)
+    np.random.seed(seed)            # vis_masked_pos is drawn with np.random.choice (:268)
     out = proc(("/data/" + img_id + ".jpg", ["w%d" % int(t) for t in tokens[:n_tokens]]))
     return out, bbox, cls, feat, min(n_tokens, max_len_b)
 

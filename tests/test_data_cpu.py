@@ -54,3 +54,24 @@ def test_text_preprocessor_invariants(mode):
         # the labels are the ORIGINAL tokens at the masked positions
         orig = [101] + [100] * 100 + [102] + toks[:nb] + [102]
         assert [orig[p] for p in t["masked_pos"][:npred]] == t["masked_ids"][:npred]
+
+
+@pytest.mark.parametrize("n,world", [(103, 8), (64, 2), (5, 8), (1000, 3)])
+def test_distributed_sampler_indices_equal_torch_distributed_sampler(n, world):
+    """The reference shards with torch's DistributedSampler and calls set_epoch every epoch (run_img2txt_dist.py:295, 455): ONE global
+    permutation per epoch, rank r takes every world-th element.  vlp_amd.data.distributed_sampler_indices must yield the same indices
+    (no process group needed: num_replicas / rank are given), cover the dataset across the ranks, and change with the epoch."""
+    from torch.utils.data.distributed import DistributedSampler
+
+    from vlp_amd.data import distributed_sampler_indices
+    data = list(range(n))
+    for epoch in (0, 1, 7):
+        seen = []
+        for rank in range(world):
+            ref = DistributedSampler(data, num_replicas=world, rank=rank, shuffle=True, seed=0)
+            ref.set_epoch(epoch)
+            mine = distributed_sampler_indices(n, world, rank, epoch)
+            assert mine == list(iter(ref)) and len(mine) == -(-n // world)
+            seen += mine
+        assert set(seen) == set(data)
+    assert distributed_sampler_indices(n, world, 0, 0) != distributed_sampler_indices(n, world, 0, 1) or n <= world

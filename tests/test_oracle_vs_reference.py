@@ -195,6 +195,23 @@ def test_loader_oracle_vs_reference(mode, n_tokens, seed):
     assert all(100 + 2 <= p < 100 + 2 + nb + 1 for p in masked_pos if p)
 
 
+@pytest.mark.parametrize("mode,n_tokens,seed", [("s2s", 9, 1), ("bi", 14, 2)])
+def test_reference_loader_leaves_masked_region_columns_attendable(mode, n_tokens, seed):
+    """mask_image_regions: `input_mask[:, vis_masked_pos].fill_(0)` (seq2seq_loader.py:303-304) indexes with a numpy array -- advanced
+    indexing returns a copy, so the UNMODIFIED loader's mask is the plain s2s / bi mask although 25 region positions were drawn.  The
+    product follows this behaviour (Engine.BLOCK_MASKED_REGION_KEYS off, synthetic.make_batch(block_masked_regions=False))."""
+    from oracle import loader_oracle as LO
+    out, _, _, _, nb = _loader_case(mode, n_tokens, seed, mask_image_regions=True, vis_mask_prob=0.25)
+    input_mask, vis_masked_pos = out[2], out[9]
+    assert len(vis_masked_pos) == 25 and all(1 <= int(p) <= 100 for p in vis_masked_pos)
+    assert np.array_equal(input_mask.numpy(), LO.attention_mask(100, nb, input_mask.shape[0], mode))
+    from vlp_amd import synthetic as S
+    b = S.make_batch(2, max_len_b=20, vocab_size=512, seed=seed, vis_mask_prob=0.25, s2s_prob=1.0 if mode == "s2s" else 0.0)
+    assert all(int(b.input_mask[i][:, b.vis_masked_pos[i]].sum()) > 0 for i in range(2))
+    bb = S.make_batch(2, max_len_b=20, vocab_size=512, seed=seed, vis_mask_prob=0.25, block_masked_regions=True)
+    assert all(int(bb.input_mask[i][:, bb.vis_masked_pos[i]].sum()) == 0 for i in range(2))
+
+
 @pytest.mark.parametrize("mode,n_tokens,seed,tail,max_pred,mask_prob", [("s2s", 9, 1, True, 3, 0.15), ("bi", 14, 2, True, 3, 0.15),
                                                                       ("s2s", 31, 3, False, 5, 0.5), ("s2s", 40, 4, False, 8, 0.7)])
 def test_text_preprocessor_reproduces_reference_sample_stream(mode, n_tokens, seed, tail, max_pred, mask_prob):

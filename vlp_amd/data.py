@@ -154,6 +154,22 @@ class TextPreprocessor(object):
 # ----------------------------------------------------------------------------------------------------
 # batches
 # ----------------------------------------------------------------------------------------------------
+def distributed_sampler_indices(n, world, rank, epoch, seed=0):
+    """The index list torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, seed=seed) yields after
+    set_epoch(epoch) -- what the reference's loader iterates (run_img2txt_dist.py:295, 455): ONE permutation of the whole dataset per
+    epoch, seeded by seed + epoch and identical on every rank, padded by wrapping around to a multiple of `world`, of which rank r
+    takes every world-th element.  A rank therefore sees DIFFERENT samples every epoch (a fixed per-rank shard, reshuffled inside
+    itself, would train on statistically different batches)."""
+    g = torch.Generator()
+    g.manual_seed(seed + epoch)
+    idx = torch.randperm(n, generator=g).tolist()
+    total = -(-n // world) * world
+    pad = total - n
+    if pad:
+        idx += idx[:pad] if pad <= len(idx) else (idx * (-(-pad // len(idx))))[:pad]
+    return idx[rank:total:world]
+
+
 class BatchPrefetcher(object):
     """Iterates device-resident batches.  `examples` is a list of (image id, caption token ids); every sample picks the s2s or the
     bidirectional preprocessor with probabilities (s2s_prob, 1 - s2s_prob) like Img2txtDataset.__getitem__ (:162-166).  One batch
@@ -161,10 +177,15 @@ class BatchPrefetcher(object):
     training step; the consumer's stream waits on the copy event only."""
 
     def __init__(self, store, examples, batch_size, proc_s2s, proc_bi=None, s2s_prob=1.0, device=None, steps=None, depth=2, seed=0,
-                 vis_mask_prob=0.0):
+                 vis_mask_prob=0.0, rank=0, world=1):
+        """world > 1: `examples` is the WHOLE dataset on every rank and the per-epoch order is DistributedSampler's
+        (distributed_sampler_indices; call set_epoch(e) before iterating epoch e like the reference does, :455)."""
         self.store, self.examples, self.B = store, examples, batch_size
-        # --vis_mask_prob > 0 (mask_image_regions): int(Nv * prob) distinct region positions per sample (seq2seq_loader.py:267-269); the
-        # engine blocks their mask columns itself (vlp_mask_build region_mask, :303-304)
+        self.rank, self.world, self.epoch = rank, world, 0
+        if world > 1 and steps is None:
+            steps = -(-len(examples) // world) // batch_size
+        # --vis_mask_prob > 0 (mask_image_regions): int(Nv * prob) distinct region positions per sample (seq2seq_loader.py:267-269); their
+        # mask columns stay attendable, as in the reference (its :303-304 fills a copy; VLP_BLOCK_MASKED_REGIONS=1 makes the engine block them)
         self.n_vis_masked = int(store.nv * vis_mask_prob)
         self.procs, self.weights = [proc_s2s, proc_bi or proc_s2s], [s2s_prob, 1.0 - s2s_prob]
         self.device = torch.device(device) if device is not None else torch.device("cuda")
@@ -221,9 +242,18 @@ class BatchPrefetcher(object):
         # (input_ids, segment_ids, input_mask, lm_label_ids, masked_pos, masked_weights, is_next, task_idx, img, vis_masked_pos, vis_pe, ans)
         return (d["ids"][0], d["ids"][1], spec, d["pred"][0], d["pred"][1], d["pred"][2], is_next, d["task"], d["feat"], vis_masked_pos, raw, ans)
 
-    def __iter__(self):
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def epoch_order(self):
+        if self.world > 1:
+            return distributed_sampler_indices(len(self.examples), self.world, self.rank, self.epoch)
         order = list(range(len(self.examples)))
         random.Random(self.seed).shuffle(order)
+        return order
+
+    def __iter__(self):
+        order = self.epoch_order()
         q = queue.Queue(maxsize=self.depth)
         free = queue.Queue()
         for s in self._slots:

@@ -58,6 +58,12 @@ class Engine(object):
     WGRAD_SIDE_STREAM = os.environ.get("VLP_WGRAD_SIDE_STREAM", "1") == "1"
     LN_DEFER = os.environ.get("VLP_LN_DEFER", "1") == "1"               # LayerNorm dgamma / dbeta second stages batched into one launch per backward
     SHADOW_ON_SIDE = os.environ.get("VLP_SHADOW_SIDE", "1") == "1"      # W^T shadows transposed on the side stream during the forward
+    # mask_image_regions: the reference's loader line `input_mask[:, vis_masked_pos].fill_(0)` (seq2seq_loader.py:303-304) indexes with a
+    # numpy array -- advanced indexing, i.e. it fills a COPY and leaves the mask untouched (checked on torch 2.10 and by
+    # tests/test_oracle_vs_reference.py against the unmodified loader): masked regions enter the encoder as zeros but stay attendable.
+    # Parity follows that behaviour; VLP_BLOCK_MASKED_REGIONS=1 follows the line's comment instead ("block the masked visual feature")
+    # on the MaskSpec path (a dense attention_mask is always used as given).
+    BLOCK_MASKED_REGION_KEYS = os.environ.get("VLP_BLOCK_MASKED_REGIONS", "0") == "1"
     GROUPED_WGRAD = os.environ.get("VLP_GROUPED_WGRAD", "1") == "1"     # one vlp_gemm_tn_grouped launch per layer instead of 4 split-M wgrads + 4 reduces
     TN_SPLITS = None         # None -> vlp_amd.tuning (variant flags, split-M factor) per (M, N, K)
     # split-M factor: the wgrad outputs are small (36..144 tiles of 128x128) and the contraction long (M = 10 688), so the
@@ -551,6 +557,13 @@ class Engine(object):
             if self._params_done is not None:
                 self._side.wait_event(self._params_done)        # the transposes read every weight matrix
             with torch.cuda.stream(self._side):
+                if self._param_works is not None:
+                    # sharded optimizer step: the parameters arrive by per-bucket all-gathers that may still be in flight; the
+                    # transposes read EVERY weight matrix, so this stream waits for all of them (the main stream keeps waiting per
+                    # bucket where the forward first reads it -- Work.wait() may be called again there)
+                    for w in self._param_works.values():
+                        if w is not None:
+                            w.wait()
                 self._refresh_shadows()
                 self._shadow_ev = torch.cuda.Event()
                 self._shadow_ev.record(self._side)
@@ -566,9 +579,9 @@ class Engine(object):
         st.pretext = (pt, st_vmp) if pt is not None else None
         if mask_spec:                       # per-sample lengths -> packed masks on the device (seq2seq_loader.py:292-301)
             attention_mask.check(B, L)
-            # (with mask_image_regions the masked regions' key columns are blocked here, as the loader does on its dense mask, :303-304)
+            # (BLOCK_MASKED_REGION_KEYS: opt-in, the reference's own loader leaves the masked regions' key columns attendable, see above)
             K.mask_build(attention_mask.second_st, attention_mask.second_end, attention_mask.is_s2s, ws["maskb"], B, L, ws["Lp"], out_t=want_t,
-                         region_mask=pt["rmask"] if pt is not None else None, Nv=Nv)
+                         region_mask=pt["rmask"] if (pt is not None and self.BLOCK_MASKED_REGION_KEYS) else None, Nv=Nv)
         else:
             if attention_mask is None:
                 attention_mask = torch.ones(B, L, dtype=torch.long, device=input_ids.device)

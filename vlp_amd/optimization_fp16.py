@@ -121,6 +121,8 @@ class FP16_Optimizer_State(object):
         # skip decision lives on the device, so the count is derived from the device-side counters when it is needed:
         #   applied = _applied0 + (cur_iter - _iter0) - (skipped - _skipped0)
         self._applied0, self._iter0, self._skipped0 = 0, 0, 0
+        self._steps_issued = 0                    # host-side count of step() calls (no device read-back)
+        self._state_gathered_at = -1              # value of _steps_issued at the last consolidate() of a sharded optimizer
 
     # ---- lazily synchronised views of the device-side state -------------------------------------------
     def _sync(self):
@@ -206,17 +208,26 @@ class FP16_Optimizer_State(object):
         K.loss_scale_update(self._scale_state, self._ovf)
         eng._param_works = plan.gather_params(eng.flat["decay"], eng.flat["nodecay"])
 
+    def consolidate(self):
+        """COLLECTIVE (VLP_DDP_MODE=sharded): every rank calls it before ANY rank asks for state_dict() / apex_state_dict() -- master /
+        m / v are current only on a rank's own chunks and are all-gathered here.  A train loop that checkpoints on rank 0 only calls
+        consolidate() on all ranks first (vlp_amd/run_img2txt_dist.py); state_dict() on an unconsolidated sharded optimizer gathers
+        itself, which is correct only when every rank calls it.  No-op for the replicated step."""
+        self._gather_sharded_state()
+
     def _gather_sharded_state(self):
         """Before a checkpoint: master / m / v are current only on this rank's chunks."""
         plan = getattr(self.engine, "shard_plan", None)
-        if plan is None:
+        if plan is None or self._state_gathered_at == self._steps_issued:
             return
+        self._state_gathered_at = self._steps_issued
         self.engine.wait_params()
         i_d, i_nd = self._group_key.index("decay"), self._group_key.index("nodecay")
         plan.gather_state([self.fp32_groups_flat[i_d], self._m[i_d], self._v[i_d]], [self.fp32_groups_flat[i_nd], self._m[i_nd], self._v[i_nd]])
 
     def step(self, closure=None):
         eng = self.engine
+        self._steps_issued += 1
         plan = getattr(eng, "shard_plan", None)
         if plan is not None:
             return self._step_sharded(plan)

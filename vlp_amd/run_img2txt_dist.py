@@ -237,26 +237,20 @@ def train_step(model, optimizer, batch, lr_this_step, mask_image_regions=False, 
 
 def build_packed_loader(args, device):
     """Img2txtDataset + Preprocess4Seq2seq (vlp/seq2seq_loader.py:62-359, run_img2txt_dist.py:248-300) on a packed region store:
-    s2s / bidirectional preprocessors drawn per sample with --s2s_prob / --bi_prob, rank r of W takes every W-th example."""
+    s2s / bidirectional preprocessors drawn per sample with --s2s_prob / --bi_prob.  With world_size > 1 the per-epoch order is
+    DistributedSampler's (:295, 455): one global permutation per epoch (seeded by the epoch, the same on every rank), padded by
+    wrapping around so that every rank gets ceil(N / W) samples, rank r taking every W-th element (vlp_amd.data.distributed_sampler_indices)."""
     from .data import BatchPrefetcher, PackedRegionStore, TextPreprocessor
     store = PackedRegionStore(args.packed_features)
     with open(args.token_file) as f:
         examples = [(e[0], e[1]) for e in json.load(f)]
-    if args.world_size > 1:
-        # DistributedSampler semantics (run_img2txt_dist.py:295): every rank gets the SAME number of samples, ceil(N / W), the
-        # list being padded by wrapping around -- unequal shards would give ranks different step counts (a hung all-reduce at the
-        # epoch end and disagreeing lr schedules)
-        W, r = args.world_size, max(args.global_rank, 0)
-        per_rank = -(-len(examples) // W)
-        padded = examples + examples[:per_rank * W - len(examples)]
-        examples = padded[r::W]
-        assert len(examples) == per_rank
     kw = dict(max_pred=args.max_pred, mask_prob=args.mask_prob, vocab_size=KNOWN_VOCABS.get(args.bert_model, 28996), cls_id=synthetic.CLS_ID,
               sep_id=synthetic.SEP_ID, mask_id=synthetic.MASK_ID, unk_id=synthetic.UNK_ID, max_len=args.max_seq_length, max_len_b=args.max_len_b,
               len_vis_input=args.len_vis_input, new_segment_ids=args.new_segment_ids, trunc_seg=args.trunc_seg,
               always_truncate_tail=args.always_truncate_tail)
     return BatchPrefetcher(store, examples, args.train_batch_size, TextPreprocessor(mode="s2s", **kw), TextPreprocessor(mode="bi", **kw),
-                           s2s_prob=args.s2s_prob, device=device, seed=args.seed, vis_mask_prob=args.vis_mask_prob)
+                           s2s_prob=args.s2s_prob, device=device, seed=args.seed, vis_mask_prob=args.vis_mask_prob,
+                           rank=max(args.global_rank, 0), world=max(args.world_size, 1))
 
 
 def synthetic_batches(args, device, steps, rank):
@@ -331,6 +325,7 @@ def main(argv=None):
         losses = []
         if loader is not None:
             loader.seed = args.seed + i_epoch                                                         # new shuffle every epoch
+            loader.set_epoch(i_epoch - 1)                                                             # train_sampler.set_epoch(i_epoch-1), :455
         for step, batch in enumerate(loader if loader is not None else synthetic_batches(args, device, steps_per_epoch, args.global_rank)):
             acc = (step + 1) % args.gradient_accumulation_steps != 0
             lr = args.learning_rate * warmup_linear(global_step / t_total, args.warmup_proportion)
@@ -344,6 +339,8 @@ def main(argv=None):
                 logger.info("Epoch %d, Iter %d, Loss %.3f", i_epoch, step, losses[-1])
         torch.cuda.synchronize()
         dt = time.time() - t0
+        if hasattr(optimizer, "consolidate"):
+            optimizer.consolidate()        # collective under VLP_DDP_MODE=sharded (every rank; rank 0 alone writes the file below)
         if args.global_rank in (-1, 0):
             print("epoch %d: %d steps, %.1f samples/s/rank, loss %s" % (i_epoch, steps_per_epoch, steps_per_epoch * args.train_batch_size / dt,
                                                                         ["%.3f" % l for l in losses[-3:]]))

@@ -50,10 +50,12 @@ def build_attention_mask(L, n_a, n_b, mode):
 
 def make_batch(batch_size, max_len_b=64, len_vis_input=100, vocab_size=28996, max_pred=3,
                mask_prob=0.15, s2s_prob=1.0, tasks="img2txt", seed=1234, new_segment_ids=True,
-               feat_dim=2048, pe_dim=1607, num_answers=3129, dtype=torch.float32, min_len_b=6, vis_mask_prob=0.0):
+               feat_dim=2048, pe_dim=1607, num_answers=3129, dtype=torch.float32, min_len_b=6, vis_mask_prob=0.0,
+               block_masked_regions=False):
     """Returns a Batch of CPU tensors (float tensors in ``dtype``).  vis_mask_prob > 0 (--vis_mask_prob, mask_image_regions): per sample
-    int(len_vis_input * vis_mask_prob) distinct region positions in 1..len_vis_input (seq2seq_loader.py:267-269), whose COLUMNS of the
-    self-attention mask are blocked (:303-304)."""
+    int(len_vis_input * vis_mask_prob) distinct region positions in 1..len_vis_input (seq2seq_loader.py:267-269).  The reference's
+    `input_mask[:, vis_masked_pos].fill_(0)` (:303-304) indexes with a numpy array, fills a copy and leaves the mask as it was, so by
+    default the mask is NOT edited here either; block_masked_regions=True applies what that line's comment intends."""
     g = torch.Generator().manual_seed(seed)
     B, Nv = batch_size, len_vis_input
     L = seq_len(max_len_b, Nv)
@@ -116,8 +118,9 @@ def make_batch(batch_size, max_len_b=64, len_vis_input=100, vocab_size=28996, ma
     n_vm = int(Nv * vis_mask_prob)
     if n_vm > 0:
         vis_masked_pos = torch.stack([torch.randperm(Nv, generator=g)[:n_vm] + 1 for _ in range(B)])     # +1 for [CLS] (:269)
-        for b in range(B):
-            input_mask[b][:, vis_masked_pos[b]] = 0                                                     # :304
+        if block_masked_regions:
+            for b in range(B):
+                input_mask[b][:, vis_masked_pos[b]] = 0                                                 # what the comment of :304 intends
     else:
         vis_masked_pos = torch.zeros(B, 0, dtype=torch.long)
     return Batch(input_ids, segment_ids, input_mask, lm_label_ids, masked_pos, masked_weights,
