@@ -177,6 +177,7 @@ def main():
                                                                 "0.75 = Conceptual Captions pre-training shape, configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-varlen", action="store_true", help="skip the second, padding-free (packed) leg reported under config.varlen")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL + the DDP wrapper even for one rank (path check)")
     args = ap.parse_args()
 
@@ -273,12 +274,76 @@ def main():
             raise SystemExit("rank parameter checksums differ: %s" % [v.tolist() for v in allv])
     prof, eng.prof = eng.prof, None
 
+    # ---- second leg: the padding-free (packed) step (Engine.varlen) on the SAME batches, timed the same way.  `value`
+    # above stays the dense run; this leg is reported under config.varlen with its EXECUTED work (rows, flops) beside it.
+    varlen = None
+    env_varlen = bool(eng.varlen)        # VLP_VARLEN=1 in the environment: the FIRST leg above already ran packed (profiling runs); say so below
+    if not args.no_varlen and not env_varlen:
+        eng.varlen = True
+        step0 = args.warmup + 2 * args.steps
+        for i in range(max(args.warmup, len(pool))):          # (the first pass over the pool derives the kept lengths from the masks: one read-back per batch)
+            one(step0 + i)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rows = 0
+        for i in range(args.steps):
+            lt_v = one(step0 + args.warmup + i)
+            rows += eng.last_packed_rows or args.batch * (args.max_len_b + 103)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dtv = time.perf_counter() - t0
+        vprof = None
+        if not args.no_kernel_events:
+            eng.prof = []
+            for i in range(args.steps):
+                one(step0 + args.warmup + args.steps + i)
+            torch.cuda.synchronize()
+            vprof, eng.prof = eng.prof, None
+        if use_dist:
+            tt = torch.tensor([dtv], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtv = float(tt)
+        eng.varlen = False
+        # executed dense-contraction work per sample, fwd + bwd = 3 x fwd (SURVEY.md 8d's accounting on the KEPT rows): per kept position and layer
+        # 7 077 888 GEMM MACs + 2 n_b H attention MACs; region projections and the LM head do not depend on the caption length
+        H, NL = 768, args.layers
+        gf = []
+        for b in pool:
+            m = b.input_mask
+            n = ((m != 0).any(dim=1).to(torch.int32) * torch.arange(1, m.shape[-1] + 1, device=m.device, dtype=torch.int32)).amax(dim=1).clamp(min=102).double()
+            enc = (n * NL * (7077888.0 + 2.0 * n * H) * 2.0).sum() / m.shape[0]
+            gf.append(3.0 * (float(enc) + (1.153 + 0.247 + (0.137 if args.tasks != "vqa2" else 0.012)) * 1e9) / 1e9)
+        ex_gflop = sum(gf) / len(gf)
+        sps = world * args.batch * args.steps / dtv
+        varlen = {"value": round(sps, 2), "unit": "samples/s", "ms_per_step": round(dtv / args.steps * 1e3, 3),
+                  "real_rows_per_step": round(rows / args.steps, 1), "dense_rows_per_step": args.batch * (args.max_len_b + 103),
+                  "executed_gflop_per_sample": round(ex_gflop, 3), "dense_gflop_per_sample": FLOP_PER_SAMPLE / 1e9,
+                  "step_mfma_frac_executed": round(sps / world * ex_gflop * 1e9 / (MFMA_PEAK_TFLOPS * 1e12), 4),
+                  "final_loss": round(float((lt_v[0] + lt_v[1] + lt_v[2]).sum().detach()), 4),
+                  "note": "padding-free step: positions past a sample's last token (attended by nothing, read by no loss) are not computed; losses / "
+                          "gradients equal the dense step's (tests/test_25_varlen_gpu.py); fractions use EXECUTED flops"}
+        if vprof:
+            ms = [a.elapsed_time(b) for a, b, _ in vprof]
+            fl = [f for _, _, f in vprof]
+            ach = (sum(fl) / len(fl)) / (sum(ms) / len(ms) * 1e-3) / 1e12
+            varlen["roofline"] = {"bound": "mfma", "kernel": "vlp_gemm_nt family at the packed row counts (executed flops per launch)", "achieved": round(ach, 1),
+                                  "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                                  "avg_launch_us": round(sum(ms) / len(ms) * 1e3, 2), "avg_gflop_per_launch": round(sum(fl) / len(fl) / 1e9, 3),
+                                  "sampled_launches": len(vprof)}
+
     if args.tasks == "vqa2":
         shape_name = "VQA 2.0 fine-tune shape (bidirectional masks, P=1, answer-classifier head + BCE)"
     elif args.s2s_prob < 1.0:
         shape_name = "Conceptual Captions pre-training shape (per-sample seq2seq w.p. %.2f / bidirectional masks)" % args.s2s_prob
     else:
         shape_name = "COCO Captions fine-tune shape"
+    if env_varlen:
+        shape_name += " -- VLP_VARLEN=1: THIS LINE IS THE PADDING-FREE STEP (profiling run; flops-based fractions below assume dense work and overstate)"
     if rank == 0:
         roof = None
         if prof:
@@ -305,7 +370,8 @@ def main():
                           "rccl_ranks": dist.get_world_size() if use_dist else 1, "rank_param_checksums_equal": ranks_equal,
                           # "sharded" (VLP_DDP_MODE=sharded, N > 1): reduce-scatter, Adam on 1/N of the state per rank, parameter all-gather
                           "optimizer": "sharded" if getattr(eng, "shard_plan", None) is not None else "replicated",
-                          "param_checksum": [float(eng.flat[k].float().sum()) for k in ("decay", "nodecay")] + [float(eng.flat["decay"].float().abs().sum())]},
+                          "param_checksum": [float(eng.flat[k].float().sum()) for k in ("decay", "nodecay")] + [float(eng.flat["decay"].float().abs().sum())],
+                          "varlen": varlen, "first_leg_packed": env_varlen},
                "roofline": roof}
         if os.environ.get("VLP_DEBUG_TUNE") == "1":  # noqa
             from vlp_amd.engine import Engine

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VLP_ABI_VERSION 3
+#define VLP_ABI_VERSION 4
 
 typedef enum {
     VLP_OK = 0,
@@ -85,6 +85,9 @@ typedef struct {
                                             tile's k tiles; bias / save-grad GeLU / plain-multiplier epilogues on N % 128 == 0, N <= 8192, K > 512 -- anything
                                             else runs on the rings (27 / 29) instead (`VLP_NT_PS_GRID` caps the workgroups of a launch: investigation).
                                             Every variant computes the same result (bit-identical on gfx950: profiles/r04_nt_variant_identity.json). */
+    const int32_t* row_map;              /* ABI 4: [M] or NULL.  Padding-free (packed) runs: the dropout element of output (m, n) is
+                                            (row_map[m], n) -- the row's LOGICAL index b*L + l -- so a packed run draws the masks of the
+                                            dense run bit for bit.  NULL: row m itself. */
 } vlp_gemm_nt_args;
 int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream);
 /* The variant the calling thread's last vlp_gemm_nt launched after its fallbacks (a wave-pipelined variant without the requested
@@ -158,6 +161,10 @@ typedef struct {
     int32_t B, L, heads;
     float scale;                         /* 1/sqrt(head_dim) */
     float dropout_p; uint64_t seed; uint32_t rng_stream;
+    const int32_t* row_off;              /* ABI 4: [B+1] or NULL.  Padding-free layout: sample b owns rows [row_off[b], row_off[b+1]) of
+                                            qkv / ctx (its first n_b = row_off[b+1] - row_off[b] <= L positions; the dropped positions
+                                            must be inert: attended by no kept query -- vlp_amd.engine derives n_b from the mask).  mask,
+                                            lse and the dropout element (b, head, q, key) stay LOGICAL ([B, L, ..]).  NULL: row b*L + l. */
 } vlp_attn_fwd_args;
 int vlp_attn_fwd(const vlp_attn_fwd_args* a, void* stream);
 
@@ -196,6 +203,7 @@ typedef struct {
     int32_t B, L, heads;
     float scale;
     float dropout_p; uint64_t seed; uint32_t rng_stream;
+    const int32_t* row_off;              /* ABI 4: as in vlp_attn_fwd_args (rows of qkv / ctx / dctx / dqkv); delta, lse, masks stay logical */
 } vlp_attn_bwd_args;
 int vlp_attn_bwd(const vlp_attn_bwd_args* a, void* stream);
 
@@ -217,6 +225,7 @@ typedef struct {
     float* mean; float* rstd;            /* [M] out (may be NULL for inference) */
     int32_t M, H; float eps;
     float dropout_p; uint64_t seed; uint32_t rng_stream;
+    const int32_t* row_map;              /* ABI 4: [M] or NULL: dropout element of (m, c) is (row_map[m], c) (packed rows, see vlp_gemm_nt_args) */
 } vlp_layernorm_fwd_args;
 int vlp_layernorm_fwd(const vlp_layernorm_fwd_args* a, void* stream);
 
@@ -239,6 +248,7 @@ typedef struct {
     void* workspace; int64_t workspace_bytes;   /* vlp_layernorm_bwd_workspace_bytes(H) */
     int32_t defer_reduce;                /* 1: leave the per-block dgamma/dbeta partials in `workspace` and do NOT touch dgamma/dbeta;
                                             the caller reduces many LayerNorms at once with vlp_layernorm_bwd_reduce_batched */
+    const int32_t* row_map;              /* ABI 4: [M] or NULL: both dropout masks are drawn at (row_map[m], c) (packed rows) */
 } vlp_layernorm_bwd_args;
 int64_t vlp_layernorm_bwd_workspace_bytes(int32_t H);
 int vlp_layernorm_bwd(const vlp_layernorm_bwd_args* a, void* stream);
@@ -298,6 +308,8 @@ typedef struct {
     int32_t max_pos;                                        /* rows of pos_emb */
     const uint8_t* region_mask;                             /* ABI 3: [B*Nv] or NULL; 1 = this region row enters as zeros (word and position
                                                                stream; mask_image_regions, modeling.py:1049-1056), vlp_region_mask_build */
+    const int32_t* row_map; int32_t rows;                   /* ABI 4: packed output: `pre` has `rows` rows, row p holds logical row row_map[p] = b*L + l
+                                                               (input_ids / segment_ids / position_ids stay [B,L]).  NULL: rows = B*L, p = b*L + l */
 } vlp_embed_fwd_args;
 int vlp_embed_fwd(const vlp_embed_fwd_args* a, void* stream);
 
@@ -341,12 +353,21 @@ typedef struct {
     int32_t rows, cols, rows_pad, reserved;
 } vlp_transpose_desc;
 int vlp_transpose_batched(const vlp_transpose_desc* descs_dev, const int32_t* tile_start_dev, int32_t n, int32_t total_tiles, void* stream);
-/* out[i,:] = src[(i / P) * L + pos[i], :]   (gather_seq_out_by_pos, modeling.py:1068-1069) */
+/* out[i,:] = src[base(i / P) + pos[i], :]   (gather_seq_out_by_pos, modeling.py:1068-1069); base(b) = b * L, or row_off[b] when
+ * row_off ([B+1], ABI 4) is given (packed rows; pos must then lie inside sample b's kept rows: clamped to them) */
 int vlp_gather_rows(const void* src, int64_t lds, const int64_t* pos, void* out, int64_t ldo,
-                    int32_t B, int32_t P, int32_t L, int32_t H, void* stream);
-/* dst[(i / P) * L + pos[i], :] += src[i, :]   (backward of the gather; fp16 packed atomics) */
+                    int32_t B, int32_t P, int32_t L, int32_t H, const int32_t* row_off, void* stream);
+/* dst[base(i / P) + pos[i], :] += src[i, :]   (backward of the gather; fp16 packed atomics) */
 int vlp_scatter_add_rows(const void* src, int64_t lds, const int64_t* pos, void* dst, int64_t ldd,
-                         int32_t B, int32_t P, int32_t L, int32_t H, void* stream);
+                         int32_t B, int32_t P, int32_t L, int32_t H, const int32_t* row_off, void* stream);
+/* Padding-free (packed) row layout, ABI 4.  row_off [B+1] (int32, device): sample b keeps its first n_b = row_off[b+1] - row_off[b]
+ * positions and owns the packed rows [row_off[b], row_off[b+1]).
+ *   vlp_rowmap_build: row_map[row_off[b] + l] = b*L + l for l < n_b  (the logical index of every packed row);
+ *   vlp_rows_unpack: dst[row_map[p], 0:H] = src[p, 0:H] for p < rows (dst rows that no packed row maps to are NOT touched: clear dst first);
+ *   vlp_rows_pack:   dst[p, 0:H] = src[row_map[p], 0:H]. */
+int vlp_rowmap_build(const int32_t* row_off, int32_t B, int32_t L, int32_t* row_map, void* stream);
+int vlp_rows_unpack(const void* src, int64_t lds, const int32_t* row_map, int32_t rows, void* dst, int64_t ldd, int32_t H, void* stream);
+int vlp_rows_pack(const void* src, int64_t lds, const int32_t* row_map, int32_t rows, void* dst, int64_t ldd, int32_t H, void* stream);
 /* Incremental decoding helpers (modeling.py:1189-1253):
  *   vlp_mask_pack_rect: [B, Lq, Lk] slice of the int64 attention mask (element strides given) -> bytes [B, Lq, roundup32(Lk)];
  *   vlp_kv_append: cache[b, start + i, 0:2H] = qkv_new[b*T + i, H:3H]  (K | V of the new tokens into the K/V cache [B, Lcap, 2H]);
@@ -412,9 +433,10 @@ typedef struct {
 int vlp_beam_select(const vlp_beam_select_args* a, void* stream);
 int vlp_kv_gather(const void* src, int64_t src_rows_per_batch, void* dst, int64_t dst_rows_per_batch, const int64_t* idx, int32_t R, int32_t lo,
                   int32_t hi, int32_t row_elems, void* stream);
-/* VQA fusion (modeling.py:1044,1138): out[b,:] = h[b,0,:] * h[b,Nv+1,:]; backward adds into dh rows. */
-int vlp_vqa_mul_fwd(const void* h, void* out, int32_t B, int32_t L, int32_t Nv, int32_t H, void* stream);
-int vlp_vqa_mul_bwd(const void* h, const void* dout, void* dh, int32_t B, int32_t L, int32_t Nv, int32_t H, void* stream);
+/* VQA fusion (modeling.py:1044,1138): out[b,:] = h[b,0,:] * h[b,Nv+1,:]; backward adds into dh rows.  row_off ([B+1] or NULL, ABI 4):
+ * packed rows, sample b starts at row row_off[b] instead of b*L. */
+int vlp_vqa_mul_fwd(const void* h, void* out, int32_t B, int32_t L, int32_t Nv, int32_t H, const int32_t* row_off, void* stream);
+int vlp_vqa_mul_bwd(const void* h, const void* dout, void* dh, int32_t B, int32_t L, int32_t Nv, int32_t H, const int32_t* row_off, void* stream);
 /* dz = dy * dropmask * (y > 0): backward of Linear->ReLU->Dropout given the layer OUTPUT y */
 int vlp_relu_dropout_bwd(const void* dy, const void* y, void* dz, int64_t n, int64_t ncols, float drop_p,
                          uint64_t seed, uint32_t rng_stream, void* stream);

@@ -25,7 +25,7 @@ class GemmNtArgs(C.Structure):
     _fields_ = [("X", vp), ("ldx", i64), ("W", vp), ("ldw", i64), ("Y", vp), ("ldy", i64), ("bias", vp),
                 ("residual", vp), ("ldr", i64), ("preact", vp), ("ldp", i64), ("mul_src", vp), ("ldm", i64),
                 ("M", i32), ("N", i32), ("K", i32), ("act", i32), ("mul_mode", i32), ("alpha", f32),
-                ("dropout_p", f32), ("seed", u64), ("rng_stream", u32), ("variant", i32)]
+                ("dropout_p", f32), ("seed", u64), ("rng_stream", u32), ("variant", i32), ("row_map", vp)]
 
 
 class GemmTnArgs(C.Structure):
@@ -42,19 +42,19 @@ class ColsumArgs(C.Structure):
 class AttnFwdArgs(C.Structure):
     _fields_ = [("qkv", vp), ("ld_qkv", i64), ("mask", vp), ("ctx", vp), ("ld_ctx", i64), ("lse", vp),
                 ("B", i32), ("L", i32), ("heads", i32), ("scale", f32),
-                ("dropout_p", f32), ("seed", u64), ("rng_stream", u32)]
+                ("dropout_p", f32), ("seed", u64), ("rng_stream", u32), ("row_off", vp)]
 
 
 class AttnBwdArgs(C.Structure):
     _fields_ = [("qkv", vp), ("ld_qkv", i64), ("mask", vp), ("mask_t", vp), ("ctx", vp), ("ld_ctx", i64), ("dctx", vp), ("ld_dctx", i64),
                 ("lse", vp), ("dqkv", vp), ("ld_dqkv", i64), ("delta", vp),
                 ("B", i32), ("L", i32), ("heads", i32), ("scale", f32),
-                ("dropout_p", f32), ("seed", u64), ("rng_stream", u32)]
+                ("dropout_p", f32), ("seed", u64), ("rng_stream", u32), ("row_off", vp)]
 
 
 class LayerNormFwdArgs(C.Structure):
     _fields_ = [("x", vp), ("ldx", i64), ("gamma", vp), ("beta", vp), ("y", vp), ("ldy", i64), ("mean", vp), ("rstd", vp),
-                ("M", i32), ("H", i32), ("eps", f32), ("dropout_p", f32), ("seed", u64), ("rng_stream", u32)]
+                ("M", i32), ("H", i32), ("eps", f32), ("dropout_p", f32), ("seed", u64), ("rng_stream", u32), ("row_map", vp)]
 
 
 class LayerNormBwdArgs(C.Structure):
@@ -63,14 +63,14 @@ class LayerNormBwdArgs(C.Structure):
                 ("M", i32), ("H", i32), ("beta", i32),
                 ("dy_drop_p", f32), ("dy_seed", u64), ("dy_stream", u32),
                 ("out_drop_p", f32), ("out_seed", u64), ("out_stream", u32),
-                ("workspace", vp), ("workspace_bytes", i64), ("defer_reduce", i32)]
+                ("workspace", vp), ("workspace_bytes", i64), ("defer_reduce", i32), ("row_map", vp)]
 
 
 class EmbedFwdArgs(C.Structure):
     _fields_ = [("input_ids", vp), ("segment_ids", vp), ("word_emb", vp), ("pos_emb", vp), ("type_emb", vp),
                 ("vis_h", vp), ("vispe_h", vp), ("pre", vp),
                 ("B", i32), ("L", i32), ("Nv", i32), ("H", i32), ("vocab", i32), ("type_vocab", i32),
-                ("position_ids", vp), ("max_pos", i32), ("region_mask", vp)]
+                ("position_ids", vp), ("max_pos", i32), ("region_mask", vp), ("row_map", vp), ("rows", i32)]
 
 
 class AttnDecodeArgs(C.Structure):
@@ -174,10 +174,13 @@ SYMBOLS = {
     "vlp_copy2d": (C.c_int, [vp, i64, i32, vp, i64, i32, i32, i32, i32, vp]),
     "vlp_transpose": (C.c_int, [vp, i64, vp, i64, i32, i32, i32, vp]),
     "vlp_transpose_batched": (C.c_int, [vp, vp, i32, i32, vp]),
-    "vlp_gather_rows": (C.c_int, [vp, i64, vp, vp, i64, i32, i32, i32, i32, vp]),
-    "vlp_scatter_add_rows": (C.c_int, [vp, i64, vp, vp, i64, i32, i32, i32, i32, vp]),
-    "vlp_vqa_mul_fwd": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
-    "vlp_vqa_mul_bwd": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "vlp_gather_rows": (C.c_int, [vp, i64, vp, vp, i64, i32, i32, i32, i32, vp, vp]),
+    "vlp_scatter_add_rows": (C.c_int, [vp, i64, vp, vp, i64, i32, i32, i32, i32, vp, vp]),
+    "vlp_rowmap_build": (C.c_int, [vp, i32, i32, vp, vp]),
+    "vlp_rows_unpack": (C.c_int, [vp, i64, vp, i32, vp, i64, i32, vp]),
+    "vlp_rows_pack": (C.c_int, [vp, i64, vp, i32, vp, i64, i32, vp]),
+    "vlp_vqa_mul_fwd": (C.c_int, [vp, vp, i32, i32, i32, i32, vp, vp]),
+    "vlp_vqa_mul_bwd": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "vlp_relu_dropout_bwd": (C.c_int, [vp, vp, vp, i64, i64, f32, u64, u32, vp]),
     "vlp_gelu_bwd": (C.c_int, [vp, vp, vp, i64, vp]),
     "vlp_mlm_loss_fwd": (C.c_int, [C.POINTER(MlmLossFwdArgs), vp]),
@@ -258,7 +261,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.vlp_version() != 3:      # include/vlp_hip.h VLP_ABI_VERSION
+    if lib.vlp_version() != 4:      # include/vlp_hip.h VLP_ABI_VERSION
         raise RuntimeError("libvlp_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -289,14 +292,14 @@ def _req_cuda(*ts):
 # --------------------------------------------------------------------------------------------------
 def gemm_nt(x, w, y, M, N, K, ldx=None, ldw=None, ldy=None, bias=None, residual=None, ldr=None, preact=None, ldp=None,
             mul_src=None, ldm=None, act=ACT_NONE, mul_mode=MUL_NONE, alpha=1.0, dropout_p=0.0, seed=0, rng_stream=0,
-            variant=0):
-    _req_cuda(x, w, y)
+            variant=0, row_map=None):
+    _req_cuda(x, w, y, row_map)
     a = GemmNtArgs(ptr(x), ldx if ldx is not None else x.stride(0), ptr(w), ldw if ldw is not None else w.stride(0),
                    ptr(y), ldy if ldy is not None else y.stride(0), ptr(bias),
                    ptr(residual), (ldr if ldr is not None else (residual.stride(0) if residual is not None else 0)),
                    ptr(preact), (ldp if ldp is not None else (preact.stride(0) if preact is not None else 0)),
                    ptr(mul_src), (ldm if ldm is not None else (mul_src.stride(0) if mul_src is not None else 0)),
-                   M, N, K, act, mul_mode, alpha, dropout_p, seed, rng_stream, variant)
+                   M, N, K, act, mul_mode, alpha, dropout_p, seed, rng_stream, variant, ptr(row_map))
     _check(load().vlp_gemm_nt(C.byref(a), stream_ptr()))
 
 
@@ -317,7 +320,7 @@ def gemm_nt_splitk(x, w, y, M, N, K, splits, workspace, ldx=None, ldw=None, ldy=
                    ptr(residual), (ldr if ldr is not None else (residual.stride(0) if residual is not None else 0)),
                    ptr(preact), (ldp if ldp is not None else (preact.stride(0) if preact is not None else 0)),
                    ptr(mul_src), (ldm if ldm is not None else (mul_src.stride(0) if mul_src is not None else 0)),
-                   M, N, K, act, mul_mode, alpha, dropout_p, seed, rng_stream, 0)
+                   M, N, K, act, mul_mode, alpha, dropout_p, seed, rng_stream, 0, None)
     _check(load().vlp_gemm_nt_splitk(C.byref(a), splits, ptr(workspace), workspace.numel() * workspace.element_size(), stream_ptr()))
 
 
@@ -363,16 +366,18 @@ def colsum(a_, out, M, N, lda=None, beta=0, workspace=None):
     _check(load().vlp_colsum(C.byref(a), stream_ptr()))
 
 
-def attn_fwd(qkv, mask, ctx, lse, B, L, heads, scale, dropout_p=0.0, seed=0, rng_stream=0):
-    _req_cuda(qkv, mask, ctx, lse)
-    a = AttnFwdArgs(ptr(qkv), qkv.stride(0), ptr(mask), ptr(ctx), ctx.stride(0), ptr(lse), B, L, heads, scale, dropout_p, seed, rng_stream)
+def attn_fwd(qkv, mask, ctx, lse, B, L, heads, scale, dropout_p=0.0, seed=0, rng_stream=0, row_off=None):
+    """row_off (int32 [B+1], device): packed rows -- sample b owns rows [row_off[b], row_off[b+1]) of qkv / ctx (include/vlp_hip.h)."""
+    _req_cuda(qkv, mask, ctx, lse, row_off)
+    a = AttnFwdArgs(ptr(qkv), qkv.stride(0), ptr(mask), ptr(ctx), ctx.stride(0), ptr(lse), B, L, heads, scale, dropout_p, seed, rng_stream,
+                    ptr(row_off))
     _check(load().vlp_attn_fwd(C.byref(a), stream_ptr()))
 
 
-def attn_bwd(qkv, mask, mask_t, ctx, dctx, lse, dqkv, delta, B, L, heads, scale, dropout_p=0.0, seed=0, rng_stream=0):
-    _req_cuda(qkv, mask, mask_t, ctx, dctx, lse, dqkv, delta)
+def attn_bwd(qkv, mask, mask_t, ctx, dctx, lse, dqkv, delta, B, L, heads, scale, dropout_p=0.0, seed=0, rng_stream=0, row_off=None):
+    _req_cuda(qkv, mask, mask_t, ctx, dctx, lse, dqkv, delta, row_off)
     a = AttnBwdArgs(ptr(qkv), qkv.stride(0), ptr(mask), ptr(mask_t), ptr(ctx), ctx.stride(0), ptr(dctx), dctx.stride(0), ptr(lse),
-                    ptr(dqkv), dqkv.stride(0), ptr(delta), B, L, heads, scale, dropout_p, seed, rng_stream)
+                    ptr(dqkv), dqkv.stride(0), ptr(delta), B, L, heads, scale, dropout_p, seed, rng_stream, ptr(row_off))
     _check(load().vlp_attn_bwd(C.byref(a), stream_ptr()))
 
 
@@ -448,10 +453,10 @@ def mask_pack(mask_i64, out_u8, B, L, Lp, out_t=None):
     _check(load().vlp_mask_pack(ptr(mask_i64), ptr(out_u8), ptr(out_t), B, L, Lp, stream_ptr()))
 
 
-def layernorm_fwd(x, gamma, beta, y, M, H, mean=None, rstd=None, eps=1e-5, dropout_p=0.0, seed=0, rng_stream=0, ldx=None, ldy=None):
-    _req_cuda(x, gamma, beta, y)
+def layernorm_fwd(x, gamma, beta, y, M, H, mean=None, rstd=None, eps=1e-5, dropout_p=0.0, seed=0, rng_stream=0, ldx=None, ldy=None, row_map=None):
+    _req_cuda(x, gamma, beta, y, row_map)
     a = LayerNormFwdArgs(ptr(x), ldx if ldx is not None else x.stride(0), ptr(gamma), ptr(beta), ptr(y),
-                         ldy if ldy is not None else y.stride(0), ptr(mean), ptr(rstd), M, H, eps, dropout_p, seed, rng_stream)
+                         ldy if ldy is not None else y.stride(0), ptr(mean), ptr(rstd), M, H, eps, dropout_p, seed, rng_stream, ptr(row_map))
     _check(load().vlp_layernorm_fwd(C.byref(a), stream_ptr()))
 
 
@@ -460,13 +465,13 @@ def layernorm_bwd_workspace_bytes(H):
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M, H, workspace, beta=0, dx_drop=None,
-                  dy_drop=(0.0, 0, 0), out_drop=(0.0, 0, 0), defer_reduce=False):
+                  dy_drop=(0.0, 0, 0), out_drop=(0.0, 0, 0), defer_reduce=False, row_map=None):
     """defer_reduce: leave the dgamma / dbeta partials in `workspace` (one private slot per LayerNorm) for layernorm_bwd_reduce_batched."""
-    _req_cuda(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace)
+    _req_cuda(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, row_map)
     a = LayerNormBwdArgs(ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), dx.stride(0),
                          ptr(dx_drop), dx_drop.stride(0) if dx_drop is not None else 0, ptr(dgamma), ptr(dbeta), M, H, beta,
                          dy_drop[0], dy_drop[1], dy_drop[2], out_drop[0], out_drop[1], out_drop[2],
-                         ptr(workspace), workspace.numel() * workspace.element_size(), 1 if defer_reduce else 0)
+                         ptr(workspace), workspace.numel() * workspace.element_size(), 1 if defer_reduce else 0, ptr(row_map))
     _check(load().vlp_layernorm_bwd(C.byref(a), stream_ptr()))
 
 
@@ -477,10 +482,13 @@ def layernorm_bwd_reduce_batched(parts, dst_table, count, M, H, beta=0):
     _check(load().vlp_layernorm_bwd_reduce_batched(ptr(parts), ptr(dst_table), count, M, H, beta, stream_ptr()))
 
 
-def embed_fwd(input_ids, segment_ids, word_emb, pos_emb, type_emb, vis_h, vispe_h, pre, B, L, Nv, H, position_ids=None, region_mask=None):
-    _req_cuda(input_ids, segment_ids, word_emb, pos_emb, type_emb, pre, position_ids, region_mask)
+def embed_fwd(input_ids, segment_ids, word_emb, pos_emb, type_emb, vis_h, vispe_h, pre, B, L, Nv, H, position_ids=None, region_mask=None,
+              row_map=None, rows=0):
+    """row_map (int32 [rows], device): packed output -- row p of `pre` is logical row row_map[p] = b*L + l."""
+    _req_cuda(input_ids, segment_ids, word_emb, pos_emb, type_emb, pre, position_ids, region_mask, row_map)
     a = EmbedFwdArgs(ptr(input_ids), ptr(segment_ids), ptr(word_emb), ptr(pos_emb), ptr(type_emb), ptr(vis_h), ptr(vispe_h),
-                     ptr(pre), B, L, Nv, H, word_emb.shape[0], type_emb.shape[0], ptr(position_ids), pos_emb.shape[0], ptr(region_mask))
+                     ptr(pre), B, L, Nv, H, word_emb.shape[0], type_emb.shape[0], ptr(position_ids), pos_emb.shape[0], ptr(region_mask),
+                     ptr(row_map), rows)
     _check(load().vlp_embed_fwd(C.byref(a), stream_ptr()))
 
 
@@ -549,24 +557,42 @@ def transpose_batched(batch):
     _check(load().vlp_transpose_batched(ptr(descs), ptr(ts), n, tot, stream_ptr()))
 
 
-def gather_rows(src, lds, pos, out, ldo, B, P, L, H):
-    _req_cuda(src, pos, out)
-    _check(load().vlp_gather_rows(ptr(src), lds, ptr(pos), ptr(out), ldo, B, P, L, H, stream_ptr()))
+def gather_rows(src, lds, pos, out, ldo, B, P, L, H, row_off=None):
+    _req_cuda(src, pos, out, row_off)
+    _check(load().vlp_gather_rows(ptr(src), lds, ptr(pos), ptr(out), ldo, B, P, L, H, ptr(row_off), stream_ptr()))
 
 
-def scatter_add_rows(src, lds, pos, dst, ldd, B, P, L, H):
-    _req_cuda(src, pos, dst)
-    _check(load().vlp_scatter_add_rows(ptr(src), lds, ptr(pos), ptr(dst), ldd, B, P, L, H, stream_ptr()))
+def scatter_add_rows(src, lds, pos, dst, ldd, B, P, L, H, row_off=None):
+    _req_cuda(src, pos, dst, row_off)
+    _check(load().vlp_scatter_add_rows(ptr(src), lds, ptr(pos), ptr(dst), ldd, B, P, L, H, ptr(row_off), stream_ptr()))
 
 
-def vqa_mul_fwd(h, out, B, L, Nv, H):
-    _req_cuda(h, out)
-    _check(load().vlp_vqa_mul_fwd(ptr(h), ptr(out), B, L, Nv, H, stream_ptr()))
+def rowmap_build(row_off, B, L, row_map):
+    """row_map[row_off[b] + l] = b*L + l for l < row_off[b+1] - row_off[b]  (packed rows -> logical rows)."""
+    _req_cuda(row_off, row_map)
+    _check(load().vlp_rowmap_build(ptr(row_off), B, L, ptr(row_map), stream_ptr()))
 
 
-def vqa_mul_bwd(h, dout, dh, B, L, Nv, H):
-    _req_cuda(h, dout, dh)
-    _check(load().vlp_vqa_mul_bwd(ptr(h), ptr(dout), ptr(dh), B, L, Nv, H, stream_ptr()))
+def rows_unpack(src, row_map, rows, dst, H):
+    """dst[row_map[p]] = src[p]; untouched dst rows keep their contents (clear dst first)."""
+    _req_cuda(src, row_map, dst)
+    _check(load().vlp_rows_unpack(ptr(src), src.stride(0), ptr(row_map), rows, ptr(dst), dst.stride(0), H, stream_ptr()))
+
+
+def rows_pack(src, row_map, rows, dst, H):
+    """dst[p] = src[row_map[p]]"""
+    _req_cuda(src, row_map, dst)
+    _check(load().vlp_rows_pack(ptr(src), src.stride(0), ptr(row_map), rows, ptr(dst), dst.stride(0), H, stream_ptr()))
+
+
+def vqa_mul_fwd(h, out, B, L, Nv, H, row_off=None):
+    _req_cuda(h, out, row_off)
+    _check(load().vlp_vqa_mul_fwd(ptr(h), ptr(out), B, L, Nv, H, ptr(row_off), stream_ptr()))
+
+
+def vqa_mul_bwd(h, dout, dh, B, L, Nv, H, row_off=None):
+    _req_cuda(h, dout, dh, row_off)
+    _check(load().vlp_vqa_mul_bwd(ptr(h), ptr(dout), ptr(dh), B, L, Nv, H, ptr(row_off), stream_ptr()))
 
 
 def relu_dropout_bwd(dy, y, dz, n, ncols, drop_p=0.0, seed=0, rng_stream=0):

@@ -54,6 +54,9 @@ struct AttnParams {
     // and every query of the tile has at least one attended key, so exp2(-10000 log2 e - max) underflows to 0) are skipped: bit-identical
     // results, ~1/3 fewer tiles under seq2seq masks (regions never attend caption tokens; tokens attend causally)
     int skip;
+    // padding-free (packed) rows, training kernels: sample b owns rows [row_off[b], row_off[b+1]) of q / k / v / ctx / dctx / dqkv (its first
+    // n_b positions); mask, lse, delta and the dropout element stay logical [B, L, ..].  nullptr: row b*L + l, n_b = L.
+    const int32_t* row_off;
 };
 
 #ifdef VLP_ATTN_TRACE
@@ -184,9 +187,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
     const int b = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
     const int L = p.Lk;                        // keys (rows >= Lk of the LDS tiles are zero, mask bytes there are 2)
     const int Lq = p.Lq;
-    const f16* qbase = p.q + (int64_t)b * p.bs_q * p.ld_q + h * HD;
-    const f16* kbase = p.k + (int64_t)b * p.bs_kv * p.ld_kv + h * HD;
-    const f16* vbase = p.v + (int64_t)b * p.bs_kv * p.ld_kv + h * HD;
+    // packed rows (training, Lq == Lk): the sample's nb kept positions start at row rb; positions >= nb are attended by no kept query
+    // (mask byte 0 -> probability exactly 0 in the dense run as well), so their K / V rows are staged as zeros and their query tiles skipped
+    const int rb_pk = p.row_off ? p.row_off[b] : 0;
+    const int nb = p.row_off ? p.row_off[b + 1] - rb_pk : L;       // key rows to stage
+    const int nq = p.row_off ? nb : Lq;                            // query rows to compute
+    const int64_t rbq = p.row_off ? (int64_t)rb_pk : (int64_t)b * p.bs_q, rbk = p.row_off ? (int64_t)rb_pk : (int64_t)b * p.bs_kv;
+    const int64_t rbo = p.row_off ? (int64_t)rb_pk : (int64_t)b * Lq;      // ctx rows
+    const f16* qbase = p.q + rbq * p.ld_q + h * HD;
+    const f16* kbase = p.k + rbk * p.ld_kv + h * HD;
+    const f16* vbase = p.v + rbk * p.ld_kv + h * HD;
 
     const f16* kpre = p.n_prefix ? p.k2 + (int64_t)(b / p.beams) * p.bs_kv2 * p.ld_kv + h * HD : nullptr;
     const f16* vpre = p.n_prefix ? p.v2 + (int64_t)(b / p.beams) * p.bs_kv2 * p.ld_kv + h * HD : nullptr;
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
         stage_rowmajor(Ks, kbase, p.ld_kv, L, LP, tid, NW * 64, kpre, p.n_prefix);
         stage_rowmajor(Vs, vbase, p.ld_kv, L, LP, tid, NW * 64, vpre, p.n_prefix);
     } else {
-        stage_two_rowmajor<LP, NW * 64>(Ks, kbase, p.ld_kv, Vs, vbase, p.ld_kv, L, tid);
+        stage_two_rowmajor<LP, NW * 64>(Ks, kbase, p.ld_kv, Vs, vbase, p.ld_kv, nb, tid);
     }
     TRACE(1);
     __syncthreads();
@@ -203,10 +213,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
 
     // (Round 4, measured and not kept: requesting the Q fragments + mask words of the wave's NEXT query tile while the current one is
     // computed -- 149 instead of 108 VGPRs, same 3 workgroups per CU -- 36.5 us against 34.3 us at B = 64, tools/attn_lab.py.)
-    const int nqt = (Lq + 15) / 16;
+    const int nqt = (nq + 15) / 16;
     for (int qt = wid; qt < nqt; qt += NW) {
         const int q = qt * 16 + li;             // this lane's query (column of every transposed tile)
-        const int qc = min(q, Lq - 1);
+        const int qc = min(q, nq - 1);
         int gq = g;                             // opaque copy: keeps per-key index math inside the loop (no LICM + spills)
         asm volatile("" : "+v"(gq));
         const f16* qrow = qbase + (int64_t)qc * p.ld_q;
@@ -291,7 +301,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
         sum += __shfl_xor(sum, 32, 64);
         // the normalisation and the dropout scale 1/(1-p) are applied to the 16 outputs of the lane instead of its 4*NT probabilities
         const float inv = p.drop.scale / sum;
-        if (p.lse && g == 0 && q < Lq) p.lse[((int64_t)b * p.heads + h) * Lq + q] = (mx + __builtin_amdgcn_logf(sum)) * LN2_F;
+        if (p.lse && g == 0 && q < nq) p.lse[((int64_t)b * p.heads + h) * Lq + q] = (mx + __builtin_amdgcn_logf(sum)) * LN2_F;
 
         // P^T (UNnormalised exp2 values in (0, 1], dropped entries zeroed) as fp16 B-operand fragments: pair u = tiles (2u, 2u+1)
         uint32_t pfw[NT / 2][4];                 // pair u = tiles (2u, 2u+1); words 2hh, 2hh+1 = the four probabilities of tile 2u+hh
@@ -337,11 +347,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
 #pragma unroll
             for (int n = 0; n < 4; ++n) o[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfr[n], pfu, o[n], 0, 0, 0);
         }
-        if (q < Lq) {
+        if (q < nq) {
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 f16x4 ov = (f16x4){(f16)(o[n][0] * inv), (f16)(o[n][1] * inv), (f16)(o[n][2] * inv), (f16)(o[n][3] * inv)};
-                st4_out<VLP_SS_ATTN>(p.ctx + ((int64_t)b * Lq + q) * p.ld_ctx + h * HD + n * 16 + 4 * g, ov);
+                st4_out<VLP_SS_ATTN>(p.ctx + (rbo + q) * p.ld_ctx + h * HD + n * 16 + 4 * g, ov);
             }
         }
         if (qt == wid) TRACE(6);       // first tile stored
@@ -907,8 +917,9 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
     u32x4 vq[IT], vd[IT];
     auto request_tiles = [&](int it) {
         const int b_ = it / p.heads, h_ = it % p.heads;
-        const __amdgpu_buffer_rsrc_t rq = rows_rsrc(p.qkv + (int64_t)b_ * L * p.ld_qkv + h_ * HD, p.ld_qkv, L),
-                                     rdo = rows_rsrc(p.dctx + (int64_t)b_ * L * p.ld_dctx + h_ * HD, p.ld_dctx, L);
+        const int rb_ = p.row_off ? p.row_off[b_] : b_ * L, nb_ = p.row_off ? p.row_off[b_ + 1] - rb_ : L;      // packed rows: the sample's kept rows
+        const __amdgpu_buffer_rsrc_t rq = rows_rsrc(p.qkv + (int64_t)rb_ * p.ld_qkv + h_ * HD, p.ld_qkv, nb_),
+                                     rdo = rows_rsrc(p.dctx + (int64_t)rb_ * p.ld_dctx + h_ * HD, p.ld_dctx, nb_);
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             const int idx = tid + i * NTHR, r = idx >> 3, c = idx & 7;
@@ -922,7 +933,11 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
     const int b = item / p.heads, h = item % p.heads;
     int g = g0, li = li0;                    // opaque per-item copies: the LDS address math of the unrolled pair loop is item-invariant, and hoisted
     asm volatile("" : "+v"(g), "+v"(li));    // out of the item loop it would occupy ~60 registers across both phases (spills at the 168-register budget)
-    const f16* vbase = p.qkv + (int64_t)b * L * p.ld_qkv + h * HD + 2 * p.H;
+    // packed rows: the sample's nb kept positions start at row rb.  Positions >= nb are treated like the padding rows >= L: query rows get
+    // lse = +inf, key columns a -inf mask base -- their probabilities were exactly 0 in the dense run too (mask byte 0 / dO = 0), so every
+    // sum below receives the same zeros
+    const int rb = p.row_off ? p.row_off[b] : b * L, nb = p.row_off ? p.row_off[b + 1] - rb : L;
+    const f16* vbase = p.qkv + (int64_t)rb * p.ld_qkv + h * HD + 2 * p.H;
 
     if (item == (int)blockIdx.x) TRACE(0);
     // ---- prologue: EVERY global load of the item is issued before the first one is consumed (one memory round trip, not four: the
@@ -933,8 +948,8 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
     uint32_t mw[NT];                                      // mask bytes of this lane's key for ALL queries (word t = queries 16 t + 4g .. +3)
     u32x4 vo[IT], vk[IT];
     {
-        const __amdgpu_buffer_rsrc_t ro = rows_rsrc(p.ctx + (int64_t)b * L * p.ld_ctx + h * HD, p.ld_ctx, L),
-                                     rkk = rows_rsrc(p.qkv + (int64_t)b * L * p.ld_qkv + h * HD + p.H, p.ld_qkv, L);
+        const __amdgpu_buffer_rsrc_t ro = rows_rsrc(p.ctx + (int64_t)rb * p.ld_ctx + h * HD, p.ld_ctx, nb),
+                                     rkk = rows_rsrc(p.qkv + (int64_t)rb * p.ld_qkv + h * HD + p.H, p.ld_qkv, nb);
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             const int idx = tid + i * NTHR, r = idx >> 3, c = idx & 7;
@@ -943,7 +958,7 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
         }
 #pragma unroll
         for (int i = 0; i < ST; ++i) lse_v[i] = p.lse[((int64_t)b * p.heads + h) * L + min(tid + i * NTHR, L - 1)];
-        const int kc = min(key, L - 1);
+        const int kc = min(key, nb - 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) vf[ks] = ld8(vbase + (int64_t)kc * p.ld_qkv + ks * 32 + g * 8);
         // unconditional loads from a clamped address + a bitwise select: a `cond ? *ptr : pad` lets the compiler sink every load into its
@@ -988,7 +1003,7 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
             const int r = tid + i * NTHR;
             if (r < LP) {
                 // padding rows (r >= L): +inf, so that every probability of the row comes out as exp2(-inf) = 0 without a per-element test
-                lse_s[r] = r < L ? lse_v[i] * LOG2E_F : INFINITY;
+                lse_s[r] = r < nb ? lse_v[i] * LOG2E_F : INFINITY;
                 rk_s[r] = p.drop.thresh ? drop_rowkey(p.drop, (uint64_t)(((int64_t)b * p.heads + h) * L + min(r, L - 1))) : 0u;   // dropout element = (row (b, h, q), col key)
             }
         }
@@ -1005,13 +1020,13 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
     if (item + (int)gridDim.x < nitems) request_tiles(item + gridDim.x);        // the staging registers are free again: next item's tiles
 
     // ---- phase 1: this wave's key tile against every query tile ------------------------------------------------------------------------
-    const int nkt = (L + 15) / 16;
+    const int nkt = (nb + 15) / 16;
     const uint32_t keyphi = ((uint32_t)key >> 1) * VLP_PHI, kodd = (uint32_t)key & 1u;
     const float sc2 = p.scale * LOG2E_F;
     // additive mask term in the log2 domain WITHOUT a per-element padding test: byte b in {0, 1} -> b * C1 + kmbase with kmbase = -C1 for a
     // real key; a padding key (>= L) has kmbase = -inf, a padding query row has lse = +inf (above): their byte is 2, and 2 C1 - inf = -inf /
     // C1 - (+inf) = -inf -- every excluded probability is exp2(-inf) = 0 and multiplies finite numbers only (dO, Q rows >= L are zero)
-    const float kmbase = key < L ? -MASK_C1 : -INFINITY;
+    const float kmbase = key < nb ? -MASK_C1 : -INFINITY;
     // (Packed fp32 pair arithmetic -- v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on element pairs -- was measured for this block and is a wash:
     // 54.2 - 54.5 us against 54.0 - 55.4 us per layer; in the FFN-up GEMM epilogue the packed erf / gelu' pair was 17 % SLOWER than the scalar
     // form (89 vs 76 us per launch).  The guide prices v_pk_* above two scalar ops on this chip; kept scalar.)
@@ -1028,7 +1043,7 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
         // dead blocks (P = 0 exactly: no (query, key) pair attended AND every query has an attended key somewhere): the PAIR is skipped when
         // both of its blocks are dead; a single dead block of a live pair is simply computed -- its probabilities come out as exact zeros
         // (exp2 of -14 000)
-        bool pair_live = kt < nkt;
+        bool pair_live = kt < nkt && 32 * u < nb;        // (a query pair past the sample's kept rows: lse = +inf, every probability 0)
         if (pair_live && p.skip) {
             bool need = false;
 #pragma unroll
@@ -1114,8 +1129,8 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
 #ifdef VLP_ATTN_TRACE
     if (item == (int)blockIdx.x && wid == (int)(blockIdx.x % NT) && lane == 0 && blockIdx.x < 4096) g_attn_trace[blockIdx.x * 8 + 7] = __builtin_readcyclecounter();     // end of phase 1 of wave blockIdx % NT
 #endif
-    if (key < L) {
-        f16* drow = p.dqkv + ((int64_t)b * L + key) * p.ld_dqkv + h * HD;
+    if (key < nb) {
+        f16* drow = p.dqkv + ((int64_t)rb + key) * p.ld_dqkv + h * HD;
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const f16x4 kv = (f16x4){(f16)dk[n][0], (f16)dk[n][1], (f16)dk[n][2], (f16)dk[n][3]};
@@ -1130,7 +1145,7 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
 
     // ---- phase 2: dQ^T tiles (rows = head-dim 16 n + 4g + reg, col = query), K^T . dS^T over all keys ---------------------------------
     // (two tiles of a wave in flight at once: the NT/2 MFMAs of a tile form one dependent chain)
-    const int nqt = (L + 15) / 16;
+    const int nqt = (nb + 15) / 16;
     for (int t = wid; t < nqt * 4; t += 2 * NT) {
         const int t1 = t + NT;
         const bool two = t1 < nqt * 4;
@@ -1144,13 +1159,13 @@ __global__ __launch_bounds__(NT * 64, NT == 12 ? 3 : 2) void attn_bwd_full_kerne
                                                         tr_frag_dsf<LP>(dSs, 32 * kp, 32 * kp + 16, 16 * qt1, g, li), o1, 0, 0, 0);
         }
         const int q0 = qt0 * 16 + li, q1 = qt1 * 16 + li;
-        if (q0 < L) {
+        if (q0 < nb) {
             const f16x4 ov = (f16x4){(f16)o0[0], (f16)o0[1], (f16)o0[2], (f16)o0[3]};
-            st4_out<VLP_SS_ATTN>(p.dqkv + ((int64_t)b * L + q0) * p.ld_dqkv + h * HD + n0 * 16 + 4 * g, ov);
+            st4_out<VLP_SS_ATTN>(p.dqkv + ((int64_t)rb + q0) * p.ld_dqkv + h * HD + n0 * 16 + 4 * g, ov);
         }
-        if (two && q1 < L) {
+        if (two && q1 < nb) {
             const f16x4 ov = (f16x4){(f16)o1[0], (f16)o1[1], (f16)o1[2], (f16)o1[3]};
-            st4_out<VLP_SS_ATTN>(p.dqkv + ((int64_t)b * L + q1) * p.ld_dqkv + h * HD + n1 * 16 + 4 * g, ov);
+            st4_out<VLP_SS_ATTN>(p.dqkv + ((int64_t)rb + q1) * p.ld_dqkv + h * HD + n1 * 16 + 4 * g, ov);
         }
     }
     if (item == (int)blockIdx.x) TRACE(6);
@@ -1218,6 +1233,7 @@ extern "C" int vlp_attn_fwd(const vlp_attn_fwd_args* a, void* stream) {
     p.drop = make_drop(a->dropout_p, a->seed, a->rng_stream);
     p.q = (const f16*)a->qkv; p.k = p.q + p.H; p.v = p.q + 2 * p.H;
     p.ld_q = p.ld_kv = a->ld_qkv; p.bs_q = p.bs_kv = a->L; p.Lq = p.Lk = a->L;
+    p.row_off = a->row_off;
     return launch_attn_fwd(p, (hipStream_t)stream);
 }
 
@@ -1268,6 +1284,7 @@ extern "C" int vlp_attn_bwd(const vlp_attn_bwd_args* a, void* stream) {
     p.scale = a->scale;
     p.drop = make_drop(a->dropout_p, a->seed, a->rng_stream);
     p.skip = attn_skip_enabled();
+    p.row_off = a->row_off;
     const int LP = lp_of(a->L);
     const size_t smem_dq = (size_t)2 * LP * HD * 2;
     const size_t smem_dkv = (size_t)2 * LP * HD * 2 + (size_t)3 * LP * 4;
@@ -1285,6 +1302,8 @@ extern "C" int vlp_attn_bwd(const vlp_attn_bwd_args* a, void* stream) {
     // merged kernel was validated against)
     const char* bwd_env = getenv("VLP_ATTN_BWD");         // read at every launch so that tests can toggle it
     const bool split = bwd_env && bwd_env[0] == 's';
+    VLP_CHECK_ARG(a->row_off == nullptr || (LP <= 192 && !split && !(bwd_env && bwd_env[0] == 'x')),
+                  "vlp_attn_bwd: packed rows (row_off) are supported by the one-kernel backward at L <= 192");
     if (!split) {
         const size_t smem_one = (size_t)3 * LP * HD * 2 + (size_t)3 * LP * 4;
 #define LAUNCH_ONE(NT_, KPW_)                                                                                           \

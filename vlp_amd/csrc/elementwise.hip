@@ -7,7 +7,7 @@
 // =================================================================================================
 __global__ __launch_bounds__(256) void embed_fwd_kernel(vlp_embed_fwd_args a) {
     const int nch = a.H >> 3;
-    const int64_t total = (int64_t)a.B * a.L * nch;
+    const int64_t total = (a.row_map ? (int64_t)a.rows : (int64_t)a.B * a.L) * nch;
     const f16* word = (const f16*)a.word_emb;
     const f16* pos = (const f16*)a.pos_emb;
     const f16* typ = (const f16*)a.type_emb;
@@ -16,7 +16,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(vlp_embed_fwd_args a) {
     f16* pre = (f16*)a.pre;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % nch);
-        const int64_t row = i / nch;
+        const int64_t prow = i / nch;                                   // output row (packed layout: row_map gives its logical index)
+        const int64_t row = a.row_map ? (int64_t)a.row_map[prow] : prow;
         const int l = (int)(row % a.L);
         const int b = (int)(row / a.L);
         f16x8 w, p;
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(vlp_embed_fwd_args a) {
         f16x8 t = ld8(typ + sg * a.H + c * 8), o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (f16)((float)w[e] + (float)p[e] + (float)t[e]);
-        st8(pre + row * a.H + c * 8, o);
+        st8(pre + prow * a.H + c * 8, o);
     }
 }
 extern "C" int vlp_embed_fwd(const vlp_embed_fwd_args* a, void* stream) {
@@ -50,7 +51,8 @@ extern "C" int vlp_embed_fwd(const vlp_embed_fwd_args* a, void* stream) {
     VLP_ENTER(a->pre, "vlp_embed_fwd");
     VLP_CHECK_ARG(a->H % 8 == 0 && a->B > 0 && a->L > 0 && a->Nv >= 0 && a->Nv + 1 < a->L + 1, "vlp_embed_fwd: bad shape");
     VLP_CHECK_ARG(a->Nv == 0 || (a->vis_h && a->vispe_h), "vlp_embed_fwd: region rows need vis_h / vispe_h");
-    const int64_t total = (int64_t)a->B * a->L * (a->H / 8);
+    VLP_CHECK_ARG(a->row_map == nullptr || (a->rows > 0 && (int64_t)a->rows <= (int64_t)a->B * a->L), "vlp_embed_fwd: packed output needs 0 < rows <= B*L");
+    const int64_t total = (a->row_map ? (int64_t)a->rows : (int64_t)a->B * a->L) * (a->H / 8);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a);
@@ -372,87 +374,143 @@ extern "C" int vlp_transpose(const void* src, int64_t lds, void* dst, int64_t ld
 // =================================================================================================
 // gather / scatter of masked positions (modeling.py:1068-1069) and the VQA fusion (:1044, :1138)
 // =================================================================================================
-__global__ void gather_rows_kernel(const f16* src, int64_t lds, const int64_t* pos, f16* out, int64_t ldo, int B, int P, int L, int H) {
+// first row and row count of sample b: dense [B, L] layout, or the packed layout given by row_off [B+1]
+DEVFN int64_t sample_base(const int32_t* row_off, int64_t b, int L, int& n) {
+    if (row_off) { const int lo = row_off[b]; n = row_off[b + 1] - lo; return lo; }
+    n = L;
+    return b * L;
+}
+__global__ void gather_rows_kernel(const f16* src, int64_t lds, const int64_t* pos, f16* out, int64_t ldo, int B, int P, int L, int H, const int32_t* row_off) {
     const int nch = H >> 3;
     const int64_t total = (int64_t)B * P * nch;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % nch);
         const int64_t r = i / nch;
+        int n;
+        const int64_t base = sample_base(row_off, r / P, L, n);
         int64_t ps = pos[r];
-        ps = ps < 0 ? 0 : (ps >= L ? L - 1 : ps);
-        st8(out + r * ldo + c * 8, ld8(src + ((r / P) * L + ps) * lds + c * 8));
+        ps = ps < 0 ? 0 : (ps >= n ? n - 1 : ps);
+        st8(out + r * ldo + c * 8, ld8(src + (base + ps) * lds + c * 8));
     }
 }
 extern "C" int vlp_gather_rows(const void* src, int64_t lds, const int64_t* pos, void* out, int64_t ldo, int32_t B, int32_t P, int32_t L,
-                               int32_t H, void* stream) {
+                               int32_t H, const int32_t* row_off, void* stream) {
     VLP_CHECK_ARG(src && pos && out && B > 0 && P > 0 && L > 0 && H % 8 == 0 && lds % 8 == 0 && ldo % 8 == 0, "vlp_gather_rows: bad args");
     VLP_ENTER(src, "vlp_gather_rows");
     const int64_t total = (int64_t)B * P * (H / 8);
     hipLaunchKernelGGL(gather_rows_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)src, lds, pos,
-                       (f16*)out, ldo, B, P, L, H);
+                       (f16*)out, ldo, B, P, L, H, row_off);
     VLP_CHECK_LAUNCH("vlp_gather_rows");
     return VLP_OK;
 }
-__global__ void scatter_add_rows_kernel(const f16* src, int64_t lds, const int64_t* pos, f16* dst, int64_t ldd, int B, int P, int L, int H) {
+__global__ void scatter_add_rows_kernel(const f16* src, int64_t lds, const int64_t* pos, f16* dst, int64_t ldd, int B, int P, int L, int H, const int32_t* row_off) {
     const int nch = H >> 3;
     const int64_t total = (int64_t)B * P * nch;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % nch);
         const int64_t r = i / nch;
+        int n;
+        const int64_t base = sample_base(row_off, r / P, L, n);
         int64_t ps = pos[r];
-        ps = ps < 0 ? 0 : (ps >= L ? L - 1 : ps);
+        ps = ps < 0 ? 0 : (ps >= n ? n - 1 : ps);
         const f16x8 v = ld8(src + r * lds + c * 8);
-        __half2* d = reinterpret_cast<__half2*>(dst + ((r / P) * L + ps) * ldd + c * 8);
+        __half2* d = reinterpret_cast<__half2*>(dst + (base + ps) * ldd + c * 8);
 #pragma unroll
         for (int e = 0; e < 4; ++e) unsafeAtomicAdd(d + e, __floats2half2_rn((float)v[2 * e], (float)v[2 * e + 1]));
     }
 }
 extern "C" int vlp_scatter_add_rows(const void* src, int64_t lds, const int64_t* pos, void* dst, int64_t ldd, int32_t B, int32_t P, int32_t L,
-                                    int32_t H, void* stream) {
+                                    int32_t H, const int32_t* row_off, void* stream) {
     VLP_CHECK_ARG(src && pos && dst && B > 0 && P > 0 && L > 0 && H % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0, "vlp_scatter_add_rows: bad args");
     VLP_ENTER(src, "vlp_scatter_add_rows");
     const int64_t total = (int64_t)B * P * (H / 8);
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)src, lds,
-                       pos, (f16*)dst, ldd, B, P, L, H);
+                       pos, (f16*)dst, ldd, B, P, L, H, row_off);
     VLP_CHECK_LAUNCH("vlp_scatter_add_rows");
     return VLP_OK;
 }
 
-__global__ void vqa_mul_fwd_kernel(const f16* h, f16* out, int B, int L, int Nv, int H) {
+__global__ void vqa_mul_fwd_kernel(const f16* h, f16* out, int B, int L, int Nv, int H, const int32_t* row_off) {
     const int64_t total = (int64_t)B * H;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = i / H;
         const int c = (int)(i % H);
-        const float a0 = (float)h[(b * L) * H + c], a1 = (float)h[(b * L + Nv + 1) * H + c];
+        const int64_t r0 = row_off ? (int64_t)row_off[b] : b * L;
+        const float a0 = (float)h[r0 * H + c], a1 = (float)h[(r0 + Nv + 1) * H + c];
         out[i] = (f16)(a0 * a1);
     }
 }
-extern "C" int vlp_vqa_mul_fwd(const void* h, void* out, int32_t B, int32_t L, int32_t Nv, int32_t H, void* stream) {
+extern "C" int vlp_vqa_mul_fwd(const void* h, void* out, int32_t B, int32_t L, int32_t Nv, int32_t H, const int32_t* row_off, void* stream) {
     VLP_CHECK_ARG(h && out && B > 0 && Nv + 1 < L, "vlp_vqa_mul_fwd: bad args");
     VLP_ENTER(h, "vlp_vqa_mul_fwd");
-    hipLaunchKernelGGL(vqa_mul_fwd_kernel, dim3(cdiv((int64_t)B * H, 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)h, (f16*)out, B, L, Nv, H);
+    hipLaunchKernelGGL(vqa_mul_fwd_kernel, dim3(cdiv((int64_t)B * H, 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)h, (f16*)out, B, L, Nv, H, row_off);
     VLP_CHECK_LAUNCH("vlp_vqa_mul_fwd");
     return VLP_OK;
 }
 // dh[b,0] += dout * h[b,Nv+1];  dh[b,Nv+1] += dout * h[b,0]   (rows are private to this kernel -> plain RMW)
-__global__ void vqa_mul_bwd_kernel(const f16* h, const f16* dout, f16* dh, int B, int L, int Nv, int H) {
+__global__ void vqa_mul_bwd_kernel(const f16* h, const f16* dout, f16* dh, int B, int L, int Nv, int H, const int32_t* row_off) {
     const int64_t total = (int64_t)B * H;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = i / H;
         const int c = (int)(i % H);
-        const int64_t i0 = (b * L) * H + c, i1 = (b * L + Nv + 1) * H + c;
+        const int64_t r0 = row_off ? (int64_t)row_off[b] : b * L;
+        const int64_t i0 = r0 * H + c, i1 = (r0 + Nv + 1) * H + c;
         const float d = (float)dout[i], a0 = (float)h[i0], a1 = (float)h[i1];
         dh[i0] = (f16)((float)dh[i0] + d * a1);
         dh[i1] = (f16)((float)dh[i1] + d * a0);
     }
 }
-extern "C" int vlp_vqa_mul_bwd(const void* h, const void* dout, void* dh, int32_t B, int32_t L, int32_t Nv, int32_t H, void* stream) {
+extern "C" int vlp_vqa_mul_bwd(const void* h, const void* dout, void* dh, int32_t B, int32_t L, int32_t Nv, int32_t H, const int32_t* row_off, void* stream) {
     VLP_CHECK_ARG(h && dout && dh && B > 0 && Nv + 1 < L, "vlp_vqa_mul_bwd: bad args");
     VLP_ENTER(h, "vlp_vqa_mul_bwd");
     hipLaunchKernelGGL(vqa_mul_bwd_kernel, dim3(cdiv((int64_t)B * H, 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)h, (const f16*)dout,
-                       (f16*)dh, B, L, Nv, H);
+                       (f16*)dh, B, L, Nv, H, row_off);
     VLP_CHECK_LAUNCH("vlp_vqa_mul_bwd");
     return VLP_OK;
+}
+
+// =================================================================================================
+// padding-free (packed) row layout: sample b keeps its first n_b = row_off[b+1] - row_off[b] positions (include/vlp_hip.h)
+// =================================================================================================
+__global__ void rowmap_build_kernel(const int32_t* row_off, int L, int32_t* row_map) {
+    const int b = blockIdx.x;
+    const int lo = row_off[b], n = row_off[b + 1] - lo;
+    for (int l = threadIdx.x; l < n; l += blockDim.x) row_map[lo + l] = b * L + l;
+}
+extern "C" int vlp_rowmap_build(const int32_t* row_off, int32_t B, int32_t L, int32_t* row_map, void* stream) {
+    VLP_CHECK_ARG(row_off && row_map && B > 0 && L > 0, "vlp_rowmap_build: bad args");
+    VLP_ENTER(row_off, "vlp_rowmap_build");
+    hipLaunchKernelGGL(rowmap_build_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, row_off, L, row_map);
+    VLP_CHECK_LAUNCH("vlp_rowmap_build");
+    return VLP_OK;
+}
+template <bool UNPACK>
+__global__ void rows_move_kernel(const f16* src, int64_t lds, const int32_t* row_map, int rows, f16* dst, int64_t ldd, int H) {
+    const int nch = H >> 3;
+    const int64_t total = (int64_t)rows * nch;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nch);
+        const int64_t p = i / nch, r = row_map[p];
+        if (UNPACK) st8(dst + r * ldd + c * 8, ld8(src + p * lds + c * 8));
+        else st8(dst + p * ldd + c * 8, ld8(src + r * lds + c * 8));
+    }
+}
+static int rows_move(bool unpack, const void* src, int64_t lds, const int32_t* row_map, int32_t rows, void* dst, int64_t ldd, int32_t H, void* stream) {
+    VLP_CHECK_ARG(src && dst && row_map && rows > 0 && H > 0 && H % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0 && lds >= H && ldd >= H, "vlp_rows_pack/unpack: bad args");
+    VLP_ENTER(src, "vlp_rows_pack/unpack");
+    const int64_t total = (int64_t)rows * (H / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    if (unpack) hipLaunchKernelGGL(rows_move_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)src, lds, row_map, rows, (f16*)dst, ldd, H);
+    else hipLaunchKernelGGL(rows_move_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)src, lds, row_map, rows, (f16*)dst, ldd, H);
+    VLP_CHECK_LAUNCH("vlp_rows_pack/unpack");
+    return VLP_OK;
+}
+extern "C" int vlp_rows_unpack(const void* src, int64_t lds, const int32_t* row_map, int32_t rows, void* dst, int64_t ldd, int32_t H, void* stream) {
+    return rows_move(true, src, lds, row_map, rows, dst, ldd, H, stream);
+}
+extern "C" int vlp_rows_pack(const void* src, int64_t lds, const int32_t* row_map, int32_t rows, void* dst, int64_t ldd, int32_t H, void* stream) {
+    return rows_move(false, src, lds, row_map, rows, dst, ldd, H, stream);
 }
 
 // dz = dy * dropmask * (y > 0), idx = row*ncols + col (the forward GEMM epilogue's index)

@@ -15,6 +15,7 @@ struct GemmNtParams {
     int mulmode;   // VLP_MUL_*
     float alpha;
     DropCtx drop;
+    const int32_t* row_map;   // packed (padding-free) runs: logical row of output row m for the dropout hash, or nullptr
     int tiles_n;
     int tiles_total; // wave-pipelined kernels: tiles of the launch (persistent variants stride them over the grid)
     int xcd_remap;   // 1: workgroups of one XCD (blockIdx % 8) take a contiguous range of tiles (X-panel reuse in that XCD's L2)
@@ -22,6 +23,9 @@ struct GemmNtParams {
     int dbg;         // investigation build (tools/build_variant_lib.sh): 1 = ring loop without MFMAs, 2 = without refill DMA, 4 = without the epilogue
 #endif
 };
+
+// dropout row of output row m: its logical index in a packed run (masks bit-identical to the dense run), m itself otherwise
+DEVFN uint64_t nt_drop_row(const GemmNtParams& p, int m) { return p.row_map ? (uint64_t)(uint32_t)p.row_map[m] : (uint64_t)m; }
 
 // phased kernels (gemm_nt_ph.hip): bn = 256 or 128 columns per workgroup tile (256 rows); p.xcd_remap honoured
 int vlp_gemm_nt_ph_launch(GemmNtParams& p, int bn, int mode, hipStream_t s);

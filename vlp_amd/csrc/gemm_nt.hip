@@ -317,7 +317,7 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BN
     for (int tm = 0; tm < 4; ++tm) {
         const int m = m0 + wm * 64 + 16 * tm + li;
         if (m >= p.M) continue;
-        const uint32_t rkey = p.drop.thresh ? drop_rowkey(p.drop, (uint64_t)m) : 0u;   // dropout element = (row m, col n)
+        const uint32_t rkey = p.drop.thresh ? drop_rowkey(p.drop, nt_drop_row(p, m)) : 0u;   // dropout element = (row m, col n)
         float v[16];
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
@@ -365,6 +365,7 @@ int vlp_gemm_nt_fill_params(const vlp_gemm_nt_args* a, GemmNtParams& p) {
     p.act = a->act; p.mulmode = a->mul_mode;
     p.alpha = a->alpha;
     p.drop = make_drop(a->dropout_p, a->seed, a->rng_stream);
+    p.row_map = a->row_map;
     p.tiles_n = 0;
     p.xcd_remap = 0;
 #ifdef VLP_NT_DEBUG

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(K32_T, 4) void gemm_nt_k32_kernel(GemmNtParams p) {
     for (int tm = 0; tm < 4; ++tm) {
         const int m = m0 + wm * 64 + 16 * tm + li;
         if (m >= p.M) continue;
-        const uint32_t rkey = p.drop.thresh ? drop_rowkey(p.drop, (uint64_t)m) : 0u;   // dropout element = (row m, col n)
+        const uint32_t rkey = p.drop.thresh ? drop_rowkey(p.drop, nt_drop_row(p, m)) : 0u;   // dropout element = (row m, col n)
         float v[16];
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ph_kernel(GemmNtParams p) {
     for (int tm = 0; tm < 2 * QM; ++tm) {
         const int m = m0 + (tm / QM) * 128 + wm * QM * 16 + 16 * (tm % QM) + li;
         if (m >= p.M) continue;
-        const uint32_t rkey = p.drop.thresh ? drop_rowkey(p.drop, (uint64_t)m) : 0u;
+        const uint32_t rkey = p.drop.thresh ? drop_rowkey(p.drop, nt_drop_row(p, m)) : 0u;
 #pragma unroll
         for (int hn = 0; hn < 2; ++hn) {
             float v[8];

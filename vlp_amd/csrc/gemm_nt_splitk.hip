@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void gemm_nt_splitk_reduce_kernel(SplitKParams
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-        const uint32_t rkey = p.drop.thresh ? drop_rowkey(p.drop, (uint64_t)m) : 0u;
+        const uint32_t rkey = p.drop.thresh ? drop_rowkey(p.drop, nt_drop_row(p, m)) : 0u;
         nt_epilogue8(p, m, nc, v, rkey);
     }
 }

@@ -74,7 +74,7 @@ DEVFN void wp_light_store8(const GemmNtParams& p, int m, int nc, bool ragged, fl
 #pragma unroll
         for (int j = 0; j < 8; ++j) vv[j] = ((float)mulv[j] > 0.f) ? vv[j] : 0.f;
     }
-    if (p.drop.thresh) drop_mult8(p.drop, drop_rowkey(p.drop, (uint64_t)m), (uint32_t)nc, vv);
+    if (p.drop.thresh) drop_mult8(p.drop, drop_rowkey(p.drop, nt_drop_row(p, m)), (uint32_t)nc, vv);
     if (p.residual) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) vv[j] += (float)resv[j];

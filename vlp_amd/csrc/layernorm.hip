@@ -14,7 +14,7 @@
 template <int NP>   // per-lane pieces of 4 halfs (piece k = columns 256k + 4*lane .. +3): H <= 256*NP; at H = 768 every lane holds 12 columns
 __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(
     const f16* __restrict__ x, int64_t ldx, const f16* __restrict__ gamma, const f16* __restrict__ beta,
-    f16* __restrict__ y, int64_t ldy, float* __restrict__ mean, float* __restrict__ rstd, int M, int H, float eps, DropCtx drop) {
+    f16* __restrict__ y, int64_t ldy, float* __restrict__ mean, float* __restrict__ rstd, int M, int H, float eps, DropCtx drop, const int32_t* __restrict__ row_map) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * LN_WAVES;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(
             if (rstd) rstd[row] = rs;
         }
         f16* yr = y + (int64_t)row * ldy;
-        const uint32_t rkey = drop.thresh ? drop_rowkey(drop, (uint64_t)row) : 0u;   // dropout element = (row, col)
+        const uint32_t rkey = drop.thresh ? drop_rowkey(drop, row_map ? (uint64_t)(uint32_t)row_map[row] : (uint64_t)row) : 0u;   // dropout element = (row, col)
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int c = 256 * k + 4 * lane;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(
 template <int NC>
 __global__ __launch_bounds__(LN_THREADS, NC <= 3 ? 6 : 4) void layernorm_fwd_hw_kernel(      // NC = 3: <= 80 VGPRs -> 6 144 resident waves >= the 5 344 of M = 10 688
     const f16* __restrict__ x, int64_t ldx, const f16* __restrict__ gamma, const f16* __restrict__ beta,
-    f16* __restrict__ y, int64_t ldy, float* __restrict__ mean, float* __restrict__ rstd, int M, int H, float eps, DropCtx drop) {
+    f16* __restrict__ y, int64_t ldy, float* __restrict__ mean, float* __restrict__ rstd, int M, int H, float eps, DropCtx drop, const int32_t* __restrict__ row_map) {
     const int lane = threadIdx.x & 63, hl = lane & 31;
     const int wave = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * LN_WAVES;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(LN_THREADS, NC <= 3 ? 6 : 4) void layernorm_fwd_hw_
         }
         if (!live) continue;
         f16* yr = y + (int64_t)row * ldy;
-        const uint32_t rkey = drop.thresh ? drop_rowkey(drop, (uint64_t)row) : 0u;   // dropout element = (row, col)
+        const uint32_t rkey = drop.thresh ? drop_rowkey(drop, row_map ? (uint64_t)(uint32_t)row_map[row] : (uint64_t)row) : 0u;   // dropout element = (row, col)
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
             const int c = 256 * k + 8 * hl;
@@ -149,7 +149,7 @@ extern "C" int vlp_layernorm_fwd(const vlp_layernorm_fwd_args* a, void* stream) 
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_LN_FWD(NP_)                                                                                                              \
     hipLaunchKernelGGL(layernorm_fwd_kernel<NP_>, dim3(blocks), dim3(LN_THREADS), 0, s, (const f16*)a->x, a->ldx, (const f16*)a->gamma, \
-                       (const f16*)a->beta, (f16*)a->y, a->ldy, a->mean, a->rstd, a->M, a->H, a->eps, d)
+                       (const f16*)a->beta, (f16*)a->y, a->ldy, a->mean, a->rstd, a->M, a->H, a->eps, d, a->row_map)
     // VLP_LN_HALFWAVE=0: the one-row-per-wave kernel everywhere (A/B runs).  Read once; the per-call decision is a local (the entry
     // points may be driven from several host threads)
     static const int use_hw = [] { const char* e = getenv("VLP_LN_HALFWAVE"); return e ? atoi(e) : 1; }();
@@ -158,7 +158,7 @@ extern "C" int vlp_layernorm_fwd(const vlp_layernorm_fwd_args* a, void* stream) 
         const int hblocks = ln_fwd_blocks((a->M + 1) / 2);
 #define LAUNCH_LN_HW(NC_)                                                                                                                  \
     hipLaunchKernelGGL(layernorm_fwd_hw_kernel<NC_>, dim3(hblocks), dim3(LN_THREADS), 0, s, (const f16*)a->x, a->ldx, (const f16*)a->gamma, \
-                       (const f16*)a->beta, (f16*)a->y, a->ldy, a->mean, a->rstd, a->M, a->H, a->eps, d)
+                       (const f16*)a->beta, (f16*)a->y, a->ldy, a->mean, a->rstd, a->M, a->H, a->eps, d, a->row_map)
         if (a->H == 768) LAUNCH_LN_HW(3);
         else if (a->H == 256) LAUNCH_LN_HW(1);
         else if (a->H == 512) LAUNCH_LN_HW(2);
@@ -196,7 +196,7 @@ template <int NP>
 __global__ __launch_bounds__(LNB_THREADS, NP <= 3 ? 4 : (NP == 4 ? 3 : 2)) void layernorm_bwd_kernel(
     const f16* __restrict__ dy, int64_t lddy, const f16* __restrict__ x, int64_t ldx, const f16* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, f16* __restrict__ dx, int64_t lddx,
-    f16* __restrict__ dxd, int64_t lddxd, float* __restrict__ part, int M, int H, DropCtx dyd, DropCtx outd) {
+    f16* __restrict__ dxd, int64_t lddxd, float* __restrict__ part, int M, int H, DropCtx dyd, DropCtx outd, const int32_t* __restrict__ row_map) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * LNB_WAVES + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * LNB_WAVES;
@@ -230,8 +230,9 @@ __global__ __launch_bounds__(LNB_THREADS, NP <= 3 ? 4 : (NP == 4 ? 3 : 2)) void 
     for (int row = wave; row < M; row += nwaves) {
         if (row + nwaves < M) fetch(row + nwaves, xn, dn, mu_n, rs_n);
         const float mu = mu_c, rs = rs_c;
-        const uint32_t rk_dy = dyd.thresh ? drop_rowkey(dyd, (uint64_t)row) : 0u;
-        const uint32_t rk_out = outd.thresh ? drop_rowkey(outd, (uint64_t)row) : 0u;
+        const uint64_t drow = ((dyd.thresh | outd.thresh) && row_map) ? (uint64_t)(uint32_t)row_map[row] : (uint64_t)row;     // packed rows: logical index
+        const uint32_t rk_dy = dyd.thresh ? drop_rowkey(dyd, drow) : 0u;
+        const uint32_t rk_out = outd.thresh ? drop_rowkey(outd, drow) : 0u;
         float xh[NP][4], d[NP][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -365,13 +366,13 @@ extern "C" int vlp_layernorm_bwd(const vlp_layernorm_bwd_args* a, void* stream) 
     });
     if (a->H <= 768)
         hipLaunchKernelGGL(layernorm_bwd_kernel<3>, dim3(blocks), dim3(LNB_THREADS), lnb_smem, s, (const f16*)a->dy, a->lddy, (const f16*)a->x, a->ldx,
-                           (const f16*)a->gamma, a->mean, a->rstd, (f16*)a->dx, a->lddx, (f16*)a->dx_drop, a->lddxd, part, a->M, a->H, dyd, outd);
+                           (const f16*)a->gamma, a->mean, a->rstd, (f16*)a->dx, a->lddx, (f16*)a->dx_drop, a->lddxd, part, a->M, a->H, dyd, outd, a->row_map);
     else if (a->H <= 1024)
         hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(blocks), dim3(LNB_THREADS), lnb_smem, s, (const f16*)a->dy, a->lddy, (const f16*)a->x, a->ldx,
-                           (const f16*)a->gamma, a->mean, a->rstd, (f16*)a->dx, a->lddx, (f16*)a->dx_drop, a->lddxd, part, a->M, a->H, dyd, outd);
+                           (const f16*)a->gamma, a->mean, a->rstd, (f16*)a->dx, a->lddx, (f16*)a->dx_drop, a->lddxd, part, a->M, a->H, dyd, outd, a->row_map);
     else
         hipLaunchKernelGGL(layernorm_bwd_kernel<8>, dim3(blocks), dim3(LNB_THREADS), lnb_smem, s, (const f16*)a->dy, a->lddy, (const f16*)a->x, a->ldx,
-                           (const f16*)a->gamma, a->mean, a->rstd, (f16*)a->dx, a->lddx, (f16*)a->dx_drop, a->lddxd, part, a->M, a->H, dyd, outd);
+                           (const f16*)a->gamma, a->mean, a->rstd, (f16*)a->dx, a->lddx, (f16*)a->dx_drop, a->lddxd, part, a->M, a->H, dyd, outd, a->row_map);
     VLP_CHECK_LAUNCH("vlp_layernorm_bwd");
     if (a->defer_reduce) return VLP_OK;
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * a->H, 64)), dim3(1024), 0, s, part, blocks, a->H, (f16*)a->dgamma,

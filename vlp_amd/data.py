@@ -234,7 +234,7 @@ class BatchPrefetcher(object):
         _, d, ev = slot
         torch.cuda.current_stream(self.device).wait_event(ev)
         B = self.B
-        spec = MaskSpec(d["spec"][0], d["spec"][1], d["spec"][2])
+        spec = MaskSpec(d["spec"][0], d["spec"][1], d["spec"][2], slot[0]["spec"][1].tolist())      # + host lengths (padding-free step)
         raw = RawRegions(d["bbox"], d["cls"])
         is_next = torch.full((B,), -1, dtype=torch.long, device=self.device)
         vis_masked_pos = d["vmp"] if self.n_vis_masked else torch.zeros(B, 0, dtype=torch.long, device=self.device)

@@ -42,7 +42,7 @@ def is_no_decay(name):
 
 class _State(object):
     """What one forward leaves behind for its backward."""
-    __slots__ = ("gen", "B", "L", "P", "seed", "p_drop", "ws", "batch", "task", "has_mlm", "task_labels", "pretext")
+    __slots__ = ("gen", "B", "L", "P", "seed", "p_drop", "ws", "batch", "task", "has_mlm", "task_labels", "pretext", "pk")
 
 
 class Engine(object):
@@ -64,6 +64,15 @@ class Engine(object):
     # Parity follows that behaviour; VLP_BLOCK_MASKED_REGIONS=1 follows the line's comment instead ("block the masked visual feature")
     # on the MaskSpec path (a dense attention_mask is always used as given).
     BLOCK_MASKED_REGION_KEYS = os.environ.get("VLP_BLOCK_MASKED_REGIONS", "0") == "1"
+    # Padding-free (packed) step, opt-in (VLP_VARLEN=1 or engine.varlen = True; training / grad-enabled forwards only).  A sample's
+    # positions past its last token are INERT in the reference's computation: no kept query attends them (their mask columns are 0 for
+    # every row: seq2seq_loader.py:295-304), no loss reads them (masked_pos, h[:, 0], h[:, Nv+1] lie before them), so their hidden states
+    # feed nothing and every gradient contribution through them is exactly zero (dO = 0 for pad queries, P = 0 for pad keys:
+    # modeling.py:289-298).  The packed step keeps the first n_b positions of sample b (n_b derived from the mask itself, _packing())
+    # as rows [row_off[b], row_off[b+1]) of every [M, *] activation and runs every row-wise kernel on M' = sum n_b rows; attention takes
+    # row_off; dropout hashes keep the logical (b*L + l, col) element, so masks -- and with them losses, logits and gradients --
+    # equal the dense run's up to the fp32 summation order of the weight-gradient / LayerNorm-parameter sums.
+    VARLEN = os.environ.get("VLP_VARLEN", "0") == "1"
     GROUPED_WGRAD = os.environ.get("VLP_GROUPED_WGRAD", "1") == "1"     # one vlp_gemm_tn_grouped launch per layer instead of 4 split-M wgrads + 4 reduces
     TN_SPLITS = None         # None -> vlp_amd.tuning (variant flags, split-M factor) per (M, N, K)
     # split-M factor: the wgrad outputs are small (36..144 tiles of 128x128) and the contraction long (M = 10 688), so the
@@ -98,6 +107,10 @@ class Engine(object):
         self._side = None                 # second HIP stream for the layer wgrads (created on first use)
         self._side_busy = False           # True while backward may have work queued on it
         self._prof_ctr = 0
+        self.varlen = self.VARLEN         # padding-free (packed) training step, see VARLEN
+        self._pk_cache = {}               # kept-length tuple -> (row_off, row_map device tensors, M'): batches repeat in bench / epochs
+        self._pk_lens = {}                # id(mask tensor) -> (weakref, version, ..., lens): lengths derived from a dense mask, once per tensor
+        self.last_packed_rows = None      # M' of the latest packed forward (None: dense) -- bench.py / tests read it
 
     # ------------------------------------------------------------------------------------------
     # parameter packing
@@ -514,6 +527,56 @@ class Engine(object):
                            dsel0=torch.empty(B, H, device=dev, dtype=torch.float16), pT=torch.empty(H, H, device=dev, dtype=torch.float16))
         return ws[key]
 
+    def _kept_lengths(self, attention_mask, masked_pos, B, L, Nv):
+        """Per-sample number of leading positions the packed step keeps (host ints): 1 + the last key column ANY query attends, and at
+        least what the heads read (masked_pos, position Nv+1).  Every dropped position is therefore attended by no query at all.
+        MaskSpec carries the lengths on the host (lens_host = second_end, the loader knows them); a dense int64 mask is reduced on the
+        device and read back ONCE per tensor object (the result is remembered while that tensor is alive and unmodified -- a device-
+        resident batch pool, bench.py / --synthetic, pays the read-back in its first pass only)."""
+        if isinstance(attention_mask, MaskSpec):
+            if attention_mask.lens_host is None:
+                return None
+            lens = [max(int(n), Nv + 2) for n in attention_mask.lens_host]
+            return lens if len(lens) == B and max(lens) <= L else None
+        if attention_mask is None or attention_mask.dim() != 3:
+            return None
+        key = id(attention_mask)
+        mp_key = (id(masked_pos), masked_pos._version) if masked_pos is not None else None
+        hit = self._pk_lens.get(key)
+        if hit is not None and hit[0]() is attention_mask and hit[1] == attention_mask._version and hit[2] == mp_key:
+            return hit[3]
+        cols = (attention_mask != 0).any(dim=1)                                            # [B, L]: key column attended by some query
+        idx = torch.arange(1, L + 1, device=cols.device, dtype=torch.int32)
+        n = (cols.to(torch.int32) * idx).amax(dim=1)
+        n = torch.clamp(n, min=Nv + 2)
+        if masked_pos is not None and masked_pos.numel() > 0:
+            n = torch.maximum(n, (masked_pos.to(torch.int32).amax(dim=1) + 1).clamp(max=L))
+        lens = [int(v) for v in n.tolist()]                                              # the one host read-back
+        if len(self._pk_lens) > 64:
+            self._pk_lens = {k: v for k, v in self._pk_lens.items() if v[0]() is not None}
+            if len(self._pk_lens) > 64:
+                self._pk_lens.clear()
+        self._pk_lens[key] = (weakref.ref(attention_mask), attention_mask._version, mp_key, lens)
+        return lens
+
+    def _packing(self, lens, B, L):
+        """(row_off int32 [B+1], row_map int32 [M'], M') on the device for the kept lengths `lens`."""
+        key = (L,) + tuple(lens)
+        ent = self._pk_cache.get(key)
+        if ent is None:
+            off = [0]
+            for n in lens:
+                off.append(off[-1] + n)
+            host = torch.tensor(off, dtype=torch.int32).pin_memory()
+            row_off = torch.empty(B + 1, dtype=torch.int32, device=self.device)
+            row_off.copy_(host, non_blocking=True)
+            row_map = torch.empty(off[-1], dtype=torch.int32, device=self.device)
+            K.rowmap_build(row_off, B, L, row_map)
+            if len(self._pk_cache) >= 256:
+                self._pk_cache.clear()
+            ent = self._pk_cache[key] = (row_off, row_map, off[-1], host)
+        return ent[0], ent[1], ent[2]
+
     def forward(self, vis_feats, vis_pe, input_ids, token_type_ids, attention_mask, masked_pos, train, want_mlm, want_vqa,
                 vis_masked_pos=None):
         """Runs embeddings + encoder (+ heads' forward up to the logits).  Returns the _State.  vis_masked_pos ([B, Pm] int64, values
@@ -544,6 +607,14 @@ class Engine(object):
             self.step_seed += 1
         seed = st.seed = self.base_seed + self.step_seed
         M, Mv = B * L, B * Nv
+        # ---- padding-free layout (opt-in): row_off / row_map / M' from the mask's own kept lengths --------------------------------
+        ro = rm = None
+        if self.varlen and (train or torch.is_grad_enabled()) and L <= 192 and os.environ.get("VLP_ATTN_BWD") is None:
+            lens = self._kept_lengths(attention_mask, masked_pos if P > 0 else None, B, L, Nv)
+            if lens is not None and sum(lens) < M:
+                ro, rm, M = self._packing(lens, B, L)
+        st.pk = (ro, rm, M) if ro is not None else None
+        self.last_packed_rows = M if ro is not None else None
 
         # ---- W^T shadows of this step's dgrad GEMMs: the weights are final once the optimizer has stepped, so the batched transpose
         # (78 us) runs on the side stream underneath the forward instead of at the head of backward
@@ -619,9 +690,9 @@ class Engine(object):
         E = "bert.embeddings."
         K.embed_fwd(st.batch[1], st.batch[2], self.P(E + "word_embeddings.weight"), self.P(E + "position_embeddings.weight"),
                     self.P(E + "token_type_embeddings.weight"), ws["vis_h"], ws["vispe_h"], ws["emb_pre"], B, L, Nv, H,
-                    region_mask=pt["rmask"] if pt is not None else None)
+                    region_mask=pt["rmask"] if pt is not None else None, row_map=rm, rows=M if rm is not None else 0)
         K.layernorm_fwd(ws["emb_pre"], self.P(E + "LayerNorm.weight"), self.P(E + "LayerNorm.bias"), ws["x0"], M, H, ws["stat0"][0], ws["stat0"][1],
-                        dropout_p=p, seed=seed, rng_stream=1000)
+                        dropout_p=p, seed=seed, rng_stream=1000, row_map=rm)
         # ---- encoder (modeling.py:268-372) -----------------------------------------------------------
         x = ws["x0"]
         scale = 1.0 / math.sqrt(H // A)
@@ -630,9 +701,9 @@ class Engine(object):
             a = ws["layers"][i]
             self.wait_params(NL - i)                            # bucket of layer i
             self._nt(x, self.P(Ln + "attention.self.query.weight"), a["qkv"], M, 3 * H, H, bias=self.P(Ln + "attention.self.query.bias"))
-            K.attn_fwd(a["qkv"], ws["maskb"], a["ctx"], a["lse"], B, L, A, scale, dropout_p=pa, seed=seed, rng_stream=16 * i + 1)
+            K.attn_fwd(a["qkv"], ws["maskb"], a["ctx"], a["lse"], B, L, A, scale, dropout_p=pa, seed=seed, rng_stream=16 * i + 1, row_off=ro)
             self._nt(a["ctx"], self.P(Ln + "attention.output.dense.weight"), a["pre1"], M, H, H, bias=self.P(Ln + "attention.output.dense.bias"),
-                     residual=x, dropout_p=p, seed=seed, rng_stream=16 * i + 2)
+                     residual=x, dropout_p=p, seed=seed, rng_stream=16 * i + 2, row_map=rm)
             K.layernorm_fwd(a["pre1"], self.P(Ln + "attention.output.LayerNorm.weight"), self.P(Ln + "attention.output.LayerNorm.bias"),
                             a["x1"], M, H, a["st1"][0], a["st1"][1])
             # a["z"] receives gelu'(z), not z: the only consumer is the FFN-down dgrad epilogue, which then multiplies by a stored
@@ -640,7 +711,7 @@ class Engine(object):
             self._nt(a["x1"], self.P(Ln + "intermediate.dense.weight"), a["g"], M, I, H, bias=self.P(Ln + "intermediate.dense.bias"),
                      preact=a["z"], act=K.ACT_GELU_SAVE_GRAD)
             self._nt(a["g"], self.P(Ln + "output.dense.weight"), a["pre2"], M, H, I, bias=self.P(Ln + "output.dense.bias"),
-                     residual=a["x1"], dropout_p=p, seed=seed, rng_stream=16 * i + 3)
+                     residual=a["x1"], dropout_p=p, seed=seed, rng_stream=16 * i + 3, row_map=rm)
             K.layernorm_fwd(a["pre2"], self.P(Ln + "output.LayerNorm.weight"), self.P(Ln + "output.LayerNorm.bias"), a["x2"], M, H,
                             a["st2"][0], a["st2"][1])
             x = a["x2"]
@@ -650,7 +721,7 @@ class Engine(object):
         if P > 0:
             C = "cls.predictions."
             R = B * P
-            K.gather_rows(x, H, masked_pos.contiguous(), ws["sel"], H, B, P, L, H)
+            K.gather_rows(x, H, masked_pos.contiguous(), ws["sel"], H, B, P, L, H, row_off=ro)
             self._nt(ws["sel"], self.P(C + "transform.dense.weight"), ws["tg"], R, H, H, bias=self.P(C + "transform.dense.bias"),
                      preact=ws["tz"], act=K.ACT_GELU)
             K.layernorm_fwd(ws["tg"], self.P(C + "transform.LayerNorm.weight"), self.P(C + "transform.LayerNorm.bias"), ws["tln"], R, H,
@@ -658,12 +729,12 @@ class Engine(object):
             self._nt(ws["tln"], self.P("bert.embeddings.word_embeddings.weight"), ws["logits"], R, V, H, bias=self.P(C + "bias"), ldy=ws["Vp"])
         if want_vqa:
             NA = model.num_answers
-            K.vqa_mul_fwd(x, ws["vq_e"], B, L, Nv, H)
+            K.vqa_mul_fwd(x, ws["vq_e"], B, L, Nv, H, row_off=ro)
             self._nt(ws["vq_e"], self.P("ans_classifier.0.weight"), ws["vq_a1"], B, 2 * H, H, bias=self.P("ans_classifier.0.bias"), act=K.ACT_RELU)
             self._nt(ws["vq_a1"], self.P("ans_classifier.2.weight"), ws["vq_logits"], B, NA, 2 * H, bias=self.P("ans_classifier.2.bias"), ldy=ws["NAp"])
         if pt is not None:
             # BertPooler (modeling.py:411-417) -- only this branch reads it -- and the pretext loss (:1113-1131)
-            K.gather_rows(x, H, pt["pos0"], pt["sel0"], H, B, 1, L, H)
+            K.gather_rows(x, H, pt["pos0"], pt["sel0"], H, B, 1, L, H, row_off=ro)
             self._nt(pt["sel0"], self.P("bert.pooler.dense.weight"), pt["pooled"], B, H, H, bias=self.P("bert.pooler.dense.bias"), act=K.ACT_TANH)
             K.pretext_fwd(ws["vis_h"], ws["vispe_h"], pt["pooled"], st_vmp, pt["probs"], pt["sample"], pt["loss"], B, Nv, st_vmp.shape[1], H)
         return st
@@ -700,8 +771,15 @@ class Engine(object):
         return st.ws["vq_logits"][:, :self._model().num_answers]
 
     def sequence_output(self, st):
+        """[B, L, H] hidden states of the last layer.  After a packed forward the dropped (padding) positions hold zeros -- the dense
+        run computes values there that nothing consumes."""
         cfg = self._model().config
-        return st.ws["layers"][cfg.num_hidden_layers - 1]["x2"].view(st.B, st.L, cfg.hidden_size)
+        x = st.ws["layers"][cfg.num_hidden_layers - 1]["x2"]
+        if st.pk is not None:
+            dense = torch.zeros(st.B * st.L, cfg.hidden_size, device=x.device, dtype=x.dtype)
+            K.rows_unpack(x, st.pk[1], st.pk[2], dense, cfg.hidden_size)
+            x = dense
+        return x.view(st.B, st.L, cfg.hidden_size)
 
     # ------------------------------------------------------------------------------------------
     # incremental greedy decoding with a K/V cache (modeling.py:1189-1253, :856-875, :386-394)
@@ -1051,6 +1129,9 @@ class Engine(object):
         B, L, P, ws, seed = st.B, st.L, st.P, st.ws, st.seed
         p, pa = st.p_drop
         M, Mv = B * L, B * Nv
+        ro = rm = None
+        if st.pk is not None:
+            ro, rm, M = st.pk                # packed rows: every [M, *] activation of this step has M' = sum of the kept lengths rows
         beta = 1 if self.grads_dirty else 0
         if beta and self.shard_plan is not None:
             raise RuntimeError("vlp_amd: VLP_DDP_MODE=sharded keeps only this rank's chunk of the reduced gradient, so gradients cannot be "
@@ -1080,7 +1161,7 @@ class Engine(object):
             self._nt(ws["vq_dlogits"], sh["a2T"], ws["vq_dz1"], B, 2 * H, NAp, mul_src=ws["vq_a1"], mul_mode=K.MUL_RELU_MASK)
             self._tn(ws["vq_dz1"], ws["vq_e"], self.G("ans_classifier.0.weight"), B, 2 * H, H, ws, beta, bias=self.G("ans_classifier.0.bias"))
             self._nt(ws["vq_dz1"], sh["a0T"], ws["vq_de"], B, H, 2 * H)
-            K.vqa_mul_bwd(x_last, ws["vq_de"], dx, B, L, Nv, H)
+            K.vqa_mul_bwd(x_last, ws["vq_de"], dx, B, L, Nv, H, row_off=ro)
             if beta == 0:
                 self.G(E + "word_embeddings.weight").zero_()     # no tied-decoder wgrad in this task: scatter needs zeros
         elif not st.has_mlm:
@@ -1105,7 +1186,7 @@ class Engine(object):
             K.gelu_bwd(ws["dtg"], ws["tz"], ws["dtz"], R * H)
             self._tn(ws["dtz"], ws["sel"], self.G(C + "transform.dense.weight"), R, H, H, ws, beta, bias=self.G(C + "transform.dense.bias"))
             self._nt(ws["dtz"], sh["tT"], ws["dsel"], R, H, H)
-            K.scatter_add_rows(ws["dsel"], H, masked_pos.contiguous(), dx, H, B, P, L, H)
+            K.scatter_add_rows(ws["dsel"], H, masked_pos.contiguous(), dx, H, B, P, L, H, row_off=ro)
         pt = st.pretext
         if pt is not None:
             # vis_pretext_loss backward (modeling.py:1113-1131): masked rows of d_vis_h / d_vispe_h (embed_bwd below leaves them alone),
@@ -1118,7 +1199,7 @@ class Engine(object):
             self._tn(ptw["dpool"], ptw["sel0"], self.G("bert.pooler.dense.weight"), B, H, H, ws, beta, bias=self.G("bert.pooler.dense.bias"))
             K.transpose(self.P("bert.pooler.dense.weight"), H, ptw["pT"], H, H, H, H)
             self._nt(ptw["dpool"], ptw["pT"], ptw["dsel0"], B, H, H)
-            K.scatter_add_rows(ptw["dsel0"], H, ptw["pos0"], dx, H, B, 1, L, H)
+            K.scatter_add_rows(ptw["dsel0"], H, ptw["pos0"], dx, H, B, 1, L, H, row_off=ro)
         elif beta == 0 and getattr(self, "_pooler_dirty", False):
             self.G("bert.pooler.dense.weight").zero_()           # a previous pretext step left gradients there; unused now
             self.G("bert.pooler.dense.bias").zero_()
@@ -1171,7 +1252,7 @@ class Engine(object):
             dpre = ds["dpre2"]
             K.layernorm_bwd(dx, a["pre2"], self.P(Ln + "output.LayerNorm.weight"), a["st2"][0], a["st2"][1], dpre,
                             self.G(Ln + "output.LayerNorm.weight"), self.G(Ln + "output.LayerNorm.bias"), M, H, ln_slot(2 * i + 1), beta=beta,
-                            dx_drop=ds["dpre2_d"] if p > 0 else None, out_drop=(p, seed, 16 * i + 3), defer_reduce=defer)
+                            dx_drop=ds["dpre2_d"] if p > 0 else None, out_drop=(p, seed, 16 * i + 3), defer_reduce=defer, row_map=rm)
             dy2 = ds["dpre2_d"] if p > 0 else dpre
             if not grouped:
                 on_side(lambda: self._tn(dy2, a["g"], self.G(Ln + "output.dense.weight"), M, H, I, ws, beta, bias=self.G(Ln + "output.dense.bias")))
@@ -1185,7 +1266,7 @@ class Engine(object):
             dpre = ds["dpre1"]
             K.layernorm_bwd(dx, a["pre1"], self.P(Ln + "attention.output.LayerNorm.weight"), a["st1"][0], a["st1"][1], dpre,
                             self.G(Ln + "attention.output.LayerNorm.weight"), self.G(Ln + "attention.output.LayerNorm.bias"), M, H, ln_slot(2 * i),
-                            beta=beta, dx_drop=ds["dpre1_d"] if p > 0 else None, out_drop=(p, seed, 16 * i + 2), defer_reduce=defer)
+                            beta=beta, dx_drop=ds["dpre1_d"] if p > 0 else None, out_drop=(p, seed, 16 * i + 2), defer_reduce=defer, row_map=rm)
             dy1 = ds["dpre1_d"] if p > 0 else dpre
             if not grouped:
                 on_side(lambda: self._tn(dy1, a["ctx"], self.G(Ln + "attention.output.dense.weight"), M, H, H, ws, beta,
@@ -1193,7 +1274,8 @@ class Engine(object):
             self._nt(dy1, s["oT"], dctx, M, H, H)
             # BertSelfAttention (modeling.py:268-303)
             dqkv = ds["dqkv"]
-            K.attn_bwd(a["qkv"], ws["maskb"], ws["maskt"], a["ctx"], dctx, a["lse"], dqkv, ws["delta"], B, L, A, scale, dropout_p=pa, seed=seed, rng_stream=16 * i + 1)
+            K.attn_bwd(a["qkv"], ws["maskb"], ws["maskt"], a["ctx"], dctx, a["lse"], dqkv, ws["delta"], B, L, A, scale, dropout_p=pa, seed=seed,
+                       rng_stream=16 * i + 1, row_off=ro)
 
             def last_wgrad():
                 if grouped:
@@ -1223,9 +1305,16 @@ class Engine(object):
         # ---- embeddings -------------------------------------------------------------------------------------
         K.layernorm_bwd(dx, ws["emb_pre"], self.P(E + "LayerNorm.weight"), ws["stat0"][0], ws["stat0"][1], dpre,
                         self.G(E + "LayerNorm.weight"), self.G(E + "LayerNorm.bias"), M, H, ln_slot(2 * NL), beta=beta, dy_drop=(p, seed, 1000),
-                        defer_reduce=defer)
+                        defer_reduce=defer, row_map=rm)
         if defer:      # dgamma / dbeta of the 2 * layers + 1 LayerNorms above: one launch (slot order = table order)
             K.layernorm_bwd_reduce_batched(ws["ln_slots"], self._ln_table(), 2 * NL + 1, M, H, beta=beta)
+        if rm is not None:
+            # the embedding backward sums over (batch, position) in the dense [B, L] geometry (position table: a column of the batch;
+            # word table: id chains in row order): hand it the dense gradient -- exact zeros on the dropped positions, as in the dense run
+            dense = ws["dx_alt"]
+            dense.zero_()
+            K.rows_unpack(dpre, rm, M, dense, H)
+            dpre = dense
         K.embed_bwd(dpre, input_ids, token_type_ids, ws["vis_h"], ws["vispe_h"], self.G(E + "word_embeddings.weight"),
                     self.G(E + "position_embeddings.weight"), self.G(E + "token_type_embeddings.weight"), ws["d_vis_h"], ws["d_vispe_h"],
                     ws["acc32"], B, L, Nv, H, V, cfg.type_vocab_size, drop_p=p, seed=seed, vis_stream=1001, vispe_stream=1002,

@@ -41,9 +41,15 @@ class RawRegions(collections.namedtuple("RawRegions", ["bbox", "cls_prob"])):
             raise RuntimeError("RawRegions must live on the GPU (there is no CPU path)")
 
 
-class MaskSpec(collections.namedtuple("MaskSpec", ["second_st", "second_end", "is_s2s"])):
-    """Per-sample description of the self-attention mask of seq2seq_loader.py:292-301; all int32 [B].
-    second_st = len(tokens_a) + 2, second_end = len(tokens_a) + len(tokens_b) + 3, is_s2s = 1 (seq2seq) / 0 (bidirectional)."""
+_MaskSpecBase = collections.namedtuple("MaskSpec", ["second_st", "second_end", "is_s2s", "lens_host"])
+_MaskSpecBase.__new__.__defaults__ = (None,)
+
+
+class MaskSpec(_MaskSpecBase):
+    """Per-sample description of the self-attention mask of seq2seq_loader.py:292-301; second_st / second_end / is_s2s: int32 [B].
+    second_st = len(tokens_a) + 2, second_end = len(tokens_a) + len(tokens_b) + 3, is_s2s = 1 (seq2seq) / 0 (bidirectional).
+    lens_host (optional): second_end as a HOST list of ints -- the number of leading positions of each sample that anything attends.
+    The loader knows it for free; with it the engine's padding-free step (VLP_VARLEN=1) needs no device read-back."""
     __slots__ = ()
 
     @staticmethod
@@ -53,20 +59,21 @@ class MaskSpec(collections.namedtuple("MaskSpec", ["second_st", "second_end", "i
         B = len_b.numel()
         len_a = torch.as_tensor(len_a, dtype=torch.int32).reshape(-1).expand(B)
         s2s = torch.as_tensor(s2s).to(torch.int32).reshape(-1).expand(B)
-        spec = MaskSpec((len_a + 2).contiguous(), (len_a + len_b + 3).contiguous(), s2s.contiguous())
+        end = (len_a + len_b + 3).contiguous()
+        spec = MaskSpec((len_a + 2).contiguous(), end, s2s.contiguous(), [int(v) for v in end.tolist()])
         return spec if device is None else spec.to(device)
 
     def to(self, device, non_blocking=False):
-        return MaskSpec(*(t.to(device, non_blocking=non_blocking) for t in self))
+        return MaskSpec(*(t.to(device, non_blocking=non_blocking) for t in self[:3]), self.lens_host)
 
     def check(self, B, L):
-        for t in self:
+        for t in self[:3]:
             if t.dtype != torch.int32 or t.numel() != B or not t.is_cuda:
                 raise RuntimeError("MaskSpec fields must be int32 [%d] tensors on the GPU" % B)
 
     def dense(self, L):
         """The int64 [B, L, L] mask this spec stands for (host/debug helper; the engine never builds it)."""
-        st, en, s2s = (t.to(torch.long).view(-1, 1, 1) for t in self)
+        st, en, s2s = (t.to(torch.long).view(-1, 1, 1) for t in self[:3])
         q = torch.arange(L, device=self.second_st.device).view(1, L, 1)
         k = torch.arange(L, device=self.second_st.device).view(1, 1, L)
         tri = (k < st) | ((q >= st) & (q < en) & (k >= st) & (k <= q))

@@ -71,6 +71,11 @@ def nt_heuristic(M, N, K):
         return 1                      # few workgroups: 128x128 LDS-DMA double buffer
     if N <= 1024:
         return 77                     # 256x128 tiles, wave-pipelined 3-slot ring (gemm_nt_wp.hip): narrow outputs (252 workgroups at M = 10 688, N = 768)
+    # Packed (padding-free) steps run every GEMM at M' = sum of the kept lengths, a different value each step (7 000 .. 10 688 at
+    # B = 64): no table row can name it, so the rules below carry what tools/varlen_lab.py measured over that range
+    # (profiles/r05_varlen_m_sweep.txt, cold operands).
+    if M >= 6144 and 1024 < N <= 2560 and N % 128 == 0 and K > 512:
+        return 264                    # QKV forward: persistent k-stream kernel (52.5 us at M = 10 688 down to 44.4 at 7 936; rings 57.7 -> 46.3)
     return 29                         # 256x256 tiles, 2-stage ring
 
 
@@ -109,10 +114,24 @@ def _nt_overrides():
     return out
 
 
+def _nt_rules():
+    """VLP_NT_RULES="N,K,Mlo,Mhi=variant;..." -- A/B runs of a variant over a RANGE of row counts (packed steps change M every step)."""
+    out = []
+    for item in os.environ.get("VLP_NT_RULES", "").split(";"):
+        if "=" in item:
+            k, v = item.split("=")
+            n, kk, lo, hi = (int(x) for x in k.split(","))
+            out.append((n, kk, lo, hi, int(v)))
+    return out
+
+
 def nt_variant(M, N, K):
     env = os.environ.get("VLP_NT_VARIANT")
     if env:
         return int(env)
+    for n, kk, lo, hi, v in _nt_rules():
+        if n == N and kk == K and lo <= M <= hi:
+            return v
     ov = _nt_overrides().get((M, N, K))
     if ov is not None:
         return ov
