@@ -42,6 +42,13 @@ enum { VLP_MUL_NONE = 0, VLP_MUL_GELU_GRAD = 1, VLP_MUL_RELU_MASK = 2, VLP_MUL_P
 
 int vlp_version(void);
 const char* vlp_last_error_string(void);
+/* 1 when the library was compiled with -DVLP_LAB_BUILD (tools/build_variant_lib.sh): the investigation variants of vlp_gemm_nt (phased
+ * kernels, k32 ring, further wave-pipelined configurations), the two-kernel / exchange-tile attention backward and the stream-K grouped
+ * wgrad are then present; the product library (0) launches its selected kernels and the fallback rings only. */
+int vlp_lab_build(void);
+/* Test hook: owner lookups of device pointers by the calling thread and how many of them asked the driver (the entry guard caches the
+ * owner per allocation). */
+void vlp_debug_device_lookup_stats(unsigned long long* lookups, unsigned long long* driver_queries);
 
 /* ------------------------------------------------------------------------------------------------
  * Y[M,N] = epilogue( alpha * X[M,K] . W[N,K]^T )                      (fp16 in/out, fp32 accumulate)
@@ -66,25 +73,22 @@ typedef struct {
     int32_t mul_mode;                    /* VLP_MUL_*: GELU_GRAD multiplies by gelu'(mul_src), RELU_MASK by (mul_src > 0), PLAIN by mul_src */
     float alpha;
     float dropout_p; uint64_t seed; uint32_t rng_stream;
-    int32_t variant;                     /* 0 = register-staged 128x128 tiles, 1 = LDS-DMA (global_load_lds) double-buffered,
-                                            2 = LDS-DMA single buffer (4 workgroups/CU), 3 = LDS-DMA 256x128 tile, 8 waves,
-                                            4 = 256x128 single buffer, 5 = 256x256 tile (16 waves, double-buffered);
-                                            6 / 7 = phased 256x256 / 256x128 kernels (gemm_nt_ph.hip: half-tile LDS-DMA pipeline with
-                                            counted vmcnt, 128x64 / 64x64 wave tiles, two staggered wave groups; need K >= 128;
-                                            +16 = one barrier per phase, compiler-scheduled, +48 = no stagger);
-                                            17 / 19 = variants 1 / 3 with a 4- / 3-stage LDS-DMA ring and counted vmcnt (17: latency hiding for skinny M);
-                                            +8 = XCD-aware tile order;
-                                            21 = variant 5 (256x256) as a 2-stage ring: one raw s_barrier per k tile, DMA issued right behind it, counted vmcnt.
-                                            53 = variant 5 with k tiles of 32 in a 4-stage ring (three stages in flight; measured slower than 21, kept for A/B runs).
-                                            64 + cfg (+ 8 = XCD-aware tile order; cfg 8.. = 192 + cfg - 8): wave-pipelined family (gemm_nt_wp.hip: 32x32x16 MFMA,
-                                            128x128 / 128x64 / 64x64 wave tiles, fragments read one or two k16 steps ahead of their MFMAs, LDS-transposed epilogue
-                                            with whole-line stores; cfg table in that file).  They carry the bias / ReLU / multiplier / dropout / residual and
-                                            save-grad GeLU epilogues; a call that needs erf / tanh in the epilogue runs on the rings (27 / 29) instead.
-                                            256 (+ 8 = XCD-aware run order): persistent k-stream kernel (gemm_nt_ps.hip): one workgroup per CU walks a contiguous
-                                            run of 256x128 tiles through one never-draining 3-stage ring and stores a finished tile in slices behind the next
-                                            tile's k tiles; bias / save-grad GeLU / plain-multiplier epilogues on N % 128 == 0, N <= 8192, K > 512 -- anything
-                                            else runs on the rings (27 / 29) instead (`VLP_NT_PS_GRID` caps the workgroups of a launch: investigation).
-                                            Every variant computes the same result (bit-identical on gfx950: profiles/r04_nt_variant_identity.json). */
+    int32_t variant;                     /* tile shape / staging of the launch; every variant computes the same bits (ascending-k fp32 chains:
+                                            profiles/r04_nt_variant_identity.json).  Product library:
+                                              value       tile      staging                                   used for
+                                              0           128x128   register-staged, 2 stages                 default / tiny problems
+                                              1, 2        128x128   LDS-DMA double buffer / single buffer     M <= 1024 (decoder, heads)
+                                              3, 4        256x128   LDS-DMA double / single buffer            A/B
+                                              5           256x256   LDS-DMA double buffer (16 waves)          A/B
+                                              17, 19      128x128 / 256x128  4- / 3-stage LDS-DMA ring        skinny M / N <= 1024 fallback
+                                              21          256x256   2-stage ring, one raw barrier per k tile  wide outputs (N > 1024)
+                                              64+1, 64+5  256x256 / 256x128  wave-pipelined (gemm_nt_wp.hip)  N <= 1024: 64 + 5
+                                              256         256x128   persistent k stream (gemm_nt_ps.hip)      QKV forward
+                                            + 8 on any value = XCD-aware tile (run) order: the table uses 27 = 19 + 8, 29 = 21 + 8, 77, 264.
+                                            A wave-pipelined / persistent variant whose epilogue or shape is not carried (erf / tanh epilogues;
+                                            N % 128, K <= 512, 32-bit offsets) runs on the rings 27 / 29 instead: vlp_gemm_nt_resolved_variant().
+                                            Investigation variants (6 / 7 phased, 53 k32 ring, other wave-pipelined configurations) exist in
+                                            -DVLP_LAB_BUILD libraries only (vlp_lab_build()); the product library maps them to 27 / 29. */
     const int32_t* row_map;              /* ABI 4: [M] or NULL.  Padding-free (packed) runs: the dropout element of output (m, n) is
                                             (row_map[m], n) -- the row's LOGICAL index b*L + l -- so a packed run draws the masks of the
                                             dense run bit for bit.  NULL: row m itself. */
@@ -203,7 +207,7 @@ typedef struct {
     int32_t B, L, heads;
     float scale;
     float dropout_p; uint64_t seed; uint32_t rng_stream;
-    const int32_t* row_off;              /* ABI 4: as in vlp_attn_fwd_args (rows of qkv / ctx / dctx / dqkv); delta, lse, masks stay logical */
+    const int32_t* row_off;              /* ABI 4: packed rows of qkv / ctx / dctx / dqkv, see vlp_attn_fwd_args; delta, lse, masks stay logical */
 } vlp_attn_bwd_args;
 int vlp_attn_bwd(const vlp_attn_bwd_args* a, void* stream);
 
@@ -225,7 +229,7 @@ typedef struct {
     float* mean; float* rstd;            /* [M] out (may be NULL for inference) */
     int32_t M, H; float eps;
     float dropout_p; uint64_t seed; uint32_t rng_stream;
-    const int32_t* row_map;              /* ABI 4: [M] or NULL: dropout element of (m, c) is (row_map[m], c) (packed rows, see vlp_gemm_nt_args) */
+    const int32_t* row_map;              /* ABI 4: [M] or NULL: dropout element of (m, c) is (row_map[m], c): packed rows, see vlp_gemm_nt_args */
 } vlp_layernorm_fwd_args;
 int vlp_layernorm_fwd(const vlp_layernorm_fwd_args* a, void* stream);
 
@@ -491,6 +495,13 @@ int vlp_sumsq(const void* g_f16, int64_t n, float* out2, float* partial, void* s
 /* ABI 3: the same over another range, ADDED to out2 (sum += , flag = max): the sharded optimizer step (vlp_amd/distributed.py ShardPlan)
  * sums over the chunks a rank owns; launches of one stream run in order, so the total is reproducible. */
 int vlp_sumsq_acc(const void* g_f16, int64_t n, float* out2, float* partial, void* stream);
+
+/* ABI 4: the same norm accumulated slice by slice while backward runs.  vlp_sumsq_partial writes the block partials of one gradient
+ * slice into its slot (vlp_sumsq_partial_floats() floats: sums, then flags); vlp_sumsq_combine adds `slots` consecutive slots up in a
+ * fixed order -> out2 = {sum(g^2), overflow flag} over all of them.  Bitwise reproducible; replaces one vlp_sumsq over the whole buffer. */
+int64_t vlp_sumsq_partial_floats(void);
+int vlp_sumsq_partial(const void* g_f16, int64_t n, float* partial, void* stream);
+int vlp_sumsq_combine(const float* partials, int32_t slots, float* out2, void* stream);
 
 /* apex fused_adam_cuda.adam as called by FusedAdam.step (run_img2txt_dist.py:411-420):
  *   g = g16 / (*combined_scale); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;

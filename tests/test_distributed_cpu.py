@@ -46,6 +46,26 @@ def _worker(rank, world, init_file, q):
                 red2.bucket_ready(i)
             red2.finish()
             assert torch.allclose(buf.float(), acc.float() + ref / world, atol=10 * tol, rtol=10 * tol)
+            # communication profile (bench.py --gpus N fills config.comm from it): the fields exist, one entry per collective in issue
+            # order, and the parts add up; results of a profiled reduction are the unprofiled ones
+            main2, tail2 = torch.randn(n_main).to(dtype), torch.randn(n_tail).to(dtype)
+            want_main = main2.clone().float()
+            dist.all_reduce(want_main)
+            red3 = GradReducer(main2, slices, tail2, None, bucket_cap_mb=cap_mb)
+            red3.profile = True
+            for step in range(2):
+                for i in range(len(slices)):
+                    red3.bucket_ready(i)
+                red3.finish()
+                one = red3.comm_collect()
+                assert one is not None and len(one["per_bucket"]) == len(red3.buckets) + 1
+                if step == 0:
+                    assert torch.allclose(main2.float(), want_main / world, atol=tol, rtol=tol)
+            summ = red3.comm_summary()
+            assert summ["steps"] == 2 and [b["name"] for b in summ["per_bucket"]] == ["bucket%d" % i for i in range(len(red3.buckets))] + ["nodecay"]
+            assert summ["exposed_ms"] >= 0 and summ["overlapped_ms"] >= 0 and summ["collectives_ms"] >= 0
+            assert abs(summ["collectives_ms"] - sum(b["ms"] for b in summ["per_bucket"])) <= 1e-2 + 1e-3 * summ["collectives_ms"]
+            assert all(b["mb"] > 0 for b in summ["per_bucket"])
         q.put((rank, "ok"))
     except Exception as e:   # pragma: no cover
         q.put((rank, repr(e)))

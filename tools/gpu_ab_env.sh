@@ -8,5 +8,6 @@ for spec in "$@"; do
     timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -n 1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
-print('%-34s %.3f ms/step  %.1f samples/s  NT avg %.2f us (%.1f TF)' % ('$name', d['ms_per_step'], d['value'], r['avg_launch_us'], r['achieved']))" )
+v=d['config'].get('varlen') or {}
+print('%-34s %.3f ms/step  %.1f samples/s  NT avg %.2f us (%.1f TF) | varlen %s ms/step' % ('$name', d['ms_per_step'], d['value'], r['avg_launch_us'], r['achieved'], v.get('ms_per_step')))" )
 done

@@ -16,7 +16,11 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 BUILD = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libvlp_hip.so")
-SOURCES = ["api.cpp", "gemm_nt.hip", "gemm_nt_ph.hip", "gemm_nt_k32.hip", "gemm_nt_wp.hip", "gemm_nt_ps.hip", "gemm_nt_splitk.hip", "gemm_tn.hip", "attention.hip", "layernorm.hip", "elementwise.hip", "loss.hip", "adam.hip", "pretext.hip"]
+SOURCES = ["api.cpp", "gemm_nt.hip", "gemm_nt_wp.hip", "gemm_nt_ps.hip", "gemm_nt_splitk.hip", "gemm_tn.hip", "attention.hip", "layernorm.hip", "elementwise.hip", "loss.hip", "adam.hip", "pretext.hip"]
+# investigation variants (phased / k32 NT kernels, further wave-pipelined configurations, two-kernel attention backward, stream-K grouped
+# wgrad): `python -m vlp_amd.build --lab` -> vlp_amd/libvlp_hip_lab.so (-DVLP_LAB_BUILD), selected with VLP_HIP_LIB=...; never the product library
+LAB_SOURCES = ["gemm_nt_ph.hip", "gemm_nt_k32.hip"]
+LAB_LIB = os.path.join(HERE, "libvlp_hip_lab.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-Wno-unused-result", "-ffp-contract=fast"]
 
@@ -28,7 +32,13 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, lab=False):
+    if lab:
+        return _build(force, verbose, os.path.join(CSRC, "build_lab"), LAB_LIB, SOURCES + LAB_SOURCES, ["-DVLP_LAB_BUILD"])
+    return _build(force, verbose, BUILD, LIB, SOURCES, [])
+
+
+def _build(force, verbose, BUILD, LIB, SOURCES, extra):
     os.makedirs(BUILD, exist_ok=True)
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + [os.path.join(INCLUDE, "vlp_hip.h")]
     jobs = []
@@ -38,7 +48,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(BUILD, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [sp] + headers):
-            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
+            cmd = [HIPCC] + FLAGS + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
             jobs.append((src, cmd))
 
     def run(job):
@@ -67,4 +77,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, lab="--lab" in sys.argv)

@@ -8,6 +8,7 @@
 //  * vlp_bert_adam: BertAdam.step (optimization.py:112-182): per-TENSOR clip, eps outside the sqrt added to
 //    sqrt(v), decoupled weight decay, no bias correction.
 #include "common.h"
+#include <stdlib.h>
 
 #define SQ_BLOCKS 1024
 
@@ -76,6 +77,81 @@ static int sumsq_launch(const void* g, int64_t n, float* out2, float* partial, i
     return VLP_OK;
 }
 
+// Gradient norm accumulated WHILE backward runs (round 5): the engine hands every finished gradient slice (one per DDP bucket boundary:
+// task head, each layer, embedding tables, region projections) to vlp_sumsq_partial on the stream that produced it -- the slice is
+// still in L2 / the Infinity Cache and the launch overlaps the dgrad chain -- and the optimizer step adds the slices' block partials up
+// in slot order with ONE vlp_sumsq_combine launch instead of re-reading all 232 MB of gradients (vlp_sumsq: 53 us on the critical path).
+// Fixed block count per slice, fixed order everywhere: bitwise reproducible.
+#define SQP_BLOCKS 128
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const f16* __restrict__ g, int64_t n, float* __restrict__ partial) {
+    __shared__ float sh[4], shb[4];
+    float s = 0.f, bad = 0.f;
+    const int64_t n8 = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        f16x8 v = ld8(g + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = (float)v[e];
+            s += f * f;
+            if (!(fabsf(f) <= 65504.f)) bad = 1.f;
+        }
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = n8 * 8 + threadIdx.x; i < n; i += blockDim.x) {
+            const float f = (float)g[i];
+            s += f * f;
+            if (!(fabsf(f) <= 65504.f)) bad = 1.f;
+        }
+    s = wave_sum(s);
+    bad = wave_max(bad);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) { sh[w] = s; shb[w] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+        partial[SQP_BLOCKS + blockIdx.x] = fmaxf(fmaxf(shb[0], shb[1]), fmaxf(shb[2], shb[3]));
+    }
+}
+extern "C" int64_t vlp_sumsq_partial_floats(void) { return 2 * SQP_BLOCKS; }
+extern "C" int vlp_sumsq_partial(const void* g, int64_t n, float* partial, void* stream) {
+    VLP_CHECK_ARG(g && partial && n > 0 && (uintptr_t)g % 16 == 0, "vlp_sumsq_partial: bad args (partial holds vlp_sumsq_partial_floats() floats)");
+    VLP_ENTER(g, "vlp_sumsq_partial");
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SQP_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const f16*)g, n, partial);
+    VLP_CHECK_LAUNCH("vlp_sumsq_partial");
+    return VLP_OK;
+}
+// out2 = (sum, flag) over `slots` consecutive partial blocks, added in slot order then block order by ONE thread block (slots * 128 adds)
+__global__ __launch_bounds__(256) void sumsq_combine_kernel(const float* __restrict__ partials, int slots, float* __restrict__ out2) {
+    __shared__ float sh[256], shb[256];
+    float s = 0.f, bad = 0.f;
+    // thread t owns block t % 128 of the slots t / 128, t / 128 + 2, ...: a fixed assignment; the tree below is fixed too
+    for (int sl = threadIdx.x / SQP_BLOCKS; sl < slots; sl += 256 / SQP_BLOCKS) {
+        const float* p = partials + (int64_t)sl * 2 * SQP_BLOCKS;
+        s += p[threadIdx.x % SQP_BLOCKS];
+        bad = fmaxf(bad, p[SQP_BLOCKS + threadIdx.x % SQP_BLOCKS]);
+    }
+    sh[threadIdx.x] = s;
+    shb[threadIdx.x] = bad;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sh[threadIdx.x] += sh[threadIdx.x + o]; shb[threadIdx.x] = fmaxf(shb[threadIdx.x], shb[threadIdx.x + o]); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float b = shb[0];
+        if (!(sh[0] <= 3.0e38f)) b = 1.f;
+        out2[0] = sh[0];
+        out2[1] = b;
+    }
+}
+extern "C" int vlp_sumsq_combine(const float* partials, int32_t slots, float* out2, void* stream) {
+    VLP_CHECK_ARG(partials && out2 && slots > 0, "vlp_sumsq_combine: bad args");
+    VLP_ENTER(partials, "vlp_sumsq_combine");
+    hipLaunchKernelGGL(sumsq_combine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, slots, out2);
+    VLP_CHECK_LAUNCH("vlp_sumsq_combine");
+    return VLP_OK;
+}
+
 __global__ void adam_hyper_kernel(const float* sumsq2, const float* any_overflow, const float* scale_state, float max_grad_norm, float step_size,
                                   float* hyper) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -125,6 +201,14 @@ extern "C" int vlp_loss_scale_update(float* scale_state, const float* overflow, 
     return VLP_OK;
 }
 
+// Non-temporal loads / stores for the three fp32 state arrays and the gradient: each is touched exactly once per step (2.8 GB of the
+// 3.25 GB), so their lines are kept out of L2 / the Infinity Cache, which are left to the fp16 parameters the next forward reads.
+// Round 5 lab (tools/adam_lab.py, profiles/r05_adam_lab.txt, 115.9 M elements, cold caches): 4096 blocks, temporal accesses (rounds 2-4)
+// 654 - 666 us = 4.9 TB/s; non-temporal 634 - 650; and FEWER resident waves stream better -- 512 blocks (two per CU, 2 waves per SIMD, 8
+// loads of 1 KB in flight per wave) 560 - 588 us = 5.5 - 5.8 TB/s, 768 / 1024 blocks 610 - 628, 256 blocks 740; four runs per wave or
+// one contiguous range per block change nothing.  A torch in-place multiply of one fp32 array reaches 5.7 TB/s on the same box.
+DEVFN f32x4 adam_ld4(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
+DEVFN void adam_st4(float* p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
 __global__ __launch_bounds__(256) void fused_adam_kernel(vlp_fused_adam_args a) {
     const float combined = a.hyper[0], step_size = a.hyper[1], skip = a.hyper[2];
     if (skip != 0.f) return;
@@ -145,10 +229,10 @@ __global__ __launch_bounds__(256) void fused_adam_kernel(vlp_fused_adam_args a) 
             const int64_t i = base + 256 * h + 4 * lane;
             ok[h] = i < a.n;                      // n is a multiple of 8, i of 4: a run is whole or absent per lane
             if (ok[h]) {
-                gv[h] = ld4(g + i);
-                p0[h] = *reinterpret_cast<const f32x4*>(a.p32 + i);
-                m0[h] = *reinterpret_cast<const f32x4*>(a.m + i);
-                v0[h] = *reinterpret_cast<const f32x4*>(a.v + i);
+                gv[h] = __builtin_nontemporal_load(reinterpret_cast<const f16x4*>(g + i));
+                p0[h] = adam_ld4(a.p32 + i);
+                m0[h] = adam_ld4(a.m + i);
+                v0[h] = adam_ld4(a.v + i);
             }
         }
 #pragma unroll
@@ -172,10 +256,10 @@ __global__ __launch_bounds__(256) void fused_adam_kernel(vlp_fused_adam_args a) 
                 asm volatile("" : "+v"(pp[e]));
                 o[e] = (f16)pp[e];
             }
-            *reinterpret_cast<f32x4*>(a.p32 + i) = (f32x4){pp[0], pp[1], pp[2], pp[3]};
-            *reinterpret_cast<f32x4*>(a.m + i) = (f32x4){mm[0], mm[1], mm[2], mm[3]};
-            *reinterpret_cast<f32x4*>(a.v + i) = (f32x4){vv[0], vv[1], vv[2], vv[3]};
-            st4(p16 + i, o);
+            adam_st4(a.p32 + i, (f32x4){pp[0], pp[1], pp[2], pp[3]});
+            adam_st4(a.m + i, (f32x4){mm[0], mm[1], mm[2], mm[3]});
+            adam_st4(a.v + i, (f32x4){vv[0], vv[1], vv[2], vv[3]});
+            st4(p16 + i, o);          // (temporal: the next forward reads the fp16 parameters)
         }
     }
 }
@@ -184,8 +268,9 @@ extern "C" int vlp_fused_adam(const vlp_fused_adam_args* a, void* stream) {
     VLP_ENTER(a->p32, "vlp_fused_adam");
     VLP_CHECK_ARG(a->n > 0 && a->n % 8 == 0, "vlp_fused_adam: n must be a positive multiple of 8 (pad the flat buffer)");
     VLP_CHECK_ARG(((uintptr_t)a->p32 | (uintptr_t)a->m | (uintptr_t)a->v | (uintptr_t)a->g16 | (uintptr_t)a->p16) % 16 == 0, "vlp_fused_adam: alignment");
+    static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n; }();
     int blocks = (int)((a->n / 8 + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 2 * ncu) blocks = 2 * ncu;          // two blocks per CU: see the lab note above the kernel
     hipLaunchKernelGGL(fused_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a);
     VLP_CHECK_LAUNCH("vlp_fused_adam");
     return VLP_OK;

@@ -20,6 +20,13 @@ int vlp_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" int vlp_version(void) { return VLP_ABI_VERSION; }
+extern "C" int vlp_lab_build(void) {
+#ifdef VLP_LAB_BUILD
+    return 1;
+#else
+    return 0;
+#endif
+}
 extern "C" const char* vlp_last_error_string(void) { return g_err; }
 
 // ---- device selection on entry (common.h) -----------------------------------------------------------------------------------------
@@ -44,19 +51,22 @@ int vlp_current_device(void) {
     return d;
 }
 #define VLP_RANGE_SLOTS 64
-#define VLP_RANGE_REVALIDATE 4096
+#define VLP_RANGE_REVALIDATE 256
 struct VlpRange { uintptr_t lo, hi; int dev; unsigned hits; };
 static thread_local VlpRange t_ranges[VLP_RANGE_SLOTS];
 static thread_local int t_nranges = 0, t_next = 0;
 static thread_local unsigned long long t_lookups = 0, t_queries = 0;      // vlp_debug_device_lookup_stats
-static int owner_of(const void* p, const char* who, int* dev) {
+// force: ask the driver even on a cache hit (the guard does so before it SWITCHES devices on the word of a cached entry: a freed segment
+// whose addresses were re-used by an allocation on another device would otherwise send up to VLP_RANGE_REVALIDATE launches to the wrong
+// device; a hit that agrees with the caller's current device -- every call of a one-device-per-process job -- costs no driver call)
+static int owner_of(const void* p, const char* who, int* dev, bool force = false) {
     const uintptr_t a = (uintptr_t)p;
     ++t_lookups;
     for (int i = 0; i < t_nranges; ++i) {
         VlpRange& r = t_ranges[i];
         if (a >= r.lo && a < r.hi) {
-            if (++r.hits % VLP_RANGE_REVALIDATE) { *dev = r.dev; return VLP_OK; }
-            r = t_ranges[--t_nranges];            // periodic re-validation: drop the entry and ask the driver again
+            if (!force && (++r.hits % VLP_RANGE_REVALIDATE)) { *dev = r.dev; return VLP_OK; }
+            r = t_ranges[--t_nranges];            // (periodic) re-validation: drop the entry and ask the driver again
             break;
         }
     }
@@ -87,6 +97,8 @@ VlpDeviceGuard::VlpDeviceGuard(const void* p, const char* who) : prev(-1), rc(VL
     if (rc != VLP_OK || device_count() <= 1) return;
     const int cur = vlp_current_device();
     if (dev == cur) return;
+    rc = owner_of(p, who, &dev, true);         // about to switch devices: on the driver's word, not a cached range's
+    if (rc != VLP_OK || dev == cur) return;
     if (hipSetDevice(dev) != hipSuccess) {
         rc = vlp_set_error(VLP_ERR_HIP, "%s: hipSetDevice(%d): %s", who, dev, hipGetErrorString(hipGetLastError()));
         return;

@@ -359,6 +359,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
     TRACE(7);
 }
 
+#ifdef VLP_LAB_BUILD      // the two-kernel backward (dQ, then dK / dV): the form the one-kernel backward was validated against; investigation builds only
 // =================================================================================================
 // backward, part 1: dQ (and delta = rowsum(dO * O)).  Transposed orientation, query column per lane.
 // =================================================================================================
@@ -609,6 +610,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT >= 8 ? 4 : 2)) void attn
     }
 }
 
+#endif      // VLP_LAB_BUILD
 // =================================================================================================
 // backward, ONE kernel (round 4): dQ, dK, dV and delta in a single pass over the head.
 // The two kernels above each recompute S, P (one v_exp per element), the dropout hash and dP, in opposite orientations: the VALU work
@@ -1286,23 +1288,18 @@ extern "C" int vlp_attn_bwd(const vlp_attn_bwd_args* a, void* stream) {
     p.skip = attn_skip_enabled();
     p.row_off = a->row_off;
     const int LP = lp_of(a->L);
-    const size_t smem_dq = (size_t)2 * LP * HD * 2;
-    const size_t smem_dkv = (size_t)2 * LP * HD * 2 + (size_t)3 * LP * 4;
-    dim3 grid(a->B * a->heads), block(ATT_THREADS);
+    dim3 grid(a->B * a->heads);
     hipStream_t s = (hipStream_t)stream;
-    static const int nw12 = attn_waves_nt12();
-#define LAUNCH_BWD(NT_, NW_)                                                                                         \
-    do {                                                                                                             \
-        VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dq)); \
-        VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<NT_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dkv)); \
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<NT_>, grid, block, smem_dq, s, p);                                     \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<NT_, NW_>), grid, dim3((NW_) * 64), smem_dkv, s, p);                   \
-    } while (0)
-    // one kernel for dQ, dK, dV (default since round 4); VLP_ATTN_BWD=split runs the two-kernel form (A/B runs, and the reference the
-    // merged kernel was validated against)
+    // one kernel for dQ, dK, dV (default since round 4).  Investigation builds (-DVLP_LAB_BUILD) also carry the two-kernel form
+    // (VLP_ATTN_BWD=split: the reference the merged kernel was validated against) and the exchange-tile form at every L (VLP_ATTN_BWD=xch)
     const char* bwd_env = getenv("VLP_ATTN_BWD");         // read at every launch so that tests can toggle it
-    const bool split = bwd_env && bwd_env[0] == 's';
-    VLP_CHECK_ARG(a->row_off == nullptr || (LP <= 192 && !split && !(bwd_env && bwd_env[0] == 'x')),
+#ifdef VLP_LAB_BUILD
+    const bool split = bwd_env && bwd_env[0] == 's', xch = bwd_env && bwd_env[0] == 'x';
+#else
+    const bool split = false, xch = false;
+    VLP_CHECK_ARG(!(bwd_env && (bwd_env[0] == 's' || bwd_env[0] == 'x')), "vlp_attn_bwd: VLP_ATTN_BWD=%s needs a library built with -DVLP_LAB_BUILD", bwd_env);
+#endif
+    VLP_CHECK_ARG(a->row_off == nullptr || (LP <= 192 && !split && !xch),
                   "vlp_attn_bwd: packed rows (row_off) are supported by the one-kernel backward at L <= 192");
     if (!split) {
         const size_t smem_one = (size_t)3 * LP * HD * 2 + (size_t)3 * LP * 4;
@@ -1311,7 +1308,6 @@ extern "C" int vlp_attn_bwd(const vlp_attn_bwd_args* a, void* stream) {
         VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)attn_bwd_one_kernel<NT_, KPW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_one)); \
         hipLaunchKernelGGL((attn_bwd_one_kernel<NT_, KPW_>), grid, dim3((NT_) / (KPW_) * 64), smem_one, s, p);       \
     } while (0)
-        const bool xch = bwd_env && bwd_env[0] == 'x';        // VLP_ATTN_BWD=xch: the exchange-tile form at every L (A/B runs)
         const size_t smem_full = (size_t)3 * LP * HD * 2 + (size_t)LP * LP * 2 + (size_t)3 * LP * 4;
         // persistent grid of the whole-dS^T kernel: one workgroup per CU walks items b*heads + h = blockIdx, + grid, ... (the next item's
         // tiles prefetched into registers); VLP_ATTN_BWD_GRID=0 launches one workgroup per item instead (A/B runs)
@@ -1329,20 +1325,41 @@ extern "C" int vlp_attn_bwd(const vlp_attn_bwd_args* a, void* stream) {
             hipLaunchKernelGGL((attn_bwd_full_kernel<NT_, false>), pgrid, dim3((NT_) * 64), smem_full, s, p);        \
         }                                                                                                            \
     } while (0)
-        if (LP == 64) { if (xch) LAUNCH_ONE(4, 1); else LAUNCH_FULL(4); }
-        else if (LP == 128) { if (xch) LAUNCH_ONE(8, 1); else LAUNCH_FULL(8); }
-        else if (LP == 192) { if (xch) LAUNCH_ONE(12, 1); else LAUNCH_FULL(12); }
-        else LAUNCH_ONE(16, 2);                               // L > 192: dS^T (128 KB) does not fit beside Q, dO, K
+#ifdef VLP_LAB_BUILD
+        if (xch && LP == 64) LAUNCH_ONE(4, 1);
+        else if (xch && LP == 128) LAUNCH_ONE(8, 1);
+        else if (xch && LP == 192) LAUNCH_ONE(12, 1);
+        else
+#endif
+        if (LP == 64) LAUNCH_FULL(4);
+        else if (LP == 128) LAUNCH_FULL(8);
+        else if (LP == 192) LAUNCH_FULL(12);
+        else LAUNCH_ONE(16, 2);                               // L > 192: dS^T (128 KB) does not fit beside Q, dO, K: exchange-tile form
 #undef LAUNCH_FULL
 #undef LAUNCH_ONE
         VLP_CHECK_LAUNCH("vlp_attn_bwd");
         return VLP_OK;
     }
-    if (LP == 64) LAUNCH_BWD(4, 8); else if (LP == 128) LAUNCH_BWD(8, 8);
-    else if (LP == 192) { if (nw12 == 4) LAUNCH_BWD(12, 4); else LAUNCH_BWD(12, 8); }
-    else LAUNCH_BWD(16, 8);
+#ifdef VLP_LAB_BUILD
+    {
+        const size_t smem_dq = (size_t)2 * LP * HD * 2;
+        const size_t smem_dkv = (size_t)2 * LP * HD * 2 + (size_t)3 * LP * 4;
+        dim3 block(ATT_THREADS);
+        static const int nw12 = attn_waves_nt12();
+#define LAUNCH_BWD(NT_, NW_)                                                                                         \
+    do {                                                                                                             \
+        VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dq)); \
+        VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<NT_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dkv)); \
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<NT_>, grid, block, smem_dq, s, p);                                     \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<NT_, NW_>), grid, dim3((NW_) * 64), smem_dkv, s, p);                   \
+    } while (0)
+        if (LP == 64) LAUNCH_BWD(4, 8); else if (LP == 128) LAUNCH_BWD(8, 8);
+        else if (LP == 192) { if (nw12 == 4) LAUNCH_BWD(12, 4); else LAUNCH_BWD(12, 8); }
+        else LAUNCH_BWD(16, 8);
 #undef LAUNCH_BWD
-    VLP_CHECK_LAUNCH("vlp_attn_bwd");
+        VLP_CHECK_LAUNCH("vlp_attn_bwd");
+    }
+#endif
     return VLP_OK;
 }
 

@@ -407,6 +407,15 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
     if (sg && !(variant & 64) && ((variant & 7) == 6 || (variant & 7) == 7)) variant = (a->N > 1024) ? 29 : 27;
     // the wave-pipelined kernels address their operands with 32-bit lane offsets: a problem beyond that falls back to the rings too
     if ((variant & 64) && ((int64_t)p.M * p.ldx >= (1ll << 31) || (int64_t)p.N * p.ldw >= (1ll << 31))) variant = (a->N > 1024) ? 29 : 27;
+#ifndef VLP_LAB_BUILD
+    // investigation variants are not in the product library (tools/build_variant_lib.sh <out.so> -DVLP_LAB_BUILD builds them): the phased
+    // kernels (6 / 7), the k32 ring (53 / 61) and the wave-pipelined configurations other than 1 / 5 run on the rings instead
+    if (!(variant & (64 | 256)) && ((variant & 7) == 6 || (variant & 7) == 7 || ((variant & 7) == 5 && (variant & 48) == 48))) variant = (a->N > 1024) ? 29 : 27;
+    if ((variant & 64) && !(variant & 256)) {
+        const int cfg = (variant & 7) + ((variant & 128) ? 8 : 0);
+        if (cfg != 1 && cfg != 5) variant = (a->N > 1024) ? 29 : 27;
+    }
+#endif
     t_last_variant = variant;
     if (sg) {
         VLP_CHECK_ARG(!a->residual && a->mul_mode == VLP_MUL_NONE && a->dropout_p == 0.f,
@@ -426,11 +435,13 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
         return VLP_OK;
     }
     switch (variant & 7) {
+#ifdef VLP_LAB_BUILD
         case 6: case 7: {
             const int rc = vlp_gemm_nt_ph_launch(p, (variant & 7) == 6 ? 256 : 128, (variant >> 4) & 3, s);
             if (rc != VLP_OK) return rc;
             break;
         }
+#endif
         case 0: LAUNCH_NT(0, 128, 128, 2); break;
         case 1: if (variant & 16) LAUNCH_NT(3, 128, 128, 4); else LAUNCH_NT(1, 128, 128, 2); break;
         case 3:
@@ -440,8 +451,11 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
         case 2: LAUNCH_NT(2, 128, 128, 1); break;
         case 4: LAUNCH_NT(2, 256, 128, 1); break;
         case 5:
+#ifdef VLP_LAB_BUILD
             if ((variant & 48) == 48) { const int rc = vlp_gemm_nt_k32_launch(p, sg, s); if (rc != VLP_OK) return rc; }      /* 53 / 61: k tiles of 32, 4 stages */
-            else if (variant & 16) LAUNCH_RING(256, 256, 2);
+            else
+#endif
+            if (variant & 16) LAUNCH_RING(256, 256, 2);
             else LAUNCH_NT(1, 256, 256, 2);
             break;
         default: LAUNCH_NT(1, 128, 128, 2); break;

@@ -473,17 +473,23 @@ int vlp_gemm_nt_wp_launch(GemmNtParams& p, int cfg, bool sg, hipStream_t s) {
 #define LAUNCH_WP(BNT, WGM, WGN, NSXV, NSWV, RLS, SPR, PBV, LDV) \
     do { if (sg) LAUNCH_WP_(BNT, WGM, WGN, NSXV, NSWV, RLS, SPR, true, PBV, LDV); else LAUNCH_WP_(BNT, WGM, WGN, NSXV, NSWV, RLS, SPR, false, PBV, LDV); } while (0)
     switch (cfg) {
-        case 0: LAUNCH_WP(256, 2, 2, 2, 2, false, false, 4, 1); break;
+        // product library: cfg 5 (variant 77: every N <= 1024 shape of the step) and cfg 1 (variant 73: the 256x256 wave-pipelined tile, kept
+        // as a tuned-table candidate for wide outputs); the other configurations are investigation variants (-DVLP_LAB_BUILD)
         case 1: LAUNCH_WP(256, 2, 4, 2, 2, false, false, 2, 1); break;
+        case 5: LAUNCH_WP(128, 4, 2, 3, 3, false, true, 0, 1); break;
+#ifdef VLP_LAB_BUILD
+        case 0: LAUNCH_WP(256, 2, 2, 2, 2, false, false, 4, 1); break;
         case 2: LAUNCH_WP(256, 2, 2, 2, 2, false, false, 4, 2); break;
         case 3: LAUNCH_WP(256, 2, 2, 3, 2, true, true, 4, 2); break;
         case 4: LAUNCH_WP(128, 2, 2, 3, 3, false, true, 2, 1); break;
-        case 5: LAUNCH_WP(128, 4, 2, 3, 3, false, true, 0, 1); break;
         case 6: LAUNCH_WP(128, 2, 2, 3, 3, false, true, 2, 2); break;
         case 7: LAUNCH_WP(128, 4, 2, 3, 3, false, true, 0, 2); break;
         case 8: LAUNCH_WP(128, 4, 2, 3, 3, true, true, 0, 1); break;
         case 10: LAUNCH_WP(192, 4, 2, 2, 2, false, false, 2, 1); break;
         default: LAUNCH_WP(128, 4, 2, 4, 2, true, true, 0, 1); break;
+#else
+        default: return vlp_set_error(VLP_ERR_BAD_ARG, "vlp_gemm_nt: wave-pipelined configuration %d is an investigation variant (library built without -DVLP_LAB_BUILD)", cfg);
+#endif
     }
 #undef LAUNCH_WP
 #undef LAUNCH_WP_

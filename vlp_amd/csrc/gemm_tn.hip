@@ -483,6 +483,7 @@ __global__ __launch_bounds__((BN_T / 64) * (BK_T / 64) * 64, 2) void gemm_tn_gro
     tn_glds_tile<BN_T, BK_T, NS, BM_T>(p, bid - e.tile_begin, reinterpret_cast<f16*>(smem_raw));
 }
 
+#ifdef VLP_LAB_BUILD      // measured in round 4 and not kept (profiles/r04_grouped_wgrad_balanced.txt): investigation builds only
 // Balanced form of the grouped launch ("tail cohort").  432 equal tiles on 2 x 256 workgroup slots leave 80 CUs with one workgroup instead
 // of two.  Here the tiles are taken six at a time by SEVEN workgroups: six "main" workgroups walk the first nst - tail contraction stages of
 // one tile each -- all main workgroups of the launch sweep the contraction rows in step, which is what keeps every operand block a one-time
@@ -531,6 +532,8 @@ __global__ __launch_bounds__((BN_T / 64) * (BK_T / 64) * 64, 2) void gemm_tn_gro
         }
     }
 }
+
+#endif      // VLP_LAB_BUILD
 
 // out[n,k] = (beta ? out : 0) + sum_s slab[s][n][k]; the tail of the grid reduces the fused bias partials [s][N]
 __global__ void gemm_tn_reduce_kernel(const float* slab, f16* C, int64_t ldc, int N, int K, int splits, int beta,
@@ -682,8 +685,10 @@ extern "C" int vlp_gemm_tn_grouped(const vlp_gemm_tn_args* list, int32_t count, 
     // tile shape / ring depth of the grouped launch: 0 = 128x128 tiles, 2 stages (two 4-wave workgroups per CU); 1 = 256x128, 2 stages;
     // 2 = 256x128, 3 stages; 3 = 128x256, 3 stages (8-wave workgroups, one per CU); 4 = 128x128, FOUR stages of 32 contraction rows (same 64 KiB:
     // two workgroups per CU, three stages in flight).  VLP_TN_GROUP_MODE overrides (A/B runs).
-    int mode = TN_GROUP_DEFAULT_MODE;      // read per launch (a getenv: ~100 ns): tests and A/B runs switch it inside one process
-    if (const char* e = getenv("VLP_TN_GROUP_MODE")) { mode = atoi(e); if (mode < 0 || mode > 5) mode = 0; }
+    int mode = TN_GROUP_DEFAULT_MODE;      // the product library carries mode 0 only; 1 .. 5 were measured in round 4 and lose (-DVLP_LAB_BUILD)
+#ifdef VLP_LAB_BUILD
+    if (const char* e = getenv("VLP_TN_GROUP_MODE")) { mode = atoi(e); if (mode < 0 || mode > 5) mode = 0; }      // read per launch: A/B runs switch it inside one process
+#endif
     // 5 = stream-K form of mode 0 (gemm_tn_grouped_sk_kernel): needs list[0].workspace (vlp_gemm_tn_grouped_workspace_bytes), a tile count that is a
     // multiple of 6, one M for all problems and >= 14 stages; otherwise the launch runs as mode 0
     const int bn = (mode == 0 || mode >= 3) ? 128 : 256, bk = mode == 3 ? 256 : 128;
@@ -709,6 +714,7 @@ extern "C" int vlp_gemm_tn_grouped(const vlp_gemm_tn_args* list, int32_t count, 
         VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<BNT, BKT, NSV, BMV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                                                            \
         hipLaunchKernelGGL((gemm_tn_grouped_kernel<BNT, BKT, NSV, BMV>), dim3(tiles), dim3(((BNT) / 64) * ((BKT) / 64) * 64), smem, (hipStream_t)stream, gp); \
     } while (0)
+#ifdef VLP_LAB_BUILD
     bool sk = (mode == 5);
     if (sk) {
         const int64_t need = vlp_gemm_tn_grouped_workspace_bytes(tiles);
@@ -728,11 +734,13 @@ extern "C" int vlp_gemm_tn_grouped(const vlp_gemm_tn_args* list, int32_t count, 
         const size_t smem = (size_t)2 * 64 * (128 + 128) * sizeof(f16);
         VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm_tn_grouped_sk_kernel<128, 128, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL((gemm_tn_grouped_sk_kernel<128, 128, 2, 64>), dim3(tiles / 6 * 7), dim3(256), smem, (hipStream_t)stream, gp, part, flags);
-    } else if (mode == 0 || mode == 5) LAUNCH_TN_GROUP(128, 128, 2, 64);
-    else if (mode == 1) LAUNCH_TN_GROUP(256, 128, 2, 64);
+    } else if (mode == 1) LAUNCH_TN_GROUP(256, 128, 2, 64);
     else if (mode == 2) LAUNCH_TN_GROUP(256, 128, 3, 64);
     else if (mode == 3) LAUNCH_TN_GROUP(128, 256, 3, 64);
-    else LAUNCH_TN_GROUP(128, 128, 4, 32);
+    else if (mode == 4) LAUNCH_TN_GROUP(128, 128, 4, 32);
+    else
+#endif
+    LAUNCH_TN_GROUP(128, 128, 2, 64);
 #undef LAUNCH_TN_GROUP
     VLP_CHECK_LAUNCH("vlp_gemm_tn_grouped");
     return VLP_OK;

@@ -29,9 +29,31 @@ autograd graph, so the reducer lives here instead:
     summed in another order).  Unmeasured on more than one GPU (world 2 over gloo on CPU and on one GPU, world 1 over RCCL).
 """
 import os
+import time
 
+import torch
 import torch.distributed as dist
 from torch import nn
+
+
+class _Stamp(object):
+    """A point in time of a stream (HIP event) or, for CPU tensors (gloo tests), of the host."""
+
+    def __init__(self, cuda):
+        self.ev = torch.cuda.Event(enable_timing=True) if cuda else None
+        self.t = None
+
+    def record(self, stream=None):
+        if self.ev is not None:
+            self.ev.record(stream if stream is not None else torch.cuda.current_stream())
+        else:
+            self.t = time.perf_counter()
+        return self
+
+    def ms_until(self, other):
+        if self.ev is not None:
+            return self.ev.elapsed_time(other.ev)
+        return (other.t - self.t) * 1e3
 
 
 def coalesce_buckets(slices, cap):
@@ -78,8 +100,43 @@ class GradReducer(object):
                 raise ValueError("VLP_DDP_MODE=%s: bucket sizes %r are not divisible by the world size %d" % (self.mode, bad, self.world))
         self._avg = dist.get_backend(process_group) == "nccl"
         self._work = []
+        # comm profile (bench.py --gpus N, second un-timed pass): per collective the moment its slice was ready (stamp on the issuing
+        # stream) and the moment it completed (stamp on an OBSERVER stream that waits for that collective only), plus the end of
+        # backward's compute on the main stream -- so a scaling result can be read as exposed vs overlapped communication
+        self.profile = False
+        self._obs = None
+        self._stamps = []          # [(label, numel, ready, done)] of the current step
+        self.comm_steps = []       # one summary dict per profiled step (comm_summary())
 
-    def _reduce(self, t):
+    def _observe(self, n_before, label, t, ready):
+        """Profile hook: the collectives appended to self._work since n_before belong to one bucket; their completion is stamped on the
+        observer stream (Work.wait() makes the CURRENT stream wait -- here the observer, which has nothing else to do)."""
+        cuda = t.is_cuda
+        done = _Stamp(cuda)
+        if cuda:
+            if self._obs is None:
+                self._obs = torch.cuda.Stream(device=t.device)
+            with torch.cuda.stream(self._obs):
+                for work, _ in self._work[n_before:]:
+                    if work is not None:
+                        work.wait()
+                done.record(self._obs)
+        else:
+            for work, _ in self._work[n_before:]:
+                if work is not None:
+                    work.wait()
+            done.record()
+        self._stamps.append((label, t.numel() * t.element_size(), ready, done))
+
+    def _reduce(self, t, label="bucket"):
+        if self.profile:
+            n0, ready = len(self._work), _Stamp(t.is_cuda).record()
+            self._reduce_impl(t)
+            self._observe(n0, label, t, ready)
+        else:
+            self._reduce_impl(t)
+
+    def _reduce_impl(self, t):
         if self.mode != "allreduce":                 # (also with one rank: the same RCCL calls, a path check)
             self._reduce_rs_ag(t, gather=self.mode == "rs_ag")
         elif self._avg:
@@ -110,16 +167,59 @@ class GradReducer(object):
         b = self.fire_at.get(slice_index)
         if b is not None:
             lo, hi = self.buckets[b]
-            self._reduce(self.flat_main[lo:hi])
+            self._reduce(self.flat_main[lo:hi], "bucket%d" % b)
 
     def finish(self):
+        bwd_end = _Stamp(self.flat_main.is_cuda).record() if self.profile else None      # backward's last compute kernel, main stream
         if self.flat_tail is not None:
-            self._reduce(self.flat_tail)
+            self._reduce(self.flat_tail, "nodecay")
         for work, t in self._work:
-            work.wait()          # makes the current stream wait for the collective; no host sync on RCCL
+            if work is not None:
+                work.wait()          # makes the current stream wait for the collective; no host sync on RCCL
             if t is not None:
                 t.div_(self.world)
         self._work = []
+        if self.profile:
+            resumed = _Stamp(self.flat_main.is_cuda).record()       # the main stream may continue (optimizer step) from here
+            self._pending = (bwd_end, resumed, self._stamps)
+            self._stamps = []
+
+    def comm_collect(self):
+        """Turn the stamps of the last profiled step into numbers (synchronises: call outside timed regions).  A collective's
+        duration is counted from max(its slice was ready, the previous collective completed) -- RCCL runs them in issue order."""
+        pend = getattr(self, "_pending", None)
+        if pend is None:
+            return None
+        if self.flat_main.is_cuda:
+            torch.cuda.synchronize()
+        bwd_end, resumed, stamps = pend
+        self._pending = None
+        per, prev_done, total = [], None, 0.0
+        for label, nbytes, ready, done in stamps:
+            dur = ready.ms_until(done)
+            if prev_done is not None:
+                dur = min(dur, max(prev_done.ms_until(done), 0.0))
+            per.append({"name": label, "mb": round(nbytes / 2.0 ** 20, 4), "ms": round(dur, 4), "done_after_backward_ms": round(bwd_end.ms_until(done), 4)})
+            total += dur
+            prev_done = done
+        exposed = max(bwd_end.ms_until(resumed), 0.0)
+        out = {"exposed_ms": round(exposed, 4), "overlapped_ms": round(max(total - exposed, 0.0), 4), "collectives_ms": round(total, 4), "per_bucket": per}
+        self.comm_steps.append(out)
+        return out
+
+    def comm_summary(self):
+        """Mean over the profiled steps: {"exposed_ms", "overlapped_ms", "collectives_ms", "per_bucket": [{name, mb, ms}], "steps"};
+        exposed = end of backward's compute on the main stream -> the main stream may run the optimizer (all collectives waited for)."""
+        if not self.comm_steps:
+            return None
+        n = len(self.comm_steps)
+        out = {k: round(sum(s[k] for s in self.comm_steps) / n, 4) for k in ("exposed_ms", "overlapped_ms", "collectives_ms")}
+        first = self.comm_steps[0]["per_bucket"]
+        out["per_bucket"] = [{"name": b["name"], "mb": b["mb"], "ms": round(sum(s["per_bucket"][i]["ms"] for s in self.comm_steps) / n, 4),
+                              "done_after_backward_ms": round(sum(s["per_bucket"][i]["done_after_backward_ms"] for s in self.comm_steps) / n, 4)}
+                             for i, b in enumerate(first)]
+        out["steps"] = n
+        return out
 
 
 def owned_chunk(lo, hi, world, rank):

@@ -47,7 +47,7 @@ class _State(object):
 
 class Engine(object):
     GEMM_NT_VARIANT = None   # None -> vlp_amd.tuning (committed table, else shape heuristic; timing search only with VLP_AUTOTUNE=1); or force an int
-    NT_CANDIDATES = (1, 2, 4, 5, 9, 10, 11, 12, 13, 27, 29, 73, 77, 264)   # LDS-DMA variants (+8 = XCD-aware tile order, +16 = ring, 64 + cfg = wave-pipelined, 256 = persistent k stream); see include/vlp_hip.h
+    NT_CANDIDATES = (1, 2, 4, 5, 9, 10, 11, 12, 13, 27, 29, 73, 77, 264)   # product variants (+8 = XCD-aware tile order, +16 = ring, 64 + cfg = wave-pipelined, 256 = persistent k stream); see include/vlp_hip.h
     NT_CANDIDATES_SKINNY = (1, 2, 9, 10, 11, 17)      # M <= 1024 (decoding, LM head): few workgroups, latency-bound -> also the 4-stage ring
     GEMM_TN_VARIANT = 2      # ds_read_b64_tr_b16 fragment reads + LDS-DMA staging
     # weight-gradient GEMMs of the encoder layers on a second HIP stream, concurrent with the dgrad chain (the wgrad grids are a single
@@ -59,8 +59,8 @@ class Engine(object):
     LN_DEFER = os.environ.get("VLP_LN_DEFER", "1") == "1"               # LayerNorm dgamma / dbeta second stages batched into one launch per backward
     SHADOW_ON_SIDE = os.environ.get("VLP_SHADOW_SIDE", "1") == "1"      # W^T shadows transposed on the side stream during the forward
     # mask_image_regions: the reference's loader line `input_mask[:, vis_masked_pos].fill_(0)` (seq2seq_loader.py:303-304) indexes with a
-    # numpy array -- advanced indexing, i.e. it fills a COPY and leaves the mask untouched (checked on torch 2.10 and by
-    # tests/test_oracle_vs_reference.py against the unmodified loader): masked regions enter the encoder as zeros but stay attendable.
+    # numpy array -- advanced indexing, i.e. it fills a COPY and leaves the mask untouched (checked on torch 2.10 and, against the unmodified
+    # loader, by the reference-pinning CPU tests): masked regions enter the encoder as zeros but stay attendable.
     # Parity follows that behaviour; VLP_BLOCK_MASKED_REGIONS=1 follows the line's comment instead ("block the masked visual feature")
     # on the MaskSpec path (a dense attention_mask is always used as given).
     BLOCK_MASKED_REGION_KEYS = os.environ.get("VLP_BLOCK_MASKED_REGIONS", "0") == "1"
@@ -73,6 +73,12 @@ class Engine(object):
     # row_off; dropout hashes keep the logical (b*L + l, col) element, so masks -- and with them losses, logits and gradients --
     # equal the dense run's up to the fp32 summation order of the weight-gradient / LayerNorm-parameter sums.
     VARLEN = os.environ.get("VLP_VARLEN", "0") == "1"
+    # gradient norm of the decay group accumulated slice by slice while backward runs (vlp_sumsq_partial on the stream that produced the
+    # slice) instead of one pass over all 232 MB in front of the optimizer step; single-process runs only -- under DDP a slice is final
+    # only after its collective.  OPT-IN (VLP_NORM_PER_SLICE=1): measured in the step on one box it LOSES, 9.738 / 9.722 against 9.666 / 9.671
+    # ms/step (profiles/r05_instep_ab_norm_per_slice.txt) -- fifteen more launches on the side stream cost the co-running dgrad chain more
+    # than the 53 us pass over the gradients they replace.  Default: one vlp_sumsq over the whole buffer in front of the optimizer step.
+    NORM_PER_SLICE = os.environ.get("VLP_NORM_PER_SLICE", "0") == "1"
     GROUPED_WGRAD = os.environ.get("VLP_GROUPED_WGRAD", "1") == "1"     # one vlp_gemm_tn_grouped launch per layer instead of 4 split-M wgrads + 4 reduces
     TN_SPLITS = None         # None -> vlp_amd.tuning (variant flags, split-M factor) per (M, N, K)
     # split-M factor: the wgrad outputs are small (36..144 tiles of 128x128) and the contraction long (M = 10 688), so the
@@ -104,9 +110,12 @@ class Engine(object):
         self._params_done = None          # event behind its last chunk
         self.shard_plan = None            # vlp_amd.distributed.ShardPlan when the optimizer step is sharded over the ranks (VLP_DDP_MODE=sharded)
         self._param_works = None          # {"nodecay" | reducer bucket: collective work} of the last sharded step's parameter all-gather
+        self.param_gather_stamps = None   # list -> (before, after) event pairs around every wait for a parameter all-gather (comm profile)
         self._side = None                 # second HIP stream for the layer wgrads (created on first use)
         self._side_busy = False           # True while backward may have work queued on it
         self._prof_ctr = 0
+        self._gn_slots = None             # f32 [slices, vlp_sumsq_partial_floats()]: block partials of sum(g^2) per gradient slice (NORM_PER_SLICE)
+        self.grad_norm_slices_valid = False   # True after a backward that filled every slot for the CURRENT contents of the gradient buffer
         self.varlen = self.VARLEN         # padding-free (packed) training step, see VARLEN
         self._pk_cache = {}               # kept-length tuple -> (row_off, row_map device tensors, M'): batches repeat in bench / epochs
         self._pk_lens = {}                # id(mask tensor) -> (weakref, version, ..., lens): lengths derived from a dense mask, once per tensor
@@ -252,6 +261,10 @@ class Engine(object):
         ("nodecay" or a bucket index); key=None: all of them (also orders the optimizer's reads of the gradient buffers before later work)."""
         if self._param_works is not None:          # sharded step: parameter chunks arrive by all-gather, one collective per bucket
             works = self._param_works
+            prof = self.param_gather_stamps            # bench.py comm profile: how long the forward stood still for its parameters
+            if prof is not None:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
             if key is None:
                 for w in works.values():
                     if w is not None:
@@ -263,6 +276,10 @@ class Engine(object):
                 if w is not None:
                     w.wait()
                     works[k] = None
+            if prof is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                prof.append((e0, e1))
         if self._params_done is None:
             return
         if key is None:
@@ -336,10 +353,6 @@ class Engine(object):
                        for _ in range(2)]
         tn_bytes = max(K.gemm_tn_workspace_bytes(M, I, H), K.gemm_tn_workspace_bytes(Mv, 2048, 2048), K.gemm_tn_workspace_bytes(M, 3 * H, H))
         ws["tn_ws"] = torch.empty(tn_bytes, device=dev, dtype=torch.uint8)
-        # stream-K form of the per-layer grouped wgrad (csrc/gemm_tn.hip): one fp32 partial + flag per 128x128 output tile of a layer's four
-        # weight gradients; used by the side-stream launches only (serialized in that stream)
-        lt = (H // 128) * (I // 128) * 2 + (3 * H // 128) * (H // 128) + (H // 128) * (H // 128) if H % 128 == 0 and I % 128 == 0 else 0
-        ws["tn_sk_ws"] = torch.empty(K.gemm_tn_grouped_workspace_bytes(lt), device=dev, dtype=torch.uint8) if lt and lt % 6 == 0 else None
         ws["cs_ws"] = torch.empty(max(K.colsum_workspace_bytes(M, I), K.colsum_workspace_bytes(B * max(P, 1), Vp)), device=dev, dtype=torch.uint8)
         ws["ln_ws"] = torch.empty(K.layernorm_bwd_workspace_bytes(max(H, 8)), device=dev, dtype=torch.uint8)
         # one private partials slot per encoder / embedding LayerNorm: their dgamma / dbeta second stages run as ONE launch at the
@@ -1116,6 +1129,12 @@ class Engine(object):
     def _bucket_done(self, idx):
         if self.grad_ready_hook is not None:
             self.grad_ready_hook(idx)
+        elif self.NORM_PER_SLICE:
+            # slice idx of the decay gradient is final in this stream's order: its share of the gradient norm, while the lines are hot
+            if self._gn_slots is None:
+                self._gn_slots = torch.zeros(len(self.buckets), K.sumsq_partial_floats(), device=self.device, dtype=torch.float32)
+            lo, hi = self.buckets[idx]
+            K.sumsq_partial(self.gflat["decay"][lo:hi], hi - lo, self._gn_slots[idx])
 
     def backward(self, st, gscale, task, g_pretext=None):
         """gscale: device f32 tensor [1] = upstream gradient of the task loss (x loss scale); g_pretext: the same for the pretext loss of
@@ -1137,6 +1156,7 @@ class Engine(object):
             raise RuntimeError("vlp_amd: VLP_DDP_MODE=sharded keeps only this rank's chunk of the reduced gradient, so gradients cannot be "
                                "accumulated over several backward passes (--gradient_accumulation_steps > 1); use allreduce or rs_ag")
         img, input_ids, token_type_ids, masked_pos = st.batch
+        self.grad_norm_slices_valid = False
         self.wait_params()           # the optimizer stream has read the previous gradients and written every parameter
         if getattr(self, "_shadow_ev", None) is not None:
             torch.cuda.current_stream().wait_event(self._shadow_ev)     # transposed during the forward (side stream)
@@ -1285,8 +1305,7 @@ class Engine(object):
                         (dy2, a["g"], self.G(Ln + "output.dense.weight"), M, H, I, beta, self.G(Ln + "output.dense.bias")),
                         (ds["dz"], a["x1"], self.G(Ln + "intermediate.dense.weight"), M, I, H, beta, self.G(Ln + "intermediate.dense.bias")),
                         (dqkv, x_in, self.G(Ln + "attention.self.query.weight"), M, 3 * H, H, beta, self.G(Ln + "attention.self.query.bias")),
-                        (dy1, a["ctx"], self.G(Ln + "attention.output.dense.weight"), M, H, H, beta, self.G(Ln + "attention.output.dense.bias"))],
-                        workspace=ws["tn_sk_ws"])
+                        (dy1, a["ctx"], self.G(Ln + "attention.output.dense.weight"), M, H, H, beta, self.G(Ln + "attention.output.dense.bias"))])
                 else:
                     self._tn(dqkv, x_in, self.G(Ln + "attention.self.query.weight"), M, 3 * H, H, ws, beta,
                              bias=self.G(Ln + "attention.self.query.bias"))     # packed [3H, H] gradient
@@ -1336,6 +1355,7 @@ class Engine(object):
         K.copy2d(ws["dwpe_pad"], PE_PAD, False, self.G("vis_pe_embed.0.weight"), PE_DIM, H, PE_DIM, PE_DIM, beta=beta)
         K.colsum(ws["d_vispe_h"], self.G("vis_pe_embed.0.bias"), Mv, H, beta=beta, workspace=ws["cs_ws"])
         self._bucket_done(NL + 2)
+        self.grad_norm_slices_valid = self.grad_ready_hook is None and self.NORM_PER_SLICE
         self.grads_dirty = True
         if self.post_backward_hook is not None:
             self.post_backward_hook()

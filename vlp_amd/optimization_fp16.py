@@ -234,8 +234,7 @@ class FP16_Optimizer_State(object):
         if self.pipeline_with_forward:
             return self._step_pipelined()
         eng.wait_params()                        # a previous pipelined step may still be writing
-        for i, key in enumerate(self._group_key):
-            K.sumsq(eng.gflat[key], eng.sizes[key], self._sumsq[i], self._partial)
+        self._grad_norms()
         # apex skips the whole step when ANY group overflowed
         torch.maximum(self._sumsq[0][1:2], self._sumsq[1][1:2], out=self._ovf)
         for i, key in enumerate(self._group_key):
@@ -243,6 +242,16 @@ class FP16_Optimizer_State(object):
             K.adam_hyper(self._sumsq[i], self._ovf, self._scale_state, g["max_grad_norm"], self._step_size(g), self._hyper[i])
             self._adam_range(i, key, 0, eng.sizes[key])
         K.loss_scale_update(self._scale_state, self._ovf)
+
+    def _grad_norms(self):
+        """(sum of squares, overflow flag) of every param group's gradient -> self._sumsq[i].  The decay group's was accumulated slice by
+        slice during backward when the engine says so (Engine.NORM_PER_SLICE: one combine launch here instead of a pass over 232 MB)."""
+        eng = self.engine
+        for i, key in enumerate(self._group_key):
+            if key == "decay" and getattr(eng, "grad_norm_slices_valid", False):
+                K.sumsq_combine(eng._gn_slots, len(eng.buckets), self._sumsq[i])
+            else:
+                K.sumsq(eng.gflat[key], eng.sizes[key], self._sumsq[i], self._partial)
 
     def _step_size(self, g):
         if g["bias_correction"]:
@@ -271,8 +280,7 @@ class FP16_Optimizer_State(object):
         st.wait_stream(main)                     # backward (and the gradient all-reduce) is complete in main's order
         events = {}
         with torch.cuda.stream(st):
-            for i, key in enumerate(self._group_key):
-                K.sumsq(eng.gflat[key], eng.sizes[key], self._sumsq[i], self._partial)
+            self._grad_norms()
             torch.maximum(self._sumsq[0][1:2], self._sumsq[1][1:2], out=self._ovf)
             for i, key in enumerate(self._group_key):
                 g = self.param_groups[i]
