@@ -36,6 +36,38 @@ def run(m, b, scale=1.0, backward=False):
     return losses[0].detach().clone(), m.last_mlm_logits.detach().clone()
 
 
+def test_full_size_padding_free_step_equals_dense(model):
+    """BASELINE size (B = 64, L = 167, 12 layers), the SAME model object run dense and packed (Engine.varlen): with dropout 0 and with
+    dropout 0.1 the logits and the loss are BIT-equal (so every parity statement about the dense logits holds for the packed step, and
+    the dropout masks are the dense run's), every gradient tensor agrees to fp32-summation noise (<= 2e-4 rel-L2)."""
+    eng = model.engine
+    batch = S.batch_to(S.make_batch(B, max_len_b=64, vocab_size=V, max_pred=3, s2s_prob=0.75, seed=7), DEV, half=True)
+    cfg = model.config
+    try:
+        for pdrop in (0.0, 0.1):
+            cfg.hidden_dropout_prob = cfg.attention_probs_dropout_prob = pdrop
+            model.train(pdrop > 0)
+            res = []
+            for packed in (False, True):
+                eng.varlen = packed
+                eng.step_seed = 41                       # same dropout stream position for both runs
+                loss, logits = run(model, batch, scale=1024.0, backward=True)
+                assert (eng.last_packed_rows is not None) == packed
+                if packed:
+                    L = batch.input_ids.shape[1]
+                    assert eng.last_packed_rows == int(sum(int(batch.input_mask[i].any(dim=0).nonzero().max()) + 1 for i in range(B))) < B * L
+                res.append((loss, logits, {n: q.grad.detach().float().clone() for n, q in model.named_parameters()}))
+            (l0, g0, gr0), (l1, g1, gr1) = res
+            assert torch.equal(l0, l1) and torch.equal(g0, g1), pdrop
+            worst = max((float((gr0[n] - gr1[n]).norm()) / max(float(gr0[n].norm()), 1e-30), n) for n in gr0 if float(gr0[n].norm()) > 0)
+            print("full size, dropout %.1f: packed rows %d of %d, worst gradient tensor rel-L2 %.2e (%s)" % (pdrop, eng.last_packed_rows, B * 167, worst[0], worst[1]))
+            assert worst[0] <= 2e-4, worst
+    finally:
+        eng.varlen = False
+        cfg.hidden_dropout_prob = cfg.attention_probs_dropout_prob = 0.0
+        model.eval()
+
+
 def permuted(b, perm):
     return type(b)(*[t[perm] if torch.is_tensor(t) and t.dim() > 0 and t.shape[0] == B else t for t in b])
 

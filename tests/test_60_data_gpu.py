@@ -47,7 +47,7 @@ def test_prefetcher_delivers_exact_batches(tmp_path):
     got = []
     for batch in pf:
         torch.cuda.synchronize()
-        got.append([t.cpu() if torch.is_tensor(t) else type(t)(*(x.cpu() for x in t)) for t in batch])
+        got.append([t.cpu() if torch.is_tensor(t) else type(t)(*(x.cpu() if torch.is_tensor(x) else x for x in t)) for t in batch])
     assert len(got) == steps
     # replay the same sample stream synchronously
     order = list(range(len(examples)))
@@ -63,6 +63,7 @@ def test_prefetcher_delivers_exact_batches(tmp_path):
             assert g[0][j].tolist() == t["input_ids"] and g[1][j].tolist() == t["segment_ids"]
             assert g[3][j].tolist() == t["masked_ids"] and g[4][j].tolist() == t["masked_pos"] and g[5][j].tolist() == t["masked_weights"]
             assert int(g[2].second_st[j]) == t["len_a"] + 2 and int(g[2].second_end[j]) == t["len_a"] + t["len_b"] + 3
+            assert g[2].lens_host[j] == t["len_a"] + t["len_b"] + 3          # host copy of second_end: the padding-free step needs no read-back
             assert int(g[2].is_s2s[j]) == int(t["is_s2s"]) and int(g[7][j]) == t["task_idx"] and int(g[6][j]) == -1
             r = row[img_id]
             assert np.array_equal(g[8][j].numpy(), feats[r]) and np.array_equal(g[10].cls_prob[j].numpy(), cls[r])
@@ -76,7 +77,7 @@ def _clone_batch(batch):
         if torch.is_tensor(t):
             out.append(t.clone())
         else:
-            out.append(type(t)(*(x.clone() for x in t)))
+            out.append(type(t)(*(x.clone() if torch.is_tensor(x) else x for x in t)))
     return tuple(out)
 
 
@@ -112,6 +113,36 @@ def test_training_from_the_prefetcher(tmp_path):
         assert torch.equal(x, y), (la, lb)
     for key in ("decay", "nodecay"):
         assert torch.equal(model_a.engine.flat[key], model_b.engine.flat[key]), key
+
+
+def test_padding_free_training_from_the_prefetcher(tmp_path):
+    """The loader's MaskSpec carries the per-sample lengths on the host (lens_host), so the padding-free step (Engine.varlen) packs its
+    rows without reading anything back from the device: same losses as the dense step bit for bit (the forward is), parameters after six
+    steps equal to fp16 working precision (weight-gradient sums run over fewer, differently grouped rows)."""
+    store, examples, *_ = make_store(tmp_path, n=16, seed=1)
+    p_s2s, p_bi = procs()
+    model_a, opt_a = _tiny_model_and_opt(3e-4)
+    model_b, opt_b = _tiny_model_and_opt(3e-4)
+    model_b.engine.varlen = True
+    random.seed(5)
+    first = None
+    for batch in BatchPrefetcher(store, examples, 8, p_s2s, p_bi, s2s_prob=0.75, device=DEV, steps=6, seed=1):
+        assert batch[2].lens_host is not None and len(batch[2].lens_host) == 8
+        resident = _clone_batch(batch)
+        la = train_step(model_a, opt_a, batch, 3e-4)[0].detach().clone()
+        lb = train_step(model_b, opt_b, resident, 3e-4)[0].detach().clone()
+        assert model_a.engine.last_packed_rows is None and model_b.engine.last_packed_rows == sum(batch[2].lens_host) < 8 * 123
+        if first is None:
+            first = (la, lb)
+        assert abs(float(la) - float(lb)) <= 2e-3 * abs(float(la))        # (later steps: the parameters differ in their last bits)
+    torch.cuda.synchronize()
+    assert torch.equal(first[0], first[1])                                # same parameters, same masks: the packed forward is bit-identical
+    for key in ("decay", "nodecay"):
+        # six Adam steps of lr 3e-4 without bias correction move a weight by up to 6 x 3e-4 x 3.2 = 5.7e-3.  Where a gradient is pure rounding
+        # noise (the key biases: exactly zero in exact arithmetic, 6 % of the no-decay group) the two runs may walk in opposite directions;
+        # everywhere else they agree to a small fraction of the distance travelled
+        d = (model_a.engine.flat[key].float() - model_b.engine.flat[key].float()).abs()
+        assert float(d.max()) <= 1.2e-2 and float((d > 1e-3).float().mean()) <= (0.10 if key == "nodecay" else 0.002), (key, float(d.max()), float((d > 1e-3).float().mean()))
 
 
 def test_repeated_prefetcher_batch_is_learned(tmp_path):
