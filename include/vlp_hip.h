@@ -334,6 +334,9 @@ typedef struct {
     float drop_p; uint64_t seed; uint32_t vis_stream; uint32_t vispe_stream;
     const uint8_t* region_mask;                             /* ABI 3: [B*Nv] or NULL; rows with 1 got no signal from the encoder: their d_vis_h /
                                                                d_vispe_h rows are NOT written here (vlp_pretext_bwd owns them) */
+    int32_t parts;                                          /* ABI 4: 0 = everything; 1 = region rows only (d_vis_h / d_vispe_h: what the region-
+                                                               projection dgrad chain waits for); 2 = the three embedding tables only.  The two
+                                                               halves read dpre and write disjoint outputs: a caller may run them on two streams. */
 } vlp_embed_bwd_args;
 int vlp_embed_bwd(const vlp_embed_bwd_args* a, void* stream);
 

@@ -94,7 +94,7 @@ class EmbedBwdArgs(C.Structure):
     _fields_ = [("dpre", vp), ("input_ids", vp), ("segment_ids", vp), ("vis_h", vp), ("vispe_h", vp),
                 ("d_word_emb", vp), ("d_pos_emb", vp), ("d_type_emb", vp), ("d_vis_h", vp), ("d_vispe_h", vp), ("acc32", vp),
                 ("B", i32), ("L", i32), ("Nv", i32), ("H", i32), ("vocab", i32), ("type_vocab", i32),
-                ("drop_p", f32), ("seed", u64), ("vis_stream", u32), ("vispe_stream", u32), ("region_mask", vp)]
+                ("drop_p", f32), ("seed", u64), ("vis_stream", u32), ("vispe_stream", u32), ("region_mask", vp), ("parts", i32)]
 
 
 class PretextFwdArgs(C.Structure):
@@ -507,11 +507,12 @@ def embed_bwd_workspace_floats(B, L, Nv, H):
 
 
 def embed_bwd(dpre, input_ids, segment_ids, vis_h, vispe_h, d_word, d_pos, d_type, d_vis_h, d_vispe_h, acc32,
-              B, L, Nv, H, vocab, type_vocab, drop_p=0.0, seed=0, vis_stream=0, vispe_stream=0, region_mask=None):
+              B, L, Nv, H, vocab, type_vocab, drop_p=0.0, seed=0, vis_stream=0, vispe_stream=0, region_mask=None, parts=0):
+    """parts: 0 = everything, 1 = region rows only (d_vis_h / d_vispe_h), 2 = the embedding tables only."""
     _req_cuda(dpre, input_ids, segment_ids, d_word, d_pos, d_type, acc32, region_mask)
     a = EmbedBwdArgs(ptr(dpre), ptr(input_ids), ptr(segment_ids), ptr(vis_h), ptr(vispe_h), ptr(d_word), ptr(d_pos), ptr(d_type),
                      ptr(d_vis_h), ptr(d_vispe_h), ptr(acc32), B, L, Nv, H, vocab, type_vocab, drop_p, seed, vis_stream, vispe_stream,
-                     ptr(region_mask))
+                     ptr(region_mask), parts)
     _check(load().vlp_embed_bwd(C.byref(a), stream_ptr()))
 
 

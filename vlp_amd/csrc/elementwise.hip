@@ -292,9 +292,13 @@ extern "C" int vlp_embed_bwd(const vlp_embed_bwd_args* a, void* stream) {
     const int64_t total = (int64_t)a->B * a->L * (a->H / 8);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(256), 0, s, *a, make_drop(a->drop_p, a->seed, a->vis_stream),
-                       make_drop(a->drop_p, a->seed, a->vispe_stream));
-    VLP_CHECK_LAUNCH("vlp_embed_bwd");
+    VLP_CHECK_ARG(a->parts >= 0 && a->parts <= 2, "vlp_embed_bwd: parts must be 0 (all), 1 (region rows) or 2 (tables)");
+    if (a->parts != 2 && a->Nv > 0) {
+        hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(256), 0, s, *a, make_drop(a->drop_p, a->seed, a->vis_stream),
+                           make_drop(a->drop_p, a->seed, a->vispe_stream));
+        VLP_CHECK_LAUNCH("vlp_embed_bwd");
+    }
+    if (a->parts == 1) return VLP_OK;
     {
         EwbGeom g;
         g.ids = a->input_ids; g.L = a->L; g.Nv = a->Nv; g.T = a->L - a->Nv; g.NT = a->B * g.T; g.vocab = a->vocab;

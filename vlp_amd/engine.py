@@ -57,6 +57,7 @@ class Engine(object):
     # first lets the side stream drain (see _nt).
     WGRAD_SIDE_STREAM = os.environ.get("VLP_WGRAD_SIDE_STREAM", "1") == "1"
     LN_DEFER = os.environ.get("VLP_LN_DEFER", "1") == "1"               # LayerNorm dgamma / dbeta second stages batched into one launch per backward
+    TAIL_ON_SIDE = os.environ.get("VLP_TAIL_SIDE", "1") == "1"          # embedding-table gradients + that batched launch on the side stream, under the region-projection backward
     SHADOW_ON_SIDE = os.environ.get("VLP_SHADOW_SIDE", "1") == "1"      # W^T shadows transposed on the side stream during the forward
     # mask_image_regions: the reference's loader line `input_mask[:, vis_masked_pos].fill_(0)` (seq2seq_loader.py:303-304) indexes with a
     # numpy array -- advanced indexing, i.e. it fills a COPY and leaves the mask untouched (checked on torch 2.10 and, against the unmodified
@@ -629,28 +630,6 @@ class Engine(object):
         st.pk = (ro, rm, M) if ro is not None else None
         self.last_packed_rows = M if ro is not None else None
 
-        # ---- W^T shadows of this step's dgrad GEMMs: the weights are final once the optimizer has stepped, so the batched transpose
-        # (78 us) runs on the side stream underneath the forward instead of at the head of backward
-        self._shadow_ev = None
-        if (train or torch.is_grad_enabled()) and self.WGRAD_SIDE_STREAM and self.SHADOW_ON_SIDE:
-            main = torch.cuda.current_stream()
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=self.device)
-                self._side_done = [None, None]
-            self._side.wait_stream(main)
-            if self._params_done is not None:
-                self._side.wait_event(self._params_done)        # the transposes read every weight matrix
-            with torch.cuda.stream(self._side):
-                if self._param_works is not None:
-                    # sharded optimizer step: the parameters arrive by per-bucket all-gathers that may still be in flight; the
-                    # transposes read EVERY weight matrix, so this stream waits for all of them (the main stream keeps waiting per
-                    # bucket where the forward first reads it -- Work.wait() may be called again there)
-                    for w in self._param_works.values():
-                        if w is not None:
-                            w.wait()
-                self._refresh_shadows()
-                self._shadow_ev = torch.cuda.Event()
-                self._shadow_ev.record(self._side)
         # ---- inputs -----------------------------------------------------------------------------
         want_t = ws["maskt"] if train or torch.is_grad_enabled() else None
         pt = None
@@ -661,42 +640,85 @@ class Engine(object):
             K.region_mask_build(st_vmp, pt["rmask"], B, Pm, Nv)
         self._pretext_on = pt is not None
         st.pretext = (pt, st_vmp) if pt is not None else None
-        if mask_spec:                       # per-sample lengths -> packed masks on the device (seq2seq_loader.py:292-301)
-            attention_mask.check(B, L)
-            # (BLOCK_MASKED_REGION_KEYS: opt-in, the reference's own loader leaves the masked regions' key columns attendable, see above)
-            K.mask_build(attention_mask.second_st, attention_mask.second_end, attention_mask.is_s2s, ws["maskb"], B, L, ws["Lp"], out_t=want_t,
-                         region_mask=pt["rmask"] if (pt is not None and self.BLOCK_MASKED_REGION_KEYS) else None, Nv=Nv)
-        else:
-            if attention_mask is None:
-                attention_mask = torch.ones(B, L, dtype=torch.long, device=input_ids.device)
-            if attention_mask.dim() == 2:       # modeling.py:818-819
-                attention_mask = attention_mask[:, None, :].expand(B, L, L)
-            attention_mask = attention_mask.to(torch.long).contiguous()
-            K.mask_pack(attention_mask, ws["maskb"], B, L, ws["Lp"], out_t=want_t)
         vf = vis_feats.reshape(Mv, 2048)
         if vf.dtype == torch.float32:
             K.copy2d(vf.contiguous(), 2048, True, ws["img16"], 2048, Mv, 2048, 2048)
             img = ws["img16"]
         else:
             img = vf.contiguous()
-        if raw_regions:                     # raw boxes + class probabilities -> K-padded encoding (seq2seq_loader.py:338-351)
-            vis_pe.check(B, Nv)
-            K.vis_pe_prep(vis_pe.bbox, vis_pe.cls_prob.reshape(Mv, PE_DIM - 6), ws["vpe_in"], B, Nv, PE_DIM - 6, PE_PAD)
-        else:
-            vp = vis_pe.reshape(Mv, PE_DIM).contiguous()
-            K.copy2d(vp, PE_DIM, vp.dtype == torch.float32, ws["vpe_in"], PE_PAD, Mv, PE_DIM, PE_PAD)
         st.batch = (img, input_ids.contiguous(), token_type_ids.contiguous(), masked_pos)
 
-        # parameters written by a pipelined optimizer step become readable chunk by chunk (wait_params is a no-op otherwise)
+        def prep_pe():
+            # K-padded box / class encoding (operand of the third region GEMM) and the K-padded copy of its weight
+            if raw_regions:                     # raw boxes + class probabilities -> K-padded encoding (seq2seq_loader.py:338-351)
+                vis_pe.check(B, Nv)
+                K.vis_pe_prep(vis_pe.bbox, vis_pe.cls_prob.reshape(Mv, PE_DIM - 6), ws["vpe_in"], B, Nv, PE_DIM - 6, PE_PAD)
+            else:
+                vp = vis_pe.reshape(Mv, PE_DIM).contiguous()
+                K.copy2d(vp, PE_DIM, vp.dtype == torch.float32, ws["vpe_in"], PE_PAD, Mv, PE_DIM, PE_PAD)
+            # parameters written by a pipelined optimizer step become readable chunk by chunk (wait_params is a no-op otherwise)
+            # (reads a parameter of the embeddings bucket: AFTER the wait, or a pipelined step would project with last step's weight)
+            self.wait_params(len(self.buckets) - 1)             # region projections
+            K.copy2d(self.P("vis_pe_embed.0.weight"), PE_DIM, False, ws["wpe_pad"], PE_PAD, H, PE_DIM, PE_PAD)
+
+        def prep_mask(am):
+            if mask_spec:                       # per-sample lengths -> packed masks on the device (seq2seq_loader.py:292-301)
+                am.check(B, L)
+                # (BLOCK_MASKED_REGION_KEYS: opt-in, the reference's own loader leaves the masked regions' key columns attendable, see above)
+                K.mask_build(am.second_st, am.second_end, am.is_s2s, ws["maskb"], B, L, ws["Lp"], out_t=want_t,
+                             region_mask=pt["rmask"] if (pt is not None and self.BLOCK_MASKED_REGION_KEYS) else None, Nv=Nv)
+            else:
+                if am is None:
+                    am = torch.ones(B, L, dtype=torch.long, device=input_ids.device)
+                if am.dim() == 2:       # modeling.py:818-819
+                    am = am[:, None, :].expand(B, L, L)
+                am = am.to(torch.long).contiguous()
+                K.mask_pack(am, ws["maskb"], B, L, ws["Lp"], out_t=want_t)
+
+        # ---- side stream underneath the forward (training): (1) the K-padded box / class operand of the third region GEMM, (2) the packed
+        # attention masks (first read by layer 0's attention, ~190 us into the forward), (3) the W^T shadows of this step's dgrad GEMMs (the
+        # weights are final once the optimizer has stepped; 78 us, first read at the head of backward).  The main stream starts the region
+        # projections at once and waits for (1) / (2) where it first reads them.
+        self._shadow_ev = None
+        pe_ev = mask_ev = None
+        if (train or torch.is_grad_enabled()) and self.WGRAD_SIDE_STREAM and self.SHADOW_ON_SIDE:
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+                self._side_done = [None, None]
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                prep_pe()
+                pe_ev = torch.cuda.Event()
+                pe_ev.record(self._side)
+                prep_mask(attention_mask)
+                mask_ev = torch.cuda.Event()
+                mask_ev.record(self._side)
+                if self._params_done is not None:
+                    self._side.wait_event(self._params_done)        # the transposes read every weight matrix
+                if self._param_works is not None:
+                    # sharded optimizer step: the parameters arrive by per-bucket all-gathers that may still be in flight; the
+                    # transposes read EVERY weight matrix, so this stream waits for all of them (the main stream keeps waiting per
+                    # bucket where the forward first reads it -- Work.wait() may be called again there)
+                    for w in self._param_works.values():
+                        if w is not None:
+                            w.wait()
+                self._refresh_shadows()
+                self._shadow_ev = torch.cuda.Event()
+                self._shadow_ev.record(self._side)
+        else:
+            prep_mask(attention_mask)
+            prep_pe()
+
         self.wait_params("nodecay")
         self.wait_params(len(self.buckets) - 1)             # region projections
         self.wait_params(len(self.buckets) - 2)             # embedding tables
-        # (reads a parameter of the embeddings bucket: AFTER the waits, or a pipelined step would project with last step's weight)
-        K.copy2d(self.P("vis_pe_embed.0.weight"), PE_DIM, False, ws["wpe_pad"], PE_PAD, H, PE_DIM, PE_PAD)
         # ---- region projections (modeling.py:1003-1018,1035-1036) ---------------------------------
         self._nt(img, self.P("vis_embed.0.weight"), ws["h1"], Mv, 2048, 2048, bias=self.P("vis_embed.0.bias"), act=K.ACT_RELU)
         self._nt(ws["h1"], self.P("vis_embed.2.weight"), ws["vis_h"], Mv, H, 2048, bias=self.P("vis_embed.2.bias"), act=K.ACT_RELU,
                  dropout_p=p, seed=seed, rng_stream=1001)
+        if pe_ev is not None:
+            torch.cuda.current_stream().wait_event(pe_ev)
         self._nt(ws["vpe_in"], ws["wpe_pad"], ws["vispe_h"], Mv, H, PE_PAD, bias=self.P("vis_pe_embed.0.bias"), act=K.ACT_RELU,
                  dropout_p=p, seed=seed, rng_stream=1002)
         # ---- embeddings (modeling.py:217-241) ------------------------------------------------------
@@ -714,6 +736,8 @@ class Engine(object):
             a = ws["layers"][i]
             self.wait_params(NL - i)                            # bucket of layer i
             self._nt(x, self.P(Ln + "attention.self.query.weight"), a["qkv"], M, 3 * H, H, bias=self.P(Ln + "attention.self.query.bias"))
+            if i == 0 and mask_ev is not None:
+                torch.cuda.current_stream().wait_event(mask_ev)
             K.attn_fwd(a["qkv"], ws["maskb"], a["ctx"], a["lse"], B, L, A, scale, dropout_p=pa, seed=seed, rng_stream=16 * i + 1, row_off=ro)
             self._nt(a["ctx"], self.P(Ln + "attention.output.dense.weight"), a["pre1"], M, H, H, bias=self.P(Ln + "attention.output.dense.bias"),
                      residual=x, dropout_p=p, seed=seed, rng_stream=16 * i + 2, row_map=rm)
@@ -1316,17 +1340,18 @@ class Engine(object):
                     self._side_done[i & 1] = ev
             on_side(last_wgrad)
             self._nt(dqkv, s["qkvT"], dx, M, H, 3 * H, residual=dpre)
-        if use_side:
-            main.wait_stream(side)          # all layer wgrads (and their bucket hand-offs) precede the rest of backward
+        if use_side and not (grouped and self.TAIL_ON_SIDE):
+            main.wait_stream(side)          # all layer wgrads (and their bucket hand-offs) precede the rest of backward (split-M wgrads share tn_ws)
             self._side_busy = False
+        # (grouped wgrads + TAIL_ON_SIDE: the main stream does NOT wait here -- layer 0's weight gradients (170 us, issued a moment ago) and the
+        # embedding tables run on the side stream underneath the embedding / region-projection backward below, which touches none of their
+        # operands; the streams join once, at the end of backward)
         dpre = ws["dpre"]
 
         # ---- embeddings -------------------------------------------------------------------------------------
         K.layernorm_bwd(dx, ws["emb_pre"], self.P(E + "LayerNorm.weight"), ws["stat0"][0], ws["stat0"][1], dpre,
                         self.G(E + "LayerNorm.weight"), self.G(E + "LayerNorm.bias"), M, H, ln_slot(2 * NL), beta=beta, dy_drop=(p, seed, 1000),
                         defer_reduce=defer, row_map=rm)
-        if defer:      # dgamma / dbeta of the 2 * layers + 1 LayerNorms above: one launch (slot order = table order)
-            K.layernorm_bwd_reduce_batched(ws["ln_slots"], self._ln_table(), 2 * NL + 1, M, H, beta=beta)
         if rm is not None:
             # the embedding backward sums over (batch, position) in the dense [B, L] geometry (position table: a column of the batch;
             # word table: id chains in row order): hand it the dense gradient -- exact zeros on the dropped positions, as in the dense run
@@ -1334,11 +1359,29 @@ class Engine(object):
             dense.zero_()
             K.rows_unpack(dpre, rm, M, dense, H)
             dpre = dense
+
+        def tables_and_ln_params():
+            # the tail of backward that nothing on the main stream waits for: dgamma / dbeta of the 2 * layers + 1 LayerNorms (one launch,
+            # slot order = table order) and the three embedding tables (five launches); their gradient slice is announced from here
+            if defer:
+                K.layernorm_bwd_reduce_batched(ws["ln_slots"], self._ln_table(), 2 * NL + 1, M, H, beta=beta)
+            K.embed_bwd(dpre, input_ids, token_type_ids, ws["vis_h"], ws["vispe_h"], self.G(E + "word_embeddings.weight"),
+                        self.G(E + "position_embeddings.weight"), self.G(E + "token_type_embeddings.weight"), ws["d_vis_h"], ws["d_vispe_h"],
+                        ws["acc32"], B, L, Nv, H, V, cfg.type_vocab_size, drop_p=p, seed=seed, vis_stream=1001, vispe_stream=1002,
+                        region_mask=pt[0]["rmask"] if pt is not None else None, parts=2)
+            self._bucket_done(NL + 1)           # position / type / word embedding tables (tied decoder wgrad + embedding backward) are final
+
+        # region rows first (the region-projection dgrad / wgrads below wait for d_vis_h / d_vispe_h only); the tables and the LayerNorm
+        # parameter sums run on the side stream underneath them (round 5: six small launches, ~140 us, off the critical path)
         K.embed_bwd(dpre, input_ids, token_type_ids, ws["vis_h"], ws["vispe_h"], self.G(E + "word_embeddings.weight"),
                     self.G(E + "position_embeddings.weight"), self.G(E + "token_type_embeddings.weight"), ws["d_vis_h"], ws["d_vispe_h"],
                     ws["acc32"], B, L, Nv, H, V, cfg.type_vocab_size, drop_p=p, seed=seed, vis_stream=1001, vispe_stream=1002,
-                    region_mask=pt[0]["rmask"] if pt is not None else None)
-        self._bucket_done(NL + 1)           # position / type / word embedding tables (tied decoder wgrad + embedding backward) are final
+                    region_mask=pt[0]["rmask"] if pt is not None else None, parts=1)
+        if use_side and self.TAIL_ON_SIDE:
+            self._side_busy = True
+            on_side(tables_and_ln_params)
+        else:
+            tables_and_ln_params()
         # vis_pe_embed: Linear(1607, H) -- wgrad into the padded shadow, then crop-accumulate
         # vis_embed: Linear(2048,2048)+ReLU -> Linear(2048,H)+ReLU+Dropout
         self._nt(ws["d_vis_h"], sh["v2T"], ws["dz1v"], Mv, 2048, H, mul_src=ws["h1"], mul_mode=K.MUL_RELU_MASK)
@@ -1355,6 +1398,9 @@ class Engine(object):
         K.copy2d(ws["dwpe_pad"], PE_PAD, False, self.G("vis_pe_embed.0.weight"), PE_DIM, H, PE_DIM, PE_DIM, beta=beta)
         K.colsum(ws["d_vispe_h"], self.G("vis_pe_embed.0.bias"), Mv, H, beta=beta, workspace=ws["cs_ws"])
         self._bucket_done(NL + 2)
+        if use_side and self._side_busy:
+            main.wait_stream(side)
+            self._side_busy = False
         self.grad_norm_slices_valid = self.grad_ready_hook is None and self.NORM_PER_SLICE
         self.grads_dirty = True
         if self.post_backward_hook is not None:
