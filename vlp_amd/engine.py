@@ -354,6 +354,7 @@ class Engine(object):
                        for _ in range(2)]
         tn_bytes = max(K.gemm_tn_workspace_bytes(M, I, H), K.gemm_tn_workspace_bytes(Mv, 2048, 2048), K.gemm_tn_workspace_bytes(M, 3 * H, H))
         ws["tn_ws"] = torch.empty(tn_bytes, device=dev, dtype=torch.uint8)
+        ws["tn_ws_main"] = torch.empty(max(K.gemm_tn_workspace_bytes(V, _ru(B * max(P, 1), 64), H), 1 << 20), device=dev, dtype=torch.uint8)
         ws["cs_ws"] = torch.empty(max(K.colsum_workspace_bytes(M, I), K.colsum_workspace_bytes(B * max(P, 1), Vp)), device=dev, dtype=torch.uint8)
         ws["ln_ws"] = torch.empty(K.layernorm_bwd_workspace_bytes(max(H, 8)), device=dev, dtype=torch.uint8)
         # one private partials slot per encoder / embedding LayerNorm: their dgamma / dbeta second stages run as ONE launch at the
@@ -1145,10 +1146,11 @@ class Engine(object):
         tuning.remember("tn", M, N, Kd, best)
         return best
 
-    def _tn(self, a, b, c, M, N, Kd, ws, beta, bias=None, **kw):
-        """wgrad GEMM; `bias` (the Linear's bias gradient = column sums of dY) is fused into the same launch."""
+    def _tn(self, a, b, c, M, N, Kd, ws, beta, bias=None, ws_key="tn_ws", **kw):
+        """wgrad GEMM; `bias` (the Linear's bias gradient = column sums of dY) is fused into the same launch.  ws_key: the split-M scratch
+        (launches on the side stream share "tn_ws"; the one TN launch of the main stream's head dgrad has its own)."""
         var, sp = self._tn_splits(a, b, c, M, N, Kd, ws)
-        K.gemm_tn(a, b, c, M, N, Kd, beta=beta, workspace=ws["tn_ws"], variant=var, bias_out=bias, splits=sp, **kw)
+        K.gemm_tn(a, b, c, M, N, Kd, beta=beta, workspace=ws[ws_key], variant=var, bias_out=bias, splits=sp, **kw)
 
     def _bucket_done(self, idx):
         if self.grad_ready_hook is not None:
@@ -1197,6 +1199,27 @@ class Engine(object):
             self.G(E + "position_embeddings.weight").zero_()
             self.G(E + "token_type_embeddings.weight").zero_()
 
+        main = torch.cuda.current_stream()
+        use_side = self.WGRAD_SIDE_STREAM
+        if use_side and self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._side_done = [None, None]
+        if use_side and getattr(self, "_side_done", None) is None:
+            self._side_done = [None, None]
+        side = self._side if use_side else None
+
+        def on_side(fn):
+            if not use_side:
+                fn()
+                return
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                fn()
+
+        if use_side:
+            self._side_busy = True
+        head_wgrads = []        # weight gradients of the task head: issued on the side stream once the head's dgrad chain is on the main stream
+
         # ---- heads ------------------------------------------------------------------------------------
         if task == "vqa2":
             NA, NAp = model.num_answers, ws["NAp"]
@@ -1218,17 +1241,17 @@ class Engine(object):
             R, Vp = B * P, ws["Vp"]
             K.mlm_loss_bwd(ws["logits"], Vp, st_labels(st), ws["lse_ce"], ws["coef"], gscale, ws["dlogits"], Vp, R, V)
             # tied decoder (modeling.py:445-448): dE[V,H] = dlogits^T . t ; the embedding scatter adds to it later
-            self._tn(ws["dlogits"], ws["tln"], self.G(E + "word_embeddings.weight"), R, V, H, ws, beta, bias=self.G(C + "bias"))
+            head_wgrads.append(lambda: self._tn(ws["dlogits"], ws["tln"], self.G(E + "word_embeddings.weight"), R, V, H, ws, beta, bias=self.G(C + "bias")))
             # dgrad through the tied decoder: dt[R,H] = dlogits[R,V] . E[V,H].  As an NT GEMM this is 12 workgroups walking
             # K = 29056; instead transpose dlogits (11 MB) and contract over the vocabulary rows with the split-M wgrad kernel,
             # reading E in place (no E^T shadow).
             Rp = _ru(R, 64)
             K.transpose(ws["dlogits"], Vp, ws["dlT"], Rp, R, Vp, Rp)
-            self._tn(ws["dlT"], self.P(E + "word_embeddings.weight"), ws["dtln"], V, R, H, ws, 0)
+            self._tn(ws["dlT"], self.P(E + "word_embeddings.weight"), ws["dtln"], V, R, H, ws, 0, ws_key="tn_ws_main")
             K.layernorm_bwd(ws["dtln"], ws["tg"], self.P(C + "transform.LayerNorm.weight"), ws["tstat"][0], ws["tstat"][1], ws["dtg"],
                             self.G(C + "transform.LayerNorm.weight"), self.G(C + "transform.LayerNorm.bias"), R, H, ws["ln_ws"], beta=beta)
             K.gelu_bwd(ws["dtg"], ws["tz"], ws["dtz"], R * H)
-            self._tn(ws["dtz"], ws["sel"], self.G(C + "transform.dense.weight"), R, H, H, ws, beta, bias=self.G(C + "transform.dense.bias"))
+            head_wgrads.append(lambda: self._tn(ws["dtz"], ws["sel"], self.G(C + "transform.dense.weight"), R, H, H, ws, beta, bias=self.G(C + "transform.dense.bias")))
             self._nt(ws["dtz"], sh["tT"], ws["dsel"], R, H, H)
             K.scatter_add_rows(ws["dsel"], H, masked_pos.contiguous(), dx, H, B, P, L, H, row_off=ro)
         pt = st.pretext
@@ -1248,7 +1271,15 @@ class Engine(object):
             self.G("bert.pooler.dense.weight").zero_()           # a previous pretext step left gradients there; unused now
             self.G("bert.pooler.dense.bias").zero_()
         self._pooler_dirty = pt is not None
-        self._bucket_done(0)
+
+        def head_tail():
+            for fn in head_wgrads:
+                fn()
+            self._bucket_done(0)
+        if self.TAIL_ON_SIDE:
+            on_side(head_tail)      # (the side stream is ordered behind everything the main stream has issued so far)
+        else:
+            head_tail()
 
         # ---- encoder layers, last to first ----------------------------------------------------------------
         # The dgrad chain (LN-bwd -> dgrad GEMMs -> attention-bwd) is the critical path; the four weight-gradient GEMMs of a
@@ -1257,26 +1288,6 @@ class Engine(object):
         # main stream waits for the side stream's event before it reuses a set.
         dctx = ws["dctx"]
         scale = 1.0 / math.sqrt(H // A)
-        main = torch.cuda.current_stream()
-        use_side = self.WGRAD_SIDE_STREAM
-        if use_side and self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-            self._side_done = [None, None]
-        if use_side and getattr(self, "_side_done", None) is None:
-            self._side_done = [None, None]
-        side = self._side if use_side else None
-
-        def on_side(fn):
-            if not use_side:
-                fn()
-                return
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                fn()
-
-        if use_side:
-            side.wait_stream(main)          # head wgrads above ran on main; order the side stream after them (tn_ws reuse)
-            self._side_busy = True
         slot_bytes = ws["ln_slot_bytes"]
         defer = self.LN_DEFER
 
