@@ -499,13 +499,6 @@ int vlp_sumsq(const void* g_f16, int64_t n, float* out2, float* partial, void* s
  * sums over the chunks a rank owns; launches of one stream run in order, so the total is reproducible. */
 int vlp_sumsq_acc(const void* g_f16, int64_t n, float* out2, float* partial, void* stream);
 
-/* ABI 4: the same norm accumulated slice by slice while backward runs.  vlp_sumsq_partial writes the block partials of one gradient
- * slice into its slot (vlp_sumsq_partial_floats() floats: sums, then flags); vlp_sumsq_combine adds `slots` consecutive slots up in a
- * fixed order -> out2 = {sum(g^2), overflow flag} over all of them.  Bitwise reproducible; replaces one vlp_sumsq over the whole buffer. */
-int64_t vlp_sumsq_partial_floats(void);
-int vlp_sumsq_partial(const void* g_f16, int64_t n, float* partial, void* stream);
-int vlp_sumsq_combine(const float* partials, int32_t slots, float* out2, void* stream);
-
 /* apex fused_adam_cuda.adam as called by FusedAdam.step (run_img2txt_dist.py:411-420):
  *   g = g16 / (*combined_scale); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
  *   denom = eps_inside_sqrt ? sqrt(v + eps) : sqrt(v) + eps;

@@ -422,50 +422,3 @@ def test_bench_world2_on_one_gpu_real_engine_ddp_hooks(mode):
     if "rs_ag" in _WORLD2_CHECKSUMS and "sharded" in _WORLD2_CHECKSUMS:
         for a, b in zip(_WORLD2_CHECKSUMS["rs_ag"], _WORLD2_CHECKSUMS["sharded"]):
             assert abs(a - b) <= 1e-6 * abs(a) + 1e-3, _WORLD2_CHECKSUMS
-
-
-def test_grad_norm_accumulated_per_slice_equals_the_whole_buffer_pass():
-    """Engine.NORM_PER_SLICE: the decay group's sum(g^2) is accumulated slice by slice during backward (vlp_sumsq_partial per finished
-    gradient slice, vlp_sumsq_combine in the step) -- the same number as one vlp_sumsq over the whole buffer up to fp32 summation order,
-    the same overflow flag, bitwise repeatable, and the step that uses it equals the whole-buffer step."""
-    from vlp_amd import _lib as K
-    model, _ = small_model(drop=0.1)
-    model.train()
-    eng = model.engine
-    eng.NORM_PER_SLICE = True            # (opt-in: VLP_NORM_PER_SLICE=1)
-    opt = FP16_Optimizer_State(FusedAdam(groups_of(model), lr=1e-3, bias_correction=False, max_grad_norm=1.0), dynamic_loss_scale=True,
-                               dynamic_loss_args={"init_scale": 2.0 ** 10})
-    batch = S.batch_to(S.make_batch(4, max_len_b=20, vocab_size=1024, max_pred=3, seed=1), DEV, half=True)
-    fwd_bwd(model, opt, batch)
-    assert eng.grad_norm_slices_valid and eng._gn_slots.shape[0] == len(eng.buckets)
-    covered = sorted(eng.buckets)
-    assert covered[0][0] == 0 and covered[-1][1] == eng.sizes["decay"] and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
-    got, got2, whole = torch.zeros(2, device=DEV), torch.zeros(2, device=DEV), torch.zeros(2, device=DEV)
-    K.sumsq_combine(eng._gn_slots, len(eng.buckets), got)
-    K.sumsq_combine(eng._gn_slots, len(eng.buckets), got2)
-    K.sumsq(eng.gflat["decay"], eng.sizes["decay"], whole, torch.zeros(2048, device=DEV))
-    ref = float((eng.gflat["decay"].double() ** 2).sum())
-    assert torch.equal(got, got2) and float(got[1]) == 0.0 and float(whole[1]) == 0.0
-    assert abs(float(got[0]) - ref) <= 2e-6 * ref and abs(float(whole[0]) - ref) <= 2e-6 * ref
-    # an inf in ONE slice raises the flag through the slots
-    lo, hi = eng.buckets[3]
-    eng.gflat["decay"][lo + 5] = float("inf")
-    K.sumsq_partial(eng.gflat["decay"][lo:hi], hi - lo, eng._gn_slots[3])
-    K.sumsq_combine(eng._gn_slots, len(eng.buckets), got)
-    assert float(got[1]) == 1.0
-    # the step: per-slice norm vs whole-buffer norm on two identical models / batches
-    res = []
-    for per_slice in (True, False):
-        m2, _ = small_model(drop=0.1)
-        m2.train()
-        m2.engine.NORM_PER_SLICE = per_slice
-        o2 = FP16_Optimizer_State(FusedAdam(groups_of(m2), lr=1e-3, bias_correction=False, max_grad_norm=1.0), dynamic_loss_scale=True,
-                                  dynamic_loss_args={"init_scale": 2.0 ** 10})
-        fwd_bwd(m2, o2, batch)
-        assert m2.engine.grad_norm_slices_valid == per_slice
-        o2.step()
-        torch.cuda.synchronize()
-        assert not o2.overflow
-        res.append([t.clone() for t in o2.fp32_groups_flat])
-    for a, b in zip(*res):
-        assert float((a - b).abs().max()) <= 1e-7 + 1e-6 * float(a.abs().max())      # the clip factor differs by an ulp at most

@@ -191,9 +191,6 @@ SYMBOLS = {
     "vlp_bce_loss_bwd": (C.c_int, [vp, i64, vp, i64, i32, i32, vp, vp, i64, vp]),
     "vlp_sumsq": (C.c_int, [vp, i64, vp, vp, vp]),
     "vlp_sumsq_acc": (C.c_int, [vp, i64, vp, vp, vp]),
-    "vlp_sumsq_partial_floats": (i64, []),
-    "vlp_sumsq_partial": (C.c_int, [vp, i64, vp, vp]),
-    "vlp_sumsq_combine": (C.c_int, [vp, i32, vp, vp]),
     "vlp_fused_adam": (C.c_int, [C.POINTER(FusedAdamArgs), vp]),
     "vlp_adam_hyper": (C.c_int, [vp, vp, vp, f32, f32, vp, vp]),
     "vlp_loss_scale_update": (C.c_int, [vp, vp, vp]),
@@ -652,20 +649,6 @@ def adam_hyper(sumsq2, any_overflow, scale_state, max_grad_norm, step_size, hype
 def loss_scale_update(scale_state, overflow):
     _req_cuda(scale_state, overflow)
     _check(load().vlp_loss_scale_update(ptr(scale_state), ptr(overflow), stream_ptr()))
-
-
-def sumsq_partial_floats():
-    return int(load().vlp_sumsq_partial_floats())
-
-
-def sumsq_partial(g, n, partial):
-    _req_cuda(g, partial)
-    _check(load().vlp_sumsq_partial(ptr(g), n, ptr(partial), stream_ptr()))
-
-
-def sumsq_combine(partials, slots, out2):
-    _req_cuda(partials, out2)
-    _check(load().vlp_sumsq_combine(ptr(partials), slots, ptr(out2), stream_ptr()))
 
 
 def fused_adam(p32, m, v, g16, p16, n, hyper, b1=0.9, b2=0.999, eps=1e-8, decay=0.0, eps_inside_sqrt=False):

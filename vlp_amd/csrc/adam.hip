@@ -77,81 +77,6 @@ static int sumsq_launch(const void* g, int64_t n, float* out2, float* partial, i
     return VLP_OK;
 }
 
-// Gradient norm accumulated WHILE backward runs (round 5): the engine hands every finished gradient slice (one per DDP bucket boundary:
-// task head, each layer, embedding tables, region projections) to vlp_sumsq_partial on the stream that produced it -- the slice is
-// still in L2 / the Infinity Cache and the launch overlaps the dgrad chain -- and the optimizer step adds the slices' block partials up
-// in slot order with ONE vlp_sumsq_combine launch instead of re-reading all 232 MB of gradients (vlp_sumsq: 53 us on the critical path).
-// Fixed block count per slice, fixed order everywhere: bitwise reproducible.
-#define SQP_BLOCKS 128
-__global__ __launch_bounds__(256) void sumsq_partial_kernel(const f16* __restrict__ g, int64_t n, float* __restrict__ partial) {
-    __shared__ float sh[4], shb[4];
-    float s = 0.f, bad = 0.f;
-    const int64_t n8 = n >> 3;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
-        f16x8 v = ld8(g + i * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float f = (float)v[e];
-            s += f * f;
-            if (!(fabsf(f) <= 65504.f)) bad = 1.f;
-        }
-    }
-    if (blockIdx.x == 0)
-        for (int64_t i = n8 * 8 + threadIdx.x; i < n; i += blockDim.x) {
-            const float f = (float)g[i];
-            s += f * f;
-            if (!(fabsf(f) <= 65504.f)) bad = 1.f;
-        }
-    s = wave_sum(s);
-    bad = wave_max(bad);
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    if (l == 0) { sh[w] = s; shb[w] = bad; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
-        partial[SQP_BLOCKS + blockIdx.x] = fmaxf(fmaxf(shb[0], shb[1]), fmaxf(shb[2], shb[3]));
-    }
-}
-extern "C" int64_t vlp_sumsq_partial_floats(void) { return 2 * SQP_BLOCKS; }
-extern "C" int vlp_sumsq_partial(const void* g, int64_t n, float* partial, void* stream) {
-    VLP_CHECK_ARG(g && partial && n > 0 && (uintptr_t)g % 16 == 0, "vlp_sumsq_partial: bad args (partial holds vlp_sumsq_partial_floats() floats)");
-    VLP_ENTER(g, "vlp_sumsq_partial");
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SQP_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const f16*)g, n, partial);
-    VLP_CHECK_LAUNCH("vlp_sumsq_partial");
-    return VLP_OK;
-}
-// out2 = (sum, flag) over `slots` consecutive partial blocks, added in slot order then block order by ONE thread block (slots * 128 adds)
-__global__ __launch_bounds__(256) void sumsq_combine_kernel(const float* __restrict__ partials, int slots, float* __restrict__ out2) {
-    __shared__ float sh[256], shb[256];
-    float s = 0.f, bad = 0.f;
-    // thread t owns block t % 128 of the slots t / 128, t / 128 + 2, ...: a fixed assignment; the tree below is fixed too
-    for (int sl = threadIdx.x / SQP_BLOCKS; sl < slots; sl += 256 / SQP_BLOCKS) {
-        const float* p = partials + (int64_t)sl * 2 * SQP_BLOCKS;
-        s += p[threadIdx.x % SQP_BLOCKS];
-        bad = fmaxf(bad, p[SQP_BLOCKS + threadIdx.x % SQP_BLOCKS]);
-    }
-    sh[threadIdx.x] = s;
-    shb[threadIdx.x] = bad;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) { sh[threadIdx.x] += sh[threadIdx.x + o]; shb[threadIdx.x] = fmaxf(shb[threadIdx.x], shb[threadIdx.x + o]); }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        float b = shb[0];
-        if (!(sh[0] <= 3.0e38f)) b = 1.f;
-        out2[0] = sh[0];
-        out2[1] = b;
-    }
-}
-extern "C" int vlp_sumsq_combine(const float* partials, int32_t slots, float* out2, void* stream) {
-    VLP_CHECK_ARG(partials && out2 && slots > 0, "vlp_sumsq_combine: bad args");
-    VLP_ENTER(partials, "vlp_sumsq_combine");
-    hipLaunchKernelGGL(sumsq_combine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, slots, out2);
-    VLP_CHECK_LAUNCH("vlp_sumsq_combine");
-    return VLP_OK;
-}
-
 __global__ void adam_hyper_kernel(const float* sumsq2, const float* any_overflow, const float* scale_state, float max_grad_norm, float step_size,
                                   float* hyper) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;

@@ -74,12 +74,10 @@ class Engine(object):
     # row_off; dropout hashes keep the logical (b*L + l, col) element, so masks -- and with them losses, logits and gradients --
     # equal the dense run's up to the fp32 summation order of the weight-gradient / LayerNorm-parameter sums.
     VARLEN = os.environ.get("VLP_VARLEN", "0") == "1"
-    # gradient norm of the decay group accumulated slice by slice while backward runs (vlp_sumsq_partial on the stream that produced the
-    # slice) instead of one pass over all 232 MB in front of the optimizer step; single-process runs only -- under DDP a slice is final
-    # only after its collective.  OPT-IN (VLP_NORM_PER_SLICE=1): measured in the step on one box it LOSES, 9.738 / 9.722 against 9.666 / 9.671
-    # ms/step (profiles/r05_instep_ab_norm_per_slice.txt) -- fifteen more launches on the side stream cost the co-running dgrad chain more
-    # than the 53 us pass over the gradients they replace.  Default: one vlp_sumsq over the whole buffer in front of the optimizer step.
-    NORM_PER_SLICE = os.environ.get("VLP_NORM_PER_SLICE", "0") == "1"
+    # (Round 5, measured and NOT kept -- the gradient norm in front of the optimizer step stays one vlp_sumsq pass over the buffer, 53 us:
+    # one partial-sum launch per finished gradient slice on the side stream during backward LOSES, 9.738 / 9.722 vs 9.666 / 9.671 ms/step;
+    # summing the 93 % of the buffer that is final when the side stream reaches the embedding tables, under the region-projection backward,
+    # is a wash, 9.568 / 9.548 vs 9.558 / 9.573 -- profiles/r05_instep_ab_norm_per_slice.txt.  Both forms were removed.)
     GROUPED_WGRAD = os.environ.get("VLP_GROUPED_WGRAD", "1") == "1"     # one vlp_gemm_tn_grouped launch per layer instead of 4 split-M wgrads + 4 reduces
     TN_SPLITS = None         # None -> vlp_amd.tuning (variant flags, split-M factor) per (M, N, K)
     # split-M factor: the wgrad outputs are small (36..144 tiles of 128x128) and the contraction long (M = 10 688), so the
@@ -115,8 +113,6 @@ class Engine(object):
         self._side = None                 # second HIP stream for the layer wgrads (created on first use)
         self._side_busy = False           # True while backward may have work queued on it
         self._prof_ctr = 0
-        self._gn_slots = None             # f32 [slices, vlp_sumsq_partial_floats()]: block partials of sum(g^2) per gradient slice (NORM_PER_SLICE)
-        self.grad_norm_slices_valid = False   # True after a backward that filled every slot for the CURRENT contents of the gradient buffer
         self.varlen = self.VARLEN         # padding-free (packed) training step, see VARLEN
         self._pk_cache = {}               # kept-length tuple -> (row_off, row_map device tensors, M'): batches repeat in bench / epochs
         self._pk_lens = {}                # id(mask tensor) -> (weakref, version, ..., lens): lengths derived from a dense mask, once per tensor
@@ -1155,12 +1151,6 @@ class Engine(object):
     def _bucket_done(self, idx):
         if self.grad_ready_hook is not None:
             self.grad_ready_hook(idx)
-        elif self.NORM_PER_SLICE:
-            # slice idx of the decay gradient is final in this stream's order: its share of the gradient norm, while the lines are hot
-            if self._gn_slots is None:
-                self._gn_slots = torch.zeros(len(self.buckets), K.sumsq_partial_floats(), device=self.device, dtype=torch.float32)
-            lo, hi = self.buckets[idx]
-            K.sumsq_partial(self.gflat["decay"][lo:hi], hi - lo, self._gn_slots[idx])
 
     def backward(self, st, gscale, task, g_pretext=None):
         """gscale: device f32 tensor [1] = upstream gradient of the task loss (x loss scale); g_pretext: the same for the pretext loss of
@@ -1182,7 +1172,6 @@ class Engine(object):
             raise RuntimeError("vlp_amd: VLP_DDP_MODE=sharded keeps only this rank's chunk of the reduced gradient, so gradients cannot be "
                                "accumulated over several backward passes (--gradient_accumulation_steps > 1); use allreduce or rs_ag")
         img, input_ids, token_type_ids, masked_pos = st.batch
-        self.grad_norm_slices_valid = False
         self.wait_params()           # the optimizer stream has read the previous gradients and written every parameter
         if getattr(self, "_shadow_ev", None) is not None:
             torch.cuda.current_stream().wait_event(self._shadow_ev)     # transposed during the forward (side stream)
@@ -1412,7 +1401,6 @@ class Engine(object):
         if use_side and self._side_busy:
             main.wait_stream(side)
             self._side_busy = False
-        self.grad_norm_slices_valid = self.grad_ready_hook is None and self.NORM_PER_SLICE
         self.grads_dirty = True
         if self.post_backward_hook is not None:
             self.post_backward_hook()

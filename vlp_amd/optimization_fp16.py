@@ -244,14 +244,10 @@ class FP16_Optimizer_State(object):
         K.loss_scale_update(self._scale_state, self._ovf)
 
     def _grad_norms(self):
-        """(sum of squares, overflow flag) of every param group's gradient -> self._sumsq[i].  The decay group's was accumulated slice by
-        slice during backward when the engine says so (Engine.NORM_PER_SLICE: one combine launch here instead of a pass over 232 MB)."""
+        """(sum of squares, overflow flag) of every param group's gradient -> self._sumsq[i]: apex FP16_Optimizer's overflow check + norm."""
         eng = self.engine
         for i, key in enumerate(self._group_key):
-            if key == "decay" and getattr(eng, "grad_norm_slices_valid", False):
-                K.sumsq_combine(eng._gn_slots, len(eng.buckets), self._sumsq[i])
-            else:
-                K.sumsq(eng.gflat[key], eng.sizes[key], self._sumsq[i], self._partial)
+            K.sumsq(eng.gflat[key], eng.sizes[key], self._sumsq[i], self._partial)
 
     def _step_size(self, g):
         if g["bias_correction"]:
