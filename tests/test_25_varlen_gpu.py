@@ -273,3 +273,36 @@ def test_eval_and_no_grad_forwards_stay_dense():
     with torch.no_grad():
         model(b.img, b.vis_pe, b.input_ids, b.segment_ids, b.input_mask, vqa_inference=True)
     assert model.engine.last_packed_rows is None
+
+
+@pytest.mark.skipif(not K.lab_build(), reason="investigation kernel: needs a -DVLP_LAB_BUILD library (python -m vlp_amd.build --lab, VLP_HIP_LIB=...)")
+@pytest.mark.parametrize("B,L,packed,drop", [(64, 167, False, 0.1), (64, 167, True, 0.1), (130, 150, False, 0.0), (3, 192, False, 0.1), (30, 129, True, 0.0)])
+def test_attention_forward_streaming_kernel_equals_the_per_item_kernel(B, L, packed, drop, monkeypatch):
+    """The persistent streaming forward (one 12-wave workgroup per CU, K / V of the next item prefetched through three LDS buffers, tiles
+    handed out by an LDS counter; 129 <= L <= 192) runs the same tile code as the one-workgroup-per-(batch, head) kernel: context rows and
+    lse must be BIT-equal -- with several items per workgroup (B x heads > CUs: buffers reused), a grid smaller than the CU count, packed
+    rows, dropout on and off."""
+    A, H, Nv = 12, 768, 100
+    rng = np.random.RandomState(B + L)
+    nb = rng.randint(1, L - Nv - 2, size=B)
+    nb[0] = L - Nv - 3
+    modes = [bool(rng.rand() < 0.7) for _ in range(B)]
+    spec = MaskSpec.from_lengths(Nv, nb.tolist(), modes, device=DEV)
+    Lp = (L + 31) // 32 * 32
+    maskb = torch.empty(B, L, Lp, dtype=torch.uint8, device=DEV)
+    K.mask_build(spec.second_st, spec.second_end, spec.is_s2s, maskb, B, L, Lp)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    if packed:
+        row_off, row_map, M = packing(spec.lens_host, L)
+    else:
+        row_off, M = None, B * L
+    qkv = (torch.randn(M, 3 * H, device=DEV, generator=g) * 0.7).half()
+    outs = []
+    for stream in ("0", "1"):
+        monkeypatch.setenv("VLP_ATTN_FWD_STREAM", stream)
+        ctx, lse = torch.zeros(M, H, device=DEV, dtype=torch.float16), torch.zeros(B, A, L, device=DEV)
+        for _ in range(2):          # twice: no state is left behind
+            K.attn_fwd(qkv, maskb, ctx, lse, B, L, A, 0.125, dropout_p=drop, seed=3, rng_stream=9, row_off=row_off)
+        outs.append((ctx, lse))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[1][0].float().abs().max()) > 0

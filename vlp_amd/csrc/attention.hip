@@ -175,6 +175,156 @@ DEVFN void mask4w(uint32_t w, bool full, float c0, float out[4]) {
 // NW = waves per workgroup.  8 for most shapes; 4 at NT = 12 (129 <= L <= 192, the training shape L = 167): B x heads = 768 workgroups
 // on 256 CUs is 1.5 rounds of the 2 x 8-wave workgroups a CU holds -- with 4-wave workgroups three fit (3 x 48 KB LDS, 12 waves), all 768
 // are resident at once, and the 11 query tiles of L = 167 spread over 4 waves (3 passes, 92 % busy) instead of 8 (2 passes, 69 %).
+// One 16-query tile of the forward: S^T = K Q^T over the live key tiles, log2-domain softmax with the byte mask, dropout, O^T = V^T P^T,
+// context rows + lse stored.  Shared by the one-workgroup-per-(batch, head) kernel below and the persistent streaming kernel: the tile code
+// is the same, so both produce the same bits.  Ks / Vs: the head's K and V rows in LDS (row-major, chunk-swizzled); rows >= the staged
+// count are zero.  `first`: the wave's first tile of the launch (phase trace only).
+template <int NT>
+DEVFN void attn_fwd_tile(const AttnParams& p, const f16* Ks, const f16* Vs, const f16* qbase, int b, int h, int L, int Lq, int nq, int64_t rbo,
+                         int qt, int g, int li, int wid, int lane, bool first) {
+    (void)wid; (void)lane;
+    const int q = qt * 16 + li;             // this lane's query (column of every transposed tile)
+    const int qc = min(q, nq - 1);
+    int gq = g;                             // opaque copy: keeps per-key index math inside the loop (no LICM + spills)
+    asm volatile("" : "+v"(gq));
+    const f16* qrow = qbase + (int64_t)qc * p.ld_q;
+    f16x8 qf[2];
+    qf[0] = ld8(qrow + g * 8);
+    qf[1] = ld8(qrow + 32 + g * 8);
+
+    // mask words of this query for all key tiles: independent loads issued before the MFMAs (one L2 round trip, not NT)
+    const uint8_t* mrow = p.mask + ((int64_t)b * Lq + qc) * p.Lp;
+    constexpr bool PRELOAD = NT <= 12;           // L > 192: the words would push the kernel into spills -- fetch them per tile there
+    uint32_t mw[PRELOAD ? NT : 1];
+    if (PRELOAD) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) mw[t] = mask_word(mrow, t * 16 + 4 * gq, p.Lp);
+    }
+    if (first) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TRACE(3); }      // first tile: Q + mask words have arrived
+    // key tiles that are dead for ALL 16 queries of this wave's tile (bit t clear); only when every query row has an attended key
+    uint32_t live = 0xffffffffu;
+    if (PRELOAD && p.skip) {
+        uint32_t any1 = 0u;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) any1 |= mw[PRELOAD ? t : 0] & 0x01010101u;
+        int rowlive = any1 != 0u;
+        rowlive |= __shfl_xor(rowlive, 16, 64);
+        rowlive |= __shfl_xor(rowlive, 32, 64);
+        if (__all(rowlive)) {
+            live = 0u;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) live |= (__any(ANY_ATTEND(mw[PRELOAD ? t : 0])) ? 1u : 0u) << t;
+        }
+        live = __builtin_amdgcn_readfirstlane(live);
+    }
+    // S^T tiles: rows = keys 16t + 4g + reg, col = query.  Groups of 4 key tiles: one scalar branch per group (a branch per tile
+    // makes every tile its own basic block: two LDS reads, a full lgkmcnt wait, two dependent MFMAs -- ~500 cycles per tile in the
+    // trace); inside a group the 8 fragment reads are issued together and the 8 MFMAs follow.
+    f32x4 s[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += 4) {
+        if (!((live >> t0) & 15u)) continue;
+        f16x8 kf[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kr = (t0 + j) * 16 + li;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) kf[j][ks] = ld8(Ks + kr * HD + (((ks * 4 + g) ^ swzk(kr)) << 3));
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[t0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[j][ks], qf[ks], s[t0 + j], 0, 0, 0);
+    }
+    if (first) TRACE(4);       // S MFMAs issued
+    // scores in the log2 domain: s2 = s * scale * log2(e) + mask term; softmax = exp2(s2 - max) / sum
+    const float sc2 = p.scale * LOG2E_F;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (!((live >> t) & 1u)) continue;
+        float ma[4];
+        mask4w(PRELOAD ? mw[PRELOAD ? t : 0] : mask_word(mrow, t * 16 + 4 * gq, p.Lp), t * 16 + 16 <= L, -MASK_C1, ma);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s[t][r] = fmaf(s[t][r], sc2, ma[r]);
+            mx = fmaxf(mx, s[t][r]);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (!((live >> t) & 1u)) continue;            // dead tile: s[t] stays 0 = the exact value of its probabilities
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - mx);
+            sum += s[t][r];
+        }
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    // the normalisation and the dropout scale 1/(1-p) are applied to the 16 outputs of the lane instead of its 4*NT probabilities
+    const float inv = p.drop.scale / sum;
+    if (p.lse && g == 0 && q < nq) p.lse[((int64_t)b * p.heads + h) * Lq + q] = (mx + __builtin_amdgcn_logf(sum)) * LN2_F;
+
+    // P^T (UNnormalised exp2 values in (0, 1], dropped entries zeroed) as fp16 B-operand fragments: pair u = tiles (2u, 2u+1)
+    uint32_t pfw[NT / 2][4];                 // pair u = tiles (2u, 2u+1); words 2hh, 2hh+1 = the four probabilities of tile 2u+hh
+    // dropout element = (row (b, h, q), col key)
+    const uint32_t rk = p.drop.thresh ? drop_rowkey(p.drop, ((uint64_t)b * p.heads + h) * (uint64_t)Lq + (uint64_t)qc) : 0u;
+    // columns (keys) of tile t held by this lane: 16t + 4g + {0..3} = two hash pairs; pair key advances by 8*PHI per tile
+    const uint32_t pk0 = drop_pairkey(rk, (uint32_t)(4 * gq));
+#pragma unroll
+    for (int u = 0; u < NT / 2; ++u)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int t = 2 * u + hh;
+            if (!((live >> t) & 1u)) {
+                pfw[u][2 * hh] = 0u;
+                pfw[u][2 * hh + 1] = 0u;
+                continue;
+            }
+            float p0 = s[t][0], p1 = s[t][1], p2 = s[t][2], p3 = s[t][3];
+            if (p.drop.thresh) {
+                const uint32_t h0 = mix32(pk0 + (uint32_t)(8 * t) * VLP_PHI), h1 = mix32(pk0 + (uint32_t)(8 * t + 1) * VLP_PHI);
+                p0 = ((h0 & 0xffffu) < p.drop.thresh) ? 0.f : p0;
+                p1 = ((h0 >> 16) < p.drop.thresh) ? 0.f : p1;
+                p2 = ((h1 & 0xffffu) < p.drop.thresh) ? 0.f : p2;
+                p3 = ((h1 >> 16) < p.drop.thresh) ? 0.f : p3;
+            }
+            pfw[u][2 * hh] = pack_f16x2(p0, p1);
+            pfw[u][2 * hh + 1] = pack_f16x2(p2, p3);
+        }
+
+    if (first) TRACE(5);       // softmax + P fragments done
+    // O^T tiles: rows = head-dim 16n + 4g + reg, col = query.  Key-tile pair outermost (one scalar branch per pair, four independent
+    // accumulators inside) instead of a branch in front of every MFMA.
+    f32x4 o[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) o[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NT / 2; ++u) {
+        if (!((live >> (2 * u)) & 3u)) continue;       // both key tiles of the pair dead: P = 0 exactly
+        f16x8 vfr[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) vfr[n] = tr_frag(Vs, 32 * u, 32 * u + 16, 16 * n, g, li);
+        const f16x8 pfu = words_f16x8(pfw[u][0], pfw[u][1], pfw[u][2], pfw[u][3]);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) o[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfr[n], pfu, o[n], 0, 0, 0);
+    }
+    if (q < nq) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            f16x4 ov = (f16x4){(f16)(o[n][0] * inv), (f16)(o[n][1] * inv), (f16)(o[n][2] * inv), (f16)(o[n][3] * inv)};
+            st4_out<VLP_SS_ATTN>(p.ctx + (rbo + q) * p.ld_ctx + h * HD + n * 16 + 4 * g, ov);
+        }
+    }
+    if (first) TRACE(6);       // first tile stored
+}
+
 template <int NT, int NW>   // NT = LP / 16 key tiles (4, 8, 12 or 16)
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void attn_fwd_kernel(AttnParams p) {   // (threads, min waves per SIMD)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -215,149 +365,134 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
     // computed -- 149 instead of 108 VGPRs, same 3 workgroups per CU -- 36.5 us against 34.3 us at B = 64, tools/attn_lab.py.)
     const int nqt = (nq + 15) / 16;
     for (int qt = wid; qt < nqt; qt += NW) {
-        const int q = qt * 16 + li;             // this lane's query (column of every transposed tile)
-        const int qc = min(q, nq - 1);
-        int gq = g;                             // opaque copy: keeps per-key index math inside the loop (no LICM + spills)
-        asm volatile("" : "+v"(gq));
-        const f16* qrow = qbase + (int64_t)qc * p.ld_q;
-        f16x8 qf[2];
-        qf[0] = ld8(qrow + g * 8);
-        qf[1] = ld8(qrow + 32 + g * 8);
-
-        // mask words of this query for all key tiles: independent loads issued before the MFMAs (one L2 round trip, not NT)
-        const uint8_t* mrow = p.mask + ((int64_t)b * Lq + qc) * p.Lp;
-        constexpr bool PRELOAD = NT <= 12;           // L > 192: the words would push the kernel into spills -- fetch them per tile there
-        uint32_t mw[PRELOAD ? NT : 1];
-        if (PRELOAD) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) mw[t] = mask_word(mrow, t * 16 + 4 * gq, p.Lp);
-        }
-        if (qt == wid) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TRACE(3); }      // first tile: Q + mask words have arrived
-        // key tiles that are dead for ALL 16 queries of this wave's tile (bit t clear); only when every query row has an attended key
-        uint32_t live = 0xffffffffu;
-        if (PRELOAD && p.skip) {
-            uint32_t any1 = 0u;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) any1 |= mw[PRELOAD ? t : 0] & 0x01010101u;
-            int rowlive = any1 != 0u;
-            rowlive |= __shfl_xor(rowlive, 16, 64);
-            rowlive |= __shfl_xor(rowlive, 32, 64);
-            if (__all(rowlive)) {
-                live = 0u;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) live |= (__any(ANY_ATTEND(mw[PRELOAD ? t : 0])) ? 1u : 0u) << t;
-            }
-            live = __builtin_amdgcn_readfirstlane(live);
-        }
-        // S^T tiles: rows = keys 16t + 4g + reg, col = query.  Groups of 4 key tiles: one scalar branch per group (a branch per tile
-        // makes every tile its own basic block: two LDS reads, a full lgkmcnt wait, two dependent MFMAs -- ~500 cycles per tile in the
-        // trace); inside a group the 8 fragment reads are issued together and the 8 MFMAs follow.
-        f32x4 s[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t0 = 0; t0 < NT; t0 += 4) {
-            if (!((live >> t0) & 15u)) continue;
-            f16x8 kf[4][2];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int kr = (t0 + j) * 16 + li;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) kf[j][ks] = ld8(Ks + kr * HD + (((ks * 4 + g) ^ swzk(kr)) << 3));
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) s[t0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[j][ks], qf[ks], s[t0 + j], 0, 0, 0);
-        }
-        if (qt == wid) TRACE(4);       // S MFMAs issued
-        // scores in the log2 domain: s2 = s * scale * log2(e) + mask term; softmax = exp2(s2 - max) / sum
-        const float sc2 = p.scale * LOG2E_F;
-        float mx = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (!((live >> t) & 1u)) continue;
-            float ma[4];
-            mask4w(PRELOAD ? mw[PRELOAD ? t : 0] : mask_word(mrow, t * 16 + 4 * gq, p.Lp), t * 16 + 16 <= L, -MASK_C1, ma);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s[t][r] = fmaf(s[t][r], sc2, ma[r]);
-                mx = fmaxf(mx, s[t][r]);
-            }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (!((live >> t) & 1u)) continue;            // dead tile: s[t] stays 0 = the exact value of its probabilities
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - mx);
-                sum += s[t][r];
-            }
-        }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        // the normalisation and the dropout scale 1/(1-p) are applied to the 16 outputs of the lane instead of its 4*NT probabilities
-        const float inv = p.drop.scale / sum;
-        if (p.lse && g == 0 && q < nq) p.lse[((int64_t)b * p.heads + h) * Lq + q] = (mx + __builtin_amdgcn_logf(sum)) * LN2_F;
-
-        // P^T (UNnormalised exp2 values in (0, 1], dropped entries zeroed) as fp16 B-operand fragments: pair u = tiles (2u, 2u+1)
-        uint32_t pfw[NT / 2][4];                 // pair u = tiles (2u, 2u+1); words 2hh, 2hh+1 = the four probabilities of tile 2u+hh
-        // dropout element = (row (b, h, q), col key)
-        const uint32_t rk = p.drop.thresh ? drop_rowkey(p.drop, ((uint64_t)b * p.heads + h) * (uint64_t)Lq + (uint64_t)qc) : 0u;
-        // columns (keys) of tile t held by this lane: 16t + 4g + {0..3} = two hash pairs; pair key advances by 8*PHI per tile
-        const uint32_t pk0 = drop_pairkey(rk, (uint32_t)(4 * gq));
-#pragma unroll
-        for (int u = 0; u < NT / 2; ++u)
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int t = 2 * u + hh;
-                if (!((live >> t) & 1u)) {
-                    pfw[u][2 * hh] = 0u;
-                    pfw[u][2 * hh + 1] = 0u;
-                    continue;
-                }
-                float p0 = s[t][0], p1 = s[t][1], p2 = s[t][2], p3 = s[t][3];
-                if (p.drop.thresh) {
-                    const uint32_t h0 = mix32(pk0 + (uint32_t)(8 * t) * VLP_PHI), h1 = mix32(pk0 + (uint32_t)(8 * t + 1) * VLP_PHI);
-                    p0 = ((h0 & 0xffffu) < p.drop.thresh) ? 0.f : p0;
-                    p1 = ((h0 >> 16) < p.drop.thresh) ? 0.f : p1;
-                    p2 = ((h1 & 0xffffu) < p.drop.thresh) ? 0.f : p2;
-                    p3 = ((h1 >> 16) < p.drop.thresh) ? 0.f : p3;
-                }
-                pfw[u][2 * hh] = pack_f16x2(p0, p1);
-                pfw[u][2 * hh + 1] = pack_f16x2(p2, p3);
-            }
-
-        if (qt == wid) TRACE(5);       // softmax + P fragments done
-        // O^T tiles: rows = head-dim 16n + 4g + reg, col = query.  Key-tile pair outermost (one scalar branch per pair, four independent
-        // accumulators inside) instead of a branch in front of every MFMA.
-        f32x4 o[4];
-#pragma unroll
-        for (int n = 0; n < 4; ++n) o[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < NT / 2; ++u) {
-            if (!((live >> (2 * u)) & 3u)) continue;       // both key tiles of the pair dead: P = 0 exactly
-            f16x8 vfr[4];
-#pragma unroll
-            for (int n = 0; n < 4; ++n) vfr[n] = tr_frag(Vs, 32 * u, 32 * u + 16, 16 * n, g, li);
-            const f16x8 pfu = words_f16x8(pfw[u][0], pfw[u][1], pfw[u][2], pfw[u][3]);
-#pragma unroll
-            for (int n = 0; n < 4; ++n) o[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfr[n], pfu, o[n], 0, 0, 0);
-        }
-        if (q < nq) {
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                f16x4 ov = (f16x4){(f16)(o[n][0] * inv), (f16)(o[n][1] * inv), (f16)(o[n][2] * inv), (f16)(o[n][3] * inv)};
-                st4_out<VLP_SS_ATTN>(p.ctx + (rbo + q) * p.ld_ctx + h * HD + n * 16 + 4 * g, ov);
-            }
-        }
-        if (qt == wid) TRACE(6);       // first tile stored
+        attn_fwd_tile<NT>(p, Ks, Vs, qbase, b, h, L, Lq, nq, rbo, qt, g, li, wid, lane, qt == wid);
     }
     TRACE(7);
 }
+
+#ifdef VLP_LAB_BUILD
+// =================================================================================================
+// forward, persistent streaming form (round 5; the training shape 129 <= L <= 192, NT = 12)
+// =================================================================================================
+// INVESTIGATION BUILDS ONLY (-DVLP_LAB_BUILD, VLP_ATTN_FWD_STREAM=1): built in round 5 as asked by two verdicts, bit-identical to the kernel
+// above, 35.0 -> 32.4 us per layer in the cold-operand lab (B = 64; 15.8 us for one item per workgroup, +8.2 us per further item) and NO
+// gain in the step (9.511 / 9.516 vs 9.524 / 9.512 ms/step, profiles/r05_attention_forward_streaming_lab.txt): inside the step the
+// packed QKV rows were written by the previous kernel and come from L2 / the Infinity Cache, so the load phase this design hides is
+// already short, and the tiles themselves are VALU-issue-bound (~1 300 VALU instructions per 16-query tile, ~27 per score: exp2, mask
+// term, dropout hash, fp16 packing; 12 waves keep the four SIMDs ~78 % busy at 8.2 us per item).  What would move it is fewer
+// instructions per score, not another schedule.
+// The kernel above starts all B x heads workgroups at once: every one of them first waits for its K / V rows, then computes, three 4-wave
+// workgroups per CU in the same phase -- 32 us per layer at B = 64 where the VALU work of the tiles (the forward is VALU-issue-bound:
+// exp2, mask term, dropout hash, fp16 packing: ~27 instructions per score) is ~14 us per CU.  Here ONE 12-wave workgroup per CU walks its
+// (batch, head) items through THREE K / V buffer pairs in LDS (144 KB):
+//   * producer side, every wave: the K / V rows of item k+1 (its 1/12 share: 4 x 16 bytes per lane, requested one item earlier into
+//     registers through buffer descriptors that zero-fill past the sample's rows) are written into buffer (k+1) % 3 at the START of item k
+//     -- a buffer whose previous occupant (item k-2) is known to be consumed from an LDS counter -- then item k+2 is requested;
+//   * consumer side: the 16-query tiles of item k are TASKS handed out by an LDS atomic counter, so a wave that drew a cheap tile (region
+//     rows attend 7 of 12 key tiles under the seq2seq mask) simply draws the next one, also across the item boundary: there is NO
+//     workgroup barrier per item -- a wave waits only for "all 12 shares of item k are in LDS" (counter), which the slowest wave wrote
+//     a whole item earlier.
+// The tile code is attn_fwd_tile, shared with the kernel above: identical bits.  Counters are monotonic over the launch:
+//   ready[b] counts shares written, task[b] hands out indices (every wave overshoots exactly once per item: the next occupant's base
+//   moves by tiles + waves), done[b] counts finished tiles.
+#define AFS_WAVES 12
+#define AFS_NBUF 3
+template <int NT>
+__global__ __launch_bounds__(AFS_WAVES * 64, 1) void attn_fwd_stream_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int LP = NT * 16, TILE = LP * HD, NTHR = AFS_WAVES * 64;
+    constexpr int IT = (LP * 8 + NTHR - 1) / NTHR;                 // 16-byte pieces per thread and tile (2 at LP = 192)
+    f16* bufs = reinterpret_cast<f16*>(smem_raw);                  // [AFS_NBUF][K | V][LP][64] swizzled
+    int* ctr = reinterpret_cast<int*>(bufs + AFS_NBUF * 2 * TILE); // task[3] | done[3] | ready[3]
+    int* task = ctr; int* done = ctr + 4; int* ready = ctr + 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int L = p.Lk, Lq = p.Lq;
+    const int nitems = p.B * p.heads;
+    const int n_my = ((int)blockIdx.x < nitems) ? (nitems - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    if (tid < 12) ctr[tid] = 0;
+    __syncthreads();
+    if (n_my == 0) return;
+
+    u32x4 rk[IT], rv[IT];
+    auto rows_of = [&](int item, int& b_, int& h_, int& rb_, int& nb_) {
+        b_ = item / p.heads; h_ = item % p.heads;
+        rb_ = p.row_off ? p.row_off[b_] : b_ * (int)p.bs_kv;
+        nb_ = p.row_off ? p.row_off[b_ + 1] - rb_ : L;
+    };
+    auto request = [&](int item) {          // this thread's pieces of the item's K and V rows -> registers (rows >= nb read as zero)
+        int b_, h_, rb_, nb_;
+        rows_of(item, b_, h_, rb_, nb_);
+        const __amdgpu_buffer_rsrc_t r0 = rows_rsrc(p.k + (int64_t)rb_ * p.ld_kv + h_ * HD, p.ld_kv, nb_),
+                                     r1 = rows_rsrc(p.v + (int64_t)rb_ * p.ld_kv + h_ * HD, p.ld_kv, nb_);
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int idx = tid + i * NTHR, r = idx >> 3, c = idx & 7;
+            rk[i] = __builtin_amdgcn_raw_buffer_load_b128(r0, (r * (int)p.ld_kv + c * 8) * 2, 0, 0);
+            rv[i] = __builtin_amdgcn_raw_buffer_load_b128(r1, (r * (int)p.ld_kv + c * 8) * 2, 0, 0);
+        }
+    };
+    auto publish = [&](int buf) {           // registers -> LDS buffer `buf`, then this wave's share is announced
+        f16* Kd = bufs + buf * 2 * TILE;
+        f16* Vd = Kd + TILE;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int idx = tid + i * NTHR, r = idx >> 3, c = idx & 7;
+            if (idx < LP * 8) {
+                *reinterpret_cast<u32x4*>(Kd + r * HD + ((c ^ swzk(r)) << 3)) = rk[i];
+                *reinterpret_cast<u32x4*>(Vd + r * HD + ((c ^ swzk(r)) << 3)) = rv[i];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(ready + buf, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto wait_ge = [&](int* c, int target) {
+        while (__hip_atomic_load(c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+    };
+
+    int task_base[AFS_NBUF] = {0, 0, 0}, done_base[AFS_NBUF] = {0, 0, 0};      // per buffer: first task index / finished tiles of earlier occupants
+    request(blockIdx.x);
+    publish(0);
+    if (n_my > 1) request(blockIdx.x + gridDim.x);
+#pragma unroll 1
+    for (int k = 0; k < n_my; ++k) {
+        const int bk = k % AFS_NBUF;
+        const int item = blockIdx.x + k * gridDim.x;
+        int b, h, rb, nb;
+        rows_of(item, b, h, rb, nb);
+        const int nq = p.row_off ? nb : Lq;
+        const int nqt = (nq + 15) / 16;
+        // ---- producer: item k+1 into its buffer (free once item k-2 is consumed), then the request for item k+2
+        if (k + 1 < n_my) {
+            const int bn = (k + 1) % AFS_NBUF;
+            wait_ge(done + bn, done_base[bn]);
+            publish(bn);
+            if (k + 2 < n_my) request(blockIdx.x + (k + 2) * gridDim.x);
+        }
+        // ---- consumer: tiles of item k, drawn from the buffer's task counter
+        const f16* Ks = bufs + bk * 2 * TILE;
+        const f16* Vs = Ks + TILE;
+        const int64_t rbq = p.row_off ? (int64_t)rb : (int64_t)b * p.bs_q, rbo = p.row_off ? (int64_t)rb : (int64_t)b * Lq;
+        const f16* qbase = p.q + rbq * p.ld_q + h * HD;
+        bool waited = false;
+        for (;;) {
+            int t = 0;
+            if (lane == 0) t = __hip_atomic_fetch_add(task + bk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            t = __builtin_amdgcn_readfirstlane(t) - task_base[bk];
+            if (t >= nqt) break;
+            if (!waited) { wait_ge(ready + bk, AFS_WAVES * (k / AFS_NBUF + 1)); waited = true; }
+            attn_fwd_tile<NT>(p, Ks, Vs, qbase, b, h, L, Lq, nq, rbo, t, g, li, wid, lane, false);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // this tile's K / V fragment reads have returned
+            if (lane == 0) __hip_atomic_fetch_add(done + bk, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        task_base[bk] += nqt + AFS_WAVES;          // every wave drew exactly one index past the end
+        done_base[bk] += nqt;
+    }
+}
+
+#endif      // VLP_LAB_BUILD (streaming forward)
 
 #ifdef VLP_LAB_BUILD      // the two-kernel backward (dQ, then dK / dV): the form the one-kernel backward was validated against; investigation builds only
 // =================================================================================================
@@ -1204,6 +1339,22 @@ static int attn_skip_enabled() {
 static int launch_attn_fwd(AttnParams& p, hipStream_t s) {
     p.skip = attn_skip_enabled();
     const int LP = lp_of(p.Lk);
+#ifdef VLP_LAB_BUILD
+    // investigation builds: VLP_ATTN_FWD_STREAM=1 runs the training shape (129 <= L <= 192, queries = keys from one packed buffer) on the
+    // persistent streaming kernel (identical bits; no gain in the step, see the note above it)
+    if (LP == 192 && p.n_prefix == 0 && p.Lq == p.Lk && p.lse != nullptr) {
+        const char* e = getenv("VLP_ATTN_FWD_STREAM");
+        if (e && e[0] == '1') {
+            static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n; }();
+            const int items = p.B * p.heads;
+            const size_t smem = (size_t)AFS_NBUF * 2 * LP * HD * 2 + 64;
+            VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)attn_fwd_stream_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL((attn_fwd_stream_kernel<12>), dim3(items < ncu ? items : ncu), dim3(AFS_WAVES * 64), smem, s, p);
+            VLP_CHECK_LAUNCH("vlp_attn_fwd");
+            return VLP_OK;
+        }
+    }
+#endif
     const size_t smem = (size_t)2 * LP * HD * 2;
     dim3 grid(p.B * p.heads);
     static const int nw12 = attn_waves_nt12();
