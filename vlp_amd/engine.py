@@ -1397,10 +1397,12 @@ class Engine(object):
             self._tn(ws["dz1v"], img, self.G("vis_embed.0.weight"), Mv, 2048, 2048, ws, beta, bias=self.G("vis_embed.0.bias"))
         K.copy2d(ws["dwpe_pad"], PE_PAD, False, self.G("vis_pe_embed.0.weight"), PE_DIM, H, PE_DIM, PE_DIM, beta=beta)
         K.colsum(ws["d_vispe_h"], self.G("vis_pe_embed.0.bias"), Mv, H, beta=beta, workspace=ws["cs_ws"])
-        self._bucket_done(NL + 2)
         if use_side and self._side_busy:
+            # the streams join HERE, in front of the last hand-off: a reducer may coalesce the embedding tables (written on the side stream)
+            # with the region projections into one bucket, and that bucket's collective is ordered behind the stream that announces it
             main.wait_stream(side)
             self._side_busy = False
+        self._bucket_done(NL + 2)
         self.grads_dirty = True
         if self.post_backward_hook is not None:
             self.post_backward_hook()
