@@ -545,6 +545,8 @@ class Engine(object):
         device and read back ONCE per tensor object (the result is remembered while that tensor is alive and unmodified -- a device-
         resident batch pool, bench.py / --synthetic, pays the read-back in its first pass only)."""
         if isinstance(attention_mask, MaskSpec):
+            # (lens_host is the loader's promise that nothing past it is attended OR read: masked_pos lies inside the tokens by construction,
+            # seq2seq_loader.py:256-265; the gather clamps a position past the kept rows to the last kept row, as the dense kernel clamps to L - 1)
             if attention_mask.lens_host is None:
                 return None
             lens = [max(int(n), Nv + 2) for n in attention_mask.lens_host]
@@ -552,10 +554,10 @@ class Engine(object):
         if attention_mask is None or attention_mask.dim() != 3:
             return None
         key = id(attention_mask)
-        mp_key = (id(masked_pos), masked_pos._version) if masked_pos is not None else None
         hit = self._pk_lens.get(key)
-        if hit is not None and hit[0]() is attention_mask and hit[1] == attention_mask._version and hit[2] == mp_key:
-            return hit[3]
+        if hit is not None and hit[0]() is attention_mask and hit[1] == attention_mask._version and \
+                (hit[2] is None) == (masked_pos is None) and (masked_pos is None or (hit[2]() is masked_pos and hit[4] == masked_pos._version)):
+            return hit[3]           # the SAME tensor objects, unmodified (weak references: a recycled id() cannot alias)
         cols = (attention_mask != 0).any(dim=1)                                            # [B, L]: key column attended by some query
         idx = torch.arange(1, L + 1, device=cols.device, dtype=torch.int32)
         n = (cols.to(torch.int32) * idx).amax(dim=1)
@@ -567,7 +569,8 @@ class Engine(object):
             self._pk_lens = {k: v for k, v in self._pk_lens.items() if v[0]() is not None}
             if len(self._pk_lens) > 64:
                 self._pk_lens.clear()
-        self._pk_lens[key] = (weakref.ref(attention_mask), attention_mask._version, mp_key, lens)
+        self._pk_lens[key] = (weakref.ref(attention_mask), attention_mask._version, weakref.ref(masked_pos) if masked_pos is not None else None, lens,
+                              masked_pos._version if masked_pos is not None else 0)
         return lens
 
     def _packing(self, lens, B, L):
