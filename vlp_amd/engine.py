@@ -291,6 +291,13 @@ class Engine(object):
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
+    def zero_placeholder(self, device):
+        """The shared read-only [1] fp32 zero that stands for a loss the task does not have (modeling.py:1096-1098, 1133)."""
+        z = getattr(self, "_zero1", None)
+        if z is None or z.device != device:
+            z = self._zero1 = torch.zeros(1, device=device, dtype=torch.float32)
+        return z
+
     def zero_grad(self):
         """optimizer.zero_grad() of the train loop (run_img2txt_dist.py:585): no memset -- the next
         backward simply overwrites (beta = 0) instead of accumulating."""

@@ -513,8 +513,9 @@ class BertForPreTrainingLossMask(PreTrainedBertModel):
             assert ans_labels is not None
         want_mlm = (not is_vqa) and masked_pos is not None and masked_pos.numel() > 0
         st = eng.forward(vis_feats, vis_pe, input_ids, token_type_ids, attention_mask, masked_pos, train, want_mlm, is_vqa, vis_masked_pos=vmp)
-        dev = input_ids.device
-        zero1 = torch.zeros(1, device=dev, dtype=torch.float32)
+        # the reference's `.new(1).fill_(0)` placeholders of the losses a task does not have (:1096-1098, 1133): ONE read-only [1] zero per engine,
+        # handed out by identity (no fill / clone launches per step; vlp_amd.run_img2txt_dist.train_step skips adding it) -- do not modify it in place
+        zero1 = eng.zero_placeholder(input_ids.device)
         need_grad = torch.is_grad_enabled()
         raw_pt = eng.pretext_loss(st) if vmp is not None else None
         if vmp is not None:
@@ -523,9 +524,9 @@ class BertForPreTrainingLossMask(PreTrainedBertModel):
         def live(raw, task):
             """(task loss, pretext loss) as autograd outputs of one node; the pretext placeholder is the reference's [1] zero (:1133)."""
             if not need_grad:
-                return raw.clone(), (raw_pt.clone().reshape(()) if raw_pt is not None else zero1.clone())
+                return raw.clone(), (raw_pt.clone().reshape(()) if raw_pt is not None else zero1)
             if raw_pt is None:
-                return _LossFn.apply(eng._anchor, raw, None, eng, st, task), zero1.clone()
+                return _LossFn.apply(eng._anchor, raw, None, eng, st, task), zero1
             a, b = _LossFn.apply(eng._anchor, raw, raw_pt, eng, st, task)
             return a, b.reshape(())                                     # :1131: a 0-dim mean
 
@@ -536,13 +537,13 @@ class BertForPreTrainingLossMask(PreTrainedBertModel):
             return zero1, pt_loss, loss.reshape(())                     # :1141 shapes ([1], [1] | [], [])
         if not want_mlm:
             if raw_pt is None:
-                return zero1, zero1.clone(), zero1.clone()              # :1096-1098
+                return zero1, zero1, zero1                              # :1096-1098
             loss, pt_loss = live(zero1.clone(), "img2txt")              # empty masked_pos: only the pretext loss is live
-            return loss, pt_loss, zero1.clone()
+            return loss, pt_loss, zero1
         raw = eng.mlm_loss(st, masked_lm_labels, masked_weights, drop_worst_ratio)
         self.last_mlm_logits = eng.mlm_logits(st)
         loss, pt_loss = live(raw, "img2txt")
-        return loss.reshape(()), pt_loss, zero1.clone()                 # :1143 shapes ([], [1] | [], [1])
+        return loss.reshape(()), pt_loss, zero1                         # :1143 shapes ([], [1] | [], [1])
 
 
 class BertForSeq2SeqDecoder(PreTrainedBertModel):

@@ -176,7 +176,10 @@ class FP16_Optimizer_State(object):
         # a pipelined step (pipeline_with_forward) may still be running on the optimizer stream: its loss_scale_update is the LAST thing it
         # enqueues, so the scale read here must be ordered behind the whole step, not only behind the first parameter chunk
         self.engine.wait_params()
-        (loss.float() * self._scale_state[0]).backward()
+        # d(loss * scale) = scale * d(loss): the device-resident scale goes in as the upstream gradient instead of being multiplied into the
+        # loss first -- the same numbers without the multiply, its autograd twin and the ones() fill (three launches between forward and backward)
+        loss = loss.float()
+        loss.backward(gradient=self._scale_state[0:1].reshape(loss.shape))
 
     def zero_grad(self, set_grads_to_None=True):
         self.engine.zero_grad()

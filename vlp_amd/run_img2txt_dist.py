@@ -223,7 +223,14 @@ def train_step(model, optimizer, batch, lr_this_step, mask_image_regions=False, 
                        masked_weights=masked_weights, task_idx=task_idx, vis_masked_pos=vis_masked_pos,
                        mask_image_regions=mask_image_regions, drop_worst_ratio=drop_worst_ratio)
     masked_lm_loss, pretext_loss, ans_loss = loss_tuple
-    loss = masked_lm_loss + pretext_loss + ans_loss          # :531
+    # :531 `loss = masked_lm_loss + pretext_loss + ans_loss`; the engine's shared zero placeholder (a loss this task does not have) is
+    # recognised by identity and not added: no add launches for `+ 0`
+    eng = getattr(model.module if hasattr(model, "module") else model, "engine", None)
+    zero = getattr(eng, "_zero1", None)
+    terms = [t for t in loss_tuple if t is not zero] or [masked_lm_loss]
+    loss = terms[0]
+    for t in terms[1:]:
+        loss = loss + t
     if accum_steps > 1:
         loss = loss / accum_steps                            # :567-568
     optimizer.backward(loss)                                 # :571
