@@ -422,3 +422,49 @@ def test_bench_world2_on_one_gpu_real_engine_ddp_hooks(mode):
     if "rs_ag" in _WORLD2_CHECKSUMS and "sharded" in _WORLD2_CHECKSUMS:
         for a, b in zip(_WORLD2_CHECKSUMS["rs_ag"], _WORLD2_CHECKSUMS["sharded"]):
             assert abs(a - b) <= 1e-6 * abs(a) + 1e-3, _WORLD2_CHECKSUMS
+
+
+def test_sharded_parameter_gathers_are_waited_for_before_the_weight_transposes():
+    """after a sharded optimizer step the updated parameters arrive by asynchronous per-bucket all-gathers
+    (Engine._param_works).  The next forward transposes EVERY weight matrix on the side stream (W^T shadows for the dgrad GEMMs): that
+    stream must wait for all gathers first, or backward would use last step's weights for the chunks other ranks own.  RCCL refuses two
+    ranks on one GPU, so the ordering is checked with stand-in work handles that record on which stream they were waited for."""
+    model, _ = small_model(drop=0.0)
+    model.train()
+    eng = model.engine
+    batch = S.batch_to(S.make_batch(4, max_len_b=20, vocab_size=1024, max_pred=3, seed=1), DEV, half=True)
+    b = batch
+    args = (b.img, b.vis_pe, b.input_ids, b.segment_ids, b.input_mask, b.lm_label_ids, b.ans_labels, b.is_next)
+    kw = dict(masked_pos=b.masked_pos, masked_weights=b.masked_weights, task_idx=b.task_idx, vis_masked_pos=b.vis_masked_pos, drop_worst_ratio=0)
+    model(*args, **kw)                                  # creates the side stream
+    side, log = eng._side, []
+    assert side is not None
+
+    class Work(object):
+        def __init__(self, name):
+            self.name = name
+
+        def wait(self):
+            log.append(("wait", self.name, torch.cuda.current_stream() == side))
+
+    class Plan(object):
+        bucket_of_slice = {i: i for i in range(len(eng.buckets))}
+
+    real = eng._refresh_shadows
+
+    def refresh():
+        log.append(("transpose", None, torch.cuda.current_stream() == side))
+        real()
+    eng._refresh_shadows = refresh
+    eng.shard_plan = Plan()
+    eng._param_works = dict([("nodecay", Work("nodecay"))] + [(i, Work(i)) for i in range(len(eng.buckets))])
+    try:
+        model(*args, **kw)
+    finally:
+        eng._refresh_shadows, eng.shard_plan, eng._param_works = real, None, None
+    t = [i for i, e in enumerate(log) if e[0] == "transpose"]
+    assert len(t) == 1 and log[t[0]][2], log            # one transpose launch, on the side stream
+    waited_on_side_before = {e[1] for e in log[:t[0]] if e[0] == "wait" and e[2]}
+    assert waited_on_side_before == {"nodecay"} | set(range(len(eng.buckets))), log
+    # the main stream still waits per bucket where the forward first reads it
+    assert {e[1] for e in log if e[0] == "wait" and not e[2]} == {"nodecay"} | set(range(len(eng.buckets))), log

@@ -253,7 +253,7 @@ class Engine(object):
     def set_param_events(self, events, done):
         self._param_events, self._params_done = events, done
 
-    def wait_params(self, key=None, host=False):
+    def wait_params(self, key=None, host=False, consume=True):
         """Make the current stream (host=True: the calling thread) wait until the optimizer stream has written parameter chunk `key`
         ("nodecay" or a bucket index); key=None: all of them (also orders the optimizer's reads of the gradient buffers before later work)."""
         if self._param_works is not None:          # sharded step: parameter chunks arrive by all-gather, one collective per bucket
@@ -272,7 +272,8 @@ class Engine(object):
                 w = works.get(k)
                 if w is not None:
                     w.wait()
-                    works[k] = None
+                    if consume:                    # (consume=False: a wait on ANOTHER stream -- the main stream still has to wait for this bucket itself)
+                        works[k] = None
             if prof is not None:
                 e1 = torch.cuda.Event(enable_timing=True)
                 e1.record()
@@ -665,7 +666,7 @@ class Engine(object):
                 K.copy2d(vp, PE_DIM, vp.dtype == torch.float32, ws["vpe_in"], PE_PAD, Mv, PE_DIM, PE_PAD)
             # parameters written by a pipelined optimizer step become readable chunk by chunk (wait_params is a no-op otherwise)
             # (reads a parameter of the embeddings bucket: AFTER the wait, or a pipelined step would project with last step's weight)
-            self.wait_params(len(self.buckets) - 1)             # region projections
+            self.wait_params(len(self.buckets) - 1, consume=False)      # region projections (this may run on the side stream)
             K.copy2d(self.P("vis_pe_embed.0.weight"), PE_DIM, False, ws["wpe_pad"], PE_PAD, H, PE_DIM, PE_PAD)
 
         def prep_mask(am):
