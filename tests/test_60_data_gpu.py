@@ -123,7 +123,7 @@ def test_padding_free_training_from_the_prefetcher(tmp_path):
     p_s2s, p_bi = procs()
     model_a, opt_a = _tiny_model_and_opt(3e-4)
     model_b, opt_b = _tiny_model_and_opt(3e-4)
-    model_b.engine.varlen = True
+    model_a.engine.varlen, model_b.engine.varlen = False, True
     random.seed(5)
     first = None
     for batch in BatchPrefetcher(store, examples, 8, p_s2s, p_bi, s2s_prob=0.75, device=DEV, steps=6, seed=1):
