@@ -28,7 +28,7 @@ def main():
     i = [0]
 
     tiles = sum((n // 128) * (k // 128) for n, k in shapes)
-    wsk = torch.empty(K.gemm_tn_grouped_workspace_bytes(tiles), device=DEV, dtype=torch.uint8)      # stream-K form (mode 5)
+    wsk = torch.empty(K.gemm_tn_grouped_workspace_bytes(tiles), device=DEV, dtype=torch.uint8) if K.lab_build() else None      # stream-K form (mode 5, investigation library)
 
     def f():
         s = sets[i[0] % ROT]
