@@ -188,12 +188,17 @@ extern "C" int vlp_layernorm_fwd(const vlp_layernorm_fwd_args* a, void* stream) 
 // the second pass): 168 VGPRs + spills, 3 waves per SIMD, no next-row prefetch -- 20.9 us against 14.5 us for this kernel (tools/ln_lab.py).
 // A third row in flight (prefetch two rows ahead, 128 VGPRs): 17.4 us -- a wave only sees 2.6 rows, the extra requests just queue up front.
 // ---------------------------------------------------------------------------------------------
-#define LNB_BLOCKS 512
-#define LNB_THREADS 512
+#ifndef LNB_WAVES      // block geometry of the backward kernel; overridable for A/B builds (tools/build_variant_lib.sh)
 #define LNB_WAVES 8
+#endif
+#define LNB_THREADS (64 * LNB_WAVES)
+#define LNB_BLOCKS (4096 / LNB_WAVES)
+#ifndef LNB_MINW
+#define LNB_MINW 4
+#endif
 
 template <int NP>
-__global__ __launch_bounds__(LNB_THREADS, NP <= 3 ? 4 : (NP == 4 ? 3 : 2)) void layernorm_bwd_kernel(
+__global__ __launch_bounds__(LNB_THREADS, NP <= 3 ? LNB_MINW : (NP == 4 ? 3 : 2)) void layernorm_bwd_kernel(
     const f16* __restrict__ dy, int64_t lddy, const f16* __restrict__ x, int64_t ldx, const f16* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, f16* __restrict__ dx, int64_t lddx,
     f16* __restrict__ dxd, int64_t lddxd, float* __restrict__ part, int M, int H, DropCtx dyd, DropCtx outd, const int32_t* __restrict__ row_map) {
