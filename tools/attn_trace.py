@@ -17,7 +17,7 @@ lib = K.load(); buf = np.zeros(4096 * 8, dtype=np.uint64)
 lib.vlp_debug_read_attn_trace.argtypes = [C.c_void_p, C.c_int64]
 rc = lib.vlp_debug_read_attn_trace(buf.ctypes.data, buf.nbytes); assert rc == 0, rc
 t = buf.reshape(4096, 8)[:B * A].astype(np.int64)
-names = ["stage issue (global->reg->LDS writes)", "wait barrier (staging lands)", "first tile: Q + mask arrive", "S MFMAs (+ live test)", "softmax + P", "PV + store", "remaining tiles of wave 0"]
+names = ["stage issue (global->reg->LDS writes)", "wait barrier (staging lands)", "first tile: Q + mask arrive", "S MFMAs (+ live test)", "scale + mask + row max", "exp2 + dropout + PV + store", "remaining tiles of wave 0"]
 t0 = t[:, 0].min()
 print("workgroup start spread: %.1f us; end spread: first %.1f us last %.1f us (100 MHz counter? ticks shown raw)" % ((t[:, 0].max() - t0) / 100.0, (t[:, 7].min() - t0) / 100.0, (t[:, 7].max() - t0) / 100.0))
 for i, n in enumerate(names):

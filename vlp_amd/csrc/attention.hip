@@ -179,27 +179,47 @@ DEVFN void mask4w(uint32_t w, bool full, float c0, float out[4]) {
 // context rows + lse stored.  Shared by the one-workgroup-per-(batch, head) kernel below and the persistent streaming kernel: the tile code
 // is the same, so both produce the same bits.  Ks / Vs: the head's K and V rows in LDS (row-major, chunk-swizzled); rows >= the staged
 // count are zero.  `first`: the wave's first tile of the launch (phase trace only).
+// packed 16-bit integer ops on a 32-bit word (written as asm: from vector C the compiler falls back to per-half compare / select / v_perm)
+DEVFN uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }
+DEVFN uint32_t pk_min_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+DEVFN uint32_t pk_mul_lo_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// Round 5 (late): the tile is straight-line code per key-tile PAIR, like the backward's pair loop -- dropout is a compile-time switch, the
+// padding-column test is folded into the additive mask base (and exists only for the last four key tiles: 16 (NT - 4) < L by the
+// launcher's choice of NT), exp2 / row sum / dropout / fp16 packing / P.V of a pair form ONE block, and the dropout zeroing works on the packed
+// fp16 pair with three packed 16-bit instructions (saturating subtract, min, multiply) instead of shift / compare / select per element.
+// The first form had a scalar branch per key tile in each of its four loops plus run-time dropout / interior-tile switches: ~60 basic blocks
+// per query tile with 168 hazard s_nops between them.  Same bits: a dead tile inside a live pair is now computed, and its probabilities are the
+// exact zeros (exp2 of -14 000) the skipped form assumed.
+// the global loads of a query tile: this lane's Q fragments and (NT <= 12) its mask words for all key tiles -- independent loads, one L2
+// round trip.  The kernel issues the loads of a wave's FIRST tile before the K / V staging, so that they travel with it: in the phase
+// trace every wave of a workgroup sat ~8 000 cycles (15 % of the workgroup's life) behind them right after the staging barrier.
 template <int NT>
-DEVFN void attn_fwd_tile(const AttnParams& p, const f16* Ks, const f16* Vs, const f16* qbase, int b, int h, int L, int Lq, int nq, int64_t rbo,
-                         int qt, int g, int li, int wid, int lane, bool first) {
-    (void)wid; (void)lane;
-    const int q = qt * 16 + li;             // this lane's query (column of every transposed tile)
-    const int qc = min(q, nq - 1);
+DEVFN void attn_fwd_tile_load(const AttnParams& p, const f16* qbase, int b, int Lq, int nq, int qt, int g, int li, f16x8 (&qf)[2], uint32_t (&mw)[NT <= 12 ? NT : 1]) {
+    const int qc = min(qt * 16 + li, nq - 1);
     int gq = g;                             // opaque copy: keeps per-key index math inside the loop (no LICM + spills)
     asm volatile("" : "+v"(gq));
     const f16* qrow = qbase + (int64_t)qc * p.ld_q;
-    f16x8 qf[2];
     qf[0] = ld8(qrow + g * 8);
     qf[1] = ld8(qrow + 32 + g * 8);
-
-    // mask words of this query for all key tiles: independent loads issued before the MFMAs (one L2 round trip, not NT)
-    const uint8_t* mrow = p.mask + ((int64_t)b * Lq + qc) * p.Lp;
-    constexpr bool PRELOAD = NT <= 12;           // L > 192: the words would push the kernel into spills -- fetch them per tile there
-    uint32_t mw[PRELOAD ? NT : 1];
-    if (PRELOAD) {
+    if (NT <= 12) {
+        const uint8_t* mrow = p.mask + ((int64_t)b * Lq + qc) * p.Lp;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) mw[t] = mask_word(mrow, t * 16 + 4 * gq, p.Lp);
+        for (int t = 0; t < NT; ++t) mw[NT <= 12 ? t : 0] = mask_word(mrow, t * 16 + 4 * gq, p.Lp);
     }
+}
+template <int NT, bool DROP>
+DEVFN void attn_fwd_tile_compute(const AttnParams& p, const f16* Ks, const f16* Vs, int b, int h, int L, int Lq, int nq, int64_t rbo,
+                                 int qt, int g, int li, int wid, int lane, bool first, const f16x8 (&qf)[2], const uint32_t (&mw)[NT <= 12 ? NT : 1]) {
+    (void)wid; (void)lane;
+#ifdef VLP_ISA_MARKERS
+    asm volatile("; TILE_BEGIN drop=%0" :: "n"((int)DROP));
+#endif
+    const int q = qt * 16 + li;             // this lane's query (column of every transposed tile)
+    const int qc = min(q, nq - 1);
+    int gq = g;
+    asm volatile("" : "+v"(gq));
+    constexpr bool PRELOAD = NT <= 12;           // L > 192: the words would push the kernel into spills -- fetch them per tile there
+    const uint8_t* mrow = p.mask + ((int64_t)b * Lq + qc) * p.Lp;
     if (first) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TRACE(3); }      // first tile: Q + mask words have arrived
     // key tiles that are dead for ALL 16 queries of this wave's tile (bit t clear); only when every query row has an attended key
     uint32_t live = 0xffffffffu;
@@ -219,10 +239,9 @@ DEVFN void attn_fwd_tile(const AttnParams& p, const f16* Ks, const f16* Vs, cons
     }
     // S^T tiles: rows = keys 16t + 4g + reg, col = query.  Groups of 4 key tiles: one scalar branch per group (a branch per tile
     // makes every tile its own basic block: two LDS reads, a full lgkmcnt wait, two dependent MFMAs -- ~500 cycles per tile in the
-    // trace); inside a group the 8 fragment reads are issued together and the 8 MFMAs follow.
+    // trace); inside a group the 8 fragment reads are issued together and the 8 MFMAs follow.  A dead group's tiles are never read below
+    // (its pairs are dead), so they are not initialised either.
     f32x4 s[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t0 = 0; t0 < NT; t0 += 4) {
         if (!((live >> t0) & 15u)) continue;
@@ -234,87 +253,80 @@ DEVFN void attn_fwd_tile(const AttnParams& p, const f16* Ks, const f16* Vs, cons
             for (int ks = 0; ks < 2; ++ks) kf[j][ks] = ld8(Ks + kr * HD + (((ks * 4 + g) ^ swzk(kr)) << 3));
         }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int j = 0; j < 4; ++j) s[t0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[j][0], qf[0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s[t0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[j][ks], qf[ks], s[t0 + j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) s[t0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[j][1], qf[1], s[t0 + j], 0, 0, 0);
     }
     if (first) TRACE(4);       // S MFMAs issued
-    // scores in the log2 domain: s2 = s * scale * log2(e) + mask term; softmax = exp2(s2 - max) / sum
+    // scores in the log2 domain: s2 = s * scale * log2(e) + mask term; softmax = exp2(s2 - max) / sum.  Mask term of a key: byte * C1 + base,
+    // base = -C1 for a real key (byte 0 / 1) and -inf for a padding column (byte 2; 2 C1 - inf = -inf)
     const float sc2 = p.scale * LOG2E_F;
     float mx = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (!((live >> t) & 1u)) continue;
-        float ma[4];
-        mask4w(PRELOAD ? mw[PRELOAD ? t : 0] : mask_word(mrow, t * 16 + 4 * gq, p.Lp), t * 16 + 16 <= L, -MASK_C1, ma);
+    for (int u = 0; u < NT / 2; ++u) {
+        if (!((live >> (2 * u)) & 3u)) continue;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            s[t][r] = fmaf(s[t][r], sc2, ma[r]);
-            mx = fmaxf(mx, s[t][r]);
+        for (int hh = 0; hh < 2; ++hh) {
+            const int t = 2 * u + hh;
+            const uint32_t w = PRELOAD ? mw[PRELOAD ? t : 0] : mask_word(mrow, t * 16 + 4 * gq, p.Lp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float base = (t < NT - 4 || t * 16 + 4 * gq + r < L) ? -MASK_C1 : -INFINITY;      // (t < NT - 4: compile time)
+                s[t][r] = fmaf(s[t][r], sc2, fmaf((float)((w >> (8 * r)) & 0xffu), MASK_C1, base));
+                mx = fmaxf(mx, s[t][r]);
+            }
         }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (!((live >> t) & 1u)) continue;            // dead tile: s[t] stays 0 = the exact value of its probabilities
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - mx);
-            sum += s[t][r];
-        }
-    }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    // the normalisation and the dropout scale 1/(1-p) are applied to the 16 outputs of the lane instead of its 4*NT probabilities
-    const float inv = p.drop.scale / sum;
-    if (p.lse && g == 0 && q < nq) p.lse[((int64_t)b * p.heads + h) * Lq + q] = (mx + __builtin_amdgcn_logf(sum)) * LN2_F;
+    if (first) TRACE(5);       // scores scaled + masked, row maximum known
 
-    // P^T (UNnormalised exp2 values in (0, 1], dropped entries zeroed) as fp16 B-operand fragments: pair u = tiles (2u, 2u+1)
-    uint32_t pfw[NT / 2][4];                 // pair u = tiles (2u, 2u+1); words 2hh, 2hh+1 = the four probabilities of tile 2u+hh
-    // dropout element = (row (b, h, q), col key)
-    const uint32_t rk = p.drop.thresh ? drop_rowkey(p.drop, ((uint64_t)b * p.heads + h) * (uint64_t)Lq + (uint64_t)qc) : 0u;
+    // per pair: P^T (UNnormalised exp2 values in (0, 1], dropped entries zeroed) as the fp16 B-operand fragment of the pair, then
+    // O^T += V^T P^T (rows = head-dim 16n + 4g + reg, col = query).  The normalisation and the dropout scale 1/(1-p) are applied to the 16
+    // outputs of the lane instead of its 4*NT probabilities.  dropout element = (row (b, h, q), col key)
+    const uint32_t rk = DROP ? drop_rowkey(p.drop, ((uint64_t)b * p.heads + h) * (uint64_t)Lq + (uint64_t)qc) : 0u;
     // columns (keys) of tile t held by this lane: 16t + 4g + {0..3} = two hash pairs; pair key advances by 8*PHI per tile
     const uint32_t pk0 = drop_pairkey(rk, (uint32_t)(4 * gq));
-#pragma unroll
-    for (int u = 0; u < NT / 2; ++u)
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int t = 2 * u + hh;
-            if (!((live >> t) & 1u)) {
-                pfw[u][2 * hh] = 0u;
-                pfw[u][2 * hh + 1] = 0u;
-                continue;
-            }
-            float p0 = s[t][0], p1 = s[t][1], p2 = s[t][2], p3 = s[t][3];
-            if (p.drop.thresh) {
-                const uint32_t h0 = mix32(pk0 + (uint32_t)(8 * t) * VLP_PHI), h1 = mix32(pk0 + (uint32_t)(8 * t + 1) * VLP_PHI);
-                p0 = ((h0 & 0xffffu) < p.drop.thresh) ? 0.f : p0;
-                p1 = ((h0 >> 16) < p.drop.thresh) ? 0.f : p1;
-                p2 = ((h1 & 0xffffu) < p.drop.thresh) ? 0.f : p2;
-                p3 = ((h1 >> 16) < p.drop.thresh) ? 0.f : p3;
-            }
-            pfw[u][2 * hh] = pack_f16x2(p0, p1);
-            pfw[u][2 * hh + 1] = pack_f16x2(p2, p3);
-        }
-
-    if (first) TRACE(5);       // softmax + P fragments done
-    // O^T tiles: rows = head-dim 16n + 4g + reg, col = query.  Key-tile pair outermost (one scalar branch per pair, four independent
-    // accumulators inside) instead of a branch in front of every MFMA.
+    const uint32_t tm1 = (p.drop.thresh - 1u) * 0x10001u;          // (threshold - 1) in both halves: hash half <= thresh - 1 = dropped
+    const uint32_t ones = 0x00010001u;
+    float sum = 0.f;
     f32x4 o[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) o[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < NT / 2; ++u) {
         if (!((live >> (2 * u)) & 3u)) continue;       // both key tiles of the pair dead: P = 0 exactly
+        uint32_t pw[4];                                // words 2hh, 2hh+1 = the four probabilities of tile 2u+hh
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int t = 2 * u + hh;
+            float pr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pr[r] = __builtin_amdgcn_exp2f(s[t][r] - mx);
+                sum += pr[r];
+            }
+            pw[2 * hh] = pack_f16x2(pr[0], pr[1]);
+            pw[2 * hh + 1] = pack_f16x2(pr[2], pr[3]);
+            if (DROP) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const uint32_t hj = mix32(pk0 + (uint32_t)(8 * t + j) * VLP_PHI);      // low half: key 4g + 2j, high half: key 4g + 2j + 1
+                    pw[2 * hh + j] = pk_mul_lo_u16(pw[2 * hh + j], pk_min_u16(pk_sub_sat_u16(hj, tm1), ones));      // keep word: 0 = dropped (hash half < threshold), 1 = kept
+                }
+            }
+        }
         f16x8 vfr[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) vfr[n] = tr_frag(Vs, 32 * u, 32 * u + 16, 16 * n, g, li);
-        const f16x8 pfu = words_f16x8(pfw[u][0], pfw[u][1], pfw[u][2], pfw[u][3]);
+        const f16x8 pfu = words_f16x8(pw[0], pw[1], pw[2], pw[3]);
 #pragma unroll
         for (int n = 0; n < 4; ++n) o[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfr[n], pfu, o[n], 0, 0, 0);
     }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = p.drop.scale / sum;
+    if (p.lse && g == 0 && q < nq) p.lse[((int64_t)b * p.heads + h) * Lq + q] = (mx + __builtin_amdgcn_logf(sum)) * LN2_F;
     if (q < nq) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -323,6 +335,18 @@ DEVFN void attn_fwd_tile(const AttnParams& p, const f16* Ks, const f16* Vs, cons
         }
     }
     if (first) TRACE(6);       // first tile stored
+#ifdef VLP_ISA_MARKERS
+    asm volatile("; TILE_END drop=%0" :: "n"((int)DROP));
+#endif
+}
+// load + compute of one tile (the streaming kernel's form)
+template <int NT, bool DROP>
+DEVFN void attn_fwd_tile(const AttnParams& p, const f16* Ks, const f16* Vs, const f16* qbase, int b, int h, int L, int Lq, int nq, int64_t rbo,
+                         int qt, int g, int li, int wid, int lane, bool first) {
+    f16x8 qf[2];
+    uint32_t mw[NT <= 12 ? NT : 1];
+    attn_fwd_tile_load<NT>(p, qbase, b, Lq, nq, qt, g, li, qf, mw);
+    attn_fwd_tile_compute<NT, DROP>(p, Ks, Vs, b, h, L, Lq, nq, rbo, qt, g, li, wid, lane, first, qf, mw);
 }
 
 template <int NT, int NW>   // NT = LP / 16 key tiles (4, 8, 12 or 16)
@@ -351,6 +375,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
     const f16* kpre = p.n_prefix ? p.k2 + (int64_t)(b / p.beams) * p.bs_kv2 * p.ld_kv + h * HD : nullptr;
     const f16* vpre = p.n_prefix ? p.v2 + (int64_t)(b / p.beams) * p.bs_kv2 * p.ld_kv + h * HD : nullptr;
     TRACE(0);
+    // the wave's first query tile: its Q fragments and mask words are requested BEFORE the K / V rows and arrive with them
+    const int nqt = (nq + 15) / 16;
+    f16x8 qf[2];
+    uint32_t mw[NT <= 12 ? NT : 1];
+    if (wid < nqt) attn_fwd_tile_load<NT>(p, qbase, b, Lq, nq, wid, g, li, qf, mw);
     if (p.n_prefix) {       // beam decode: rows < n_prefix come from the per-sample prefix cache
         stage_rowmajor(Ks, kbase, p.ld_kv, L, LP, tid, NW * 64, kpre, p.n_prefix);
         stage_rowmajor(Vs, vbase, p.ld_kv, L, LP, tid, NW * 64, vpre, p.n_prefix);
@@ -363,9 +392,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
 
     // (Round 4, measured and not kept: requesting the Q fragments + mask words of the wave's NEXT query tile while the current one is
     // computed -- 149 instead of 108 VGPRs, same 3 workgroups per CU -- 36.5 us against 34.3 us at B = 64, tools/attn_lab.py.)
-    const int nqt = (nq + 15) / 16;
     for (int qt = wid; qt < nqt; qt += NW) {
-        attn_fwd_tile<NT>(p, Ks, Vs, qbase, b, h, L, Lq, nq, rbo, qt, g, li, wid, lane, qt == wid);
+        if (qt != wid) attn_fwd_tile_load<NT>(p, qbase, b, Lq, nq, qt, g, li, qf, mw);
+        if (p.drop.thresh) attn_fwd_tile_compute<NT, true>(p, Ks, Vs, b, h, L, Lq, nq, rbo, qt, g, li, wid, lane, qt == wid, qf, mw);
+        else attn_fwd_tile_compute<NT, false>(p, Ks, Vs, b, h, L, Lq, nq, rbo, qt, g, li, wid, lane, qt == wid, qf, mw);
     }
     TRACE(7);
 }
@@ -483,7 +513,8 @@ __global__ __launch_bounds__(AFS_WAVES * 64, 1) void attn_fwd_stream_kernel(Attn
             t = __builtin_amdgcn_readfirstlane(t) - task_base[bk];
             if (t >= nqt) break;
             if (!waited) { wait_ge(ready + bk, AFS_WAVES * (k / AFS_NBUF + 1)); waited = true; }
-            attn_fwd_tile<NT>(p, Ks, Vs, qbase, b, h, L, Lq, nq, rbo, t, g, li, wid, lane, false);
+            if (p.drop.thresh) attn_fwd_tile<NT, true>(p, Ks, Vs, qbase, b, h, L, Lq, nq, rbo, t, g, li, wid, lane, false);
+            else attn_fwd_tile<NT, false>(p, Ks, Vs, qbase, b, h, L, Lq, nq, rbo, t, g, li, wid, lane, false);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // this tile's K / V fragment reads have returned
             if (lane == 0) __hip_atomic_fetch_add(done + bk, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
