@@ -405,12 +405,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : (NT <= 12 ? 4 : 2)) void att
 // forward, persistent streaming form (round 5; the training shape 129 <= L <= 192, NT = 12)
 // =================================================================================================
 // INVESTIGATION BUILDS ONLY (-DVLP_LAB_BUILD, VLP_ATTN_FWD_STREAM=1): built in round 5 as asked by two verdicts, bit-identical to the kernel
-// above, 35.0 -> 32.4 us per layer in the cold-operand lab (B = 64; 15.8 us for one item per workgroup, +8.2 us per further item) and NO
-// gain in the step (9.511 / 9.516 vs 9.524 / 9.512 ms/step, profiles/r05_attention_forward_streaming_lab.txt): inside the step the
-// packed QKV rows were written by the previous kernel and come from L2 / the Infinity Cache, so the load phase this design hides is
-// already short, and the tiles themselves are VALU-issue-bound (~1 300 VALU instructions per 16-query tile, ~27 per score: exp2, mask
-// term, dropout hash, fp16 packing; 12 waves keep the four SIMDs ~78 % busy at 8.2 us per item).  What would move it is fewer
-// instructions per score, not another schedule.
+// above, 35.0 -> 32.4 us per layer in the cold-operand lab with the first tile code (B = 64; 15.8 us for one item per workgroup, +8.2 us per
+// further item) and NO gain in the step (9.511 / 9.516 vs 9.524 / 9.512 ms/step, profiles/r05_attention_forward_streaming_lab.txt): inside
+// the step the packed QKV rows were written by the previous kernel and come from L2 / the Infinity Cache, so the load phase this design
+// hides is already short.  With the rewritten tile (889 instead of ~1 400 VALU instructions) and the first tile's loads ahead of the staging
+// the plain kernel caught up: 30.4 us both (profiles/r05_attention_forward_tile_rewrite.txt).  A second form -- static rotating tile
+// assignment, so that a wave's next tile is known and its Q / mask loads can be requested one item ahead -- was bit-identical and SLOWER
+// (35.0 us, +0.045 ms/step): the dynamic hand-out below is worth more than the hidden round trip.  It lives in the history only.
 // The kernel above starts all B x heads workgroups at once: every one of them first waits for its K / V rows, then computes, three 4-wave
 // workgroups per CU in the same phase -- 32 us per layer at B = 64 where the VALU work of the tiles (the forward is VALU-issue-bound:
 // exp2, mask term, dropout hash, fp16 packing: ~27 instructions per score) is ~14 us per CU.  Here ONE 12-wave workgroup per CU walks its
@@ -523,122 +524,6 @@ __global__ __launch_bounds__(AFS_WAVES * 64, 1) void attn_fwd_stream_kernel(Attn
     }
 }
 
-
-// Second streaming form (round 5, late; VLP_ATTN_FWD_STREAM=2): the same producer side, but the consumer side is STATIC -- wave w computes tile
-// (w + k) mod 12 of its workgroup's k-th item (a rotation, so that the cheap region-row tiles and the expensive text-row tiles change hands
-// every item) -- which makes the next tile known one item ahead: its Q fragments and mask words are requested before the current tile is
-// computed and travel under it.  In the first form every tile started with an exposed load round trip (12 waves, ~1 tile per wave and item:
-// nothing else to hide it), which is where its per-item time went.  The tile code is attn_fwd_tile_compute: identical bits.
-template <int NT>
-__global__ __launch_bounds__(AFS_WAVES * 64, 1) void attn_fwd_stream2_kernel(AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int LP = NT * 16, TILE = LP * HD, NTHR = AFS_WAVES * 64;
-    constexpr int IT = (LP * 8 + NTHR - 1) / NTHR;                 // 16-byte pieces per thread and tile (2 at LP = 192)
-    f16* bufs = reinterpret_cast<f16*>(smem_raw);                  // [AFS_NBUF][K | V][LP][64] swizzled
-    int* ctr = reinterpret_cast<int*>(bufs + AFS_NBUF * 2 * TILE); // done[3] | ready[3]
-    int* done = ctr + 4; int* ready = ctr + 8;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, li = lane & 15;
-    const int L = p.Lk, Lq = p.Lq;
-    const int nitems = p.B * p.heads;
-    const int n_my = ((int)blockIdx.x < nitems) ? (nitems - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-    if (tid < 12) ctr[tid] = 0;
-    __syncthreads();
-    if (n_my == 0) return;
-
-    u32x4 rk[IT], rv[IT];
-    auto rows_of = [&](int item, int& b_, int& h_, int& rb_, int& nb_) {
-        b_ = item / p.heads; h_ = item % p.heads;
-        rb_ = p.row_off ? p.row_off[b_] : b_ * (int)p.bs_kv;
-        nb_ = p.row_off ? p.row_off[b_ + 1] - rb_ : L;
-    };
-    auto request = [&](int item) {          // this thread's pieces of the item's K and V rows -> registers (rows >= nb read as zero)
-        int b_, h_, rb_, nb_;
-        rows_of(item, b_, h_, rb_, nb_);
-        const __amdgpu_buffer_rsrc_t r0 = rows_rsrc(p.k + (int64_t)rb_ * p.ld_kv + h_ * HD, p.ld_kv, nb_),
-                                     r1 = rows_rsrc(p.v + (int64_t)rb_ * p.ld_kv + h_ * HD, p.ld_kv, nb_);
-#pragma unroll
-        for (int i = 0; i < IT; ++i) {
-            const int idx = tid + i * NTHR, r = idx >> 3, c = idx & 7;
-            rk[i] = __builtin_amdgcn_raw_buffer_load_b128(r0, (r * (int)p.ld_kv + c * 8) * 2, 0, 0);
-            rv[i] = __builtin_amdgcn_raw_buffer_load_b128(r1, (r * (int)p.ld_kv + c * 8) * 2, 0, 0);
-        }
-    };
-    auto publish = [&](int buf) {           // registers -> LDS buffer `buf`, then this wave's share is announced
-        f16* Kd = bufs + buf * 2 * TILE;
-        f16* Vd = Kd + TILE;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < IT; ++i) {
-            const int idx = tid + i * NTHR, r = idx >> 3, c = idx & 7;
-            if (idx < LP * 8) {
-                *reinterpret_cast<u32x4*>(Kd + r * HD + ((c ^ swzk(r)) << 3)) = rk[i];
-                *reinterpret_cast<u32x4*>(Vd + r * HD + ((c ^ swzk(r)) << 3)) = rv[i];
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(ready + buf, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    auto wait_ge = [&](int* c, int target) {
-        while (__hip_atomic_load(c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
-    };
-    // the wave's tile of its workgroup's k-th item and that tile's loads (nothing when the rotation lands past the item's last tile)
-    auto tile_of = [&](int k, int nqt) { const int t = (wid + k) % AFS_WAVES; return t < nqt ? t : -1; };
-    auto prefetch = [&](int k, f16x8 (&qf)[2], uint32_t (&mw)[NT]) {
-        int b_, h_, rb_, nb_;
-        rows_of(blockIdx.x + k * gridDim.x, b_, h_, rb_, nb_);
-        const int nq_ = p.row_off ? nb_ : Lq;
-        const int t = tile_of(k, (nq_ + 15) / 16);
-        if (t >= 0) {
-            const int64_t rbq = p.row_off ? (int64_t)rb_ : (int64_t)b_ * p.bs_q;
-            attn_fwd_tile_load<NT>(p, p.q + rbq * p.ld_q + h_ * HD, b_, Lq, nq_, t, g, li, qf, mw);
-        }
-    };
-
-    int done_base[AFS_NBUF] = {0, 0, 0};      // per buffer: finished tiles of earlier occupants
-    f16x8 qfA[2], qfB[2];
-    uint32_t mwA[NT], mwB[NT];
-    request(blockIdx.x);
-    prefetch(0, qfA, mwA);
-    publish(0);
-    if (n_my > 1) request(blockIdx.x + gridDim.x);
-    auto step = [&](int k, f16x8 (&qfc)[2], uint32_t (&mwc)[NT], f16x8 (&qfn)[2], uint32_t (&mwn)[NT]) {
-        const int bk = k % AFS_NBUF;
-        const int item = blockIdx.x + k * gridDim.x;
-        int b, h, rb, nb;
-        rows_of(item, b, h, rb, nb);
-        const int nq = p.row_off ? nb : Lq;
-        const int nqt = (nq + 15) / 16;
-        // ---- producer: item k+1 into its buffer (free once item k-2 is consumed); then the loads that travel under this item's tile: the
-        // wave's tile of item k+1 (Q, mask words) and the K / V rows of item k+2
-        if (k + 1 < n_my) {
-            const int bn = (k + 1) % AFS_NBUF;
-            wait_ge(done + bn, done_base[bn]);
-            publish(bn);
-            prefetch(k + 1, qfn, mwn);
-            if (k + 2 < n_my) request(blockIdx.x + (k + 2) * gridDim.x);
-        }
-        // ---- consumer: this wave's tile of item k
-        const int t = tile_of(k, nqt);
-        if (t >= 0) {
-            const f16* Ks = bufs + bk * 2 * TILE;
-            const f16* Vs = Ks + TILE;
-            const int64_t rbo = p.row_off ? (int64_t)rb : (int64_t)b * Lq;
-            wait_ge(ready + bk, AFS_WAVES * (k / AFS_NBUF + 1));
-            if (p.drop.thresh) attn_fwd_tile_compute<NT, true>(p, Ks, Vs, b, h, L, Lq, nq, rbo, t, g, li, wid, lane, false, qfc, mwc);
-            else attn_fwd_tile_compute<NT, false>(p, Ks, Vs, b, h, L, Lq, nq, rbo, t, g, li, wid, lane, false, qfc, mwc);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // this tile's K / V fragment reads have returned
-            if (lane == 0) __hip_atomic_fetch_add(done + bk, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        done_base[bk] += nqt;
-    };
-#pragma unroll 1
-    for (int k = 0; k < n_my; k += 2) {
-        step(k, qfA, mwA, qfB, mwB);
-        if (k + 1 < n_my) step(k + 1, qfB, mwB, qfA, mwA);
-    }
-}
 
 #endif      // VLP_LAB_BUILD (streaming forward)
 
@@ -1492,16 +1377,12 @@ static int launch_attn_fwd(AttnParams& p, hipStream_t s) {
     // persistent streaming kernel (identical bits; no gain in the step, see the note above it)
     if (LP == 192 && p.n_prefix == 0 && p.Lq == p.Lk && p.lse != nullptr) {
         const char* e = getenv("VLP_ATTN_FWD_STREAM");
-        if (e && (e[0] == '1' || e[0] == '2')) {
+        if (e && e[0] == '1') {
             static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n; }();
             const int items = p.B * p.heads;
             const size_t smem = (size_t)AFS_NBUF * 2 * LP * HD * 2 + 64;
-            VLP_ONCE_PER_DEVICE({
-                (void)hipFuncSetAttribute((const void*)attn_fwd_stream_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-                (void)hipFuncSetAttribute((const void*)attn_fwd_stream2_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            });
-            if (e[0] == '2') hipLaunchKernelGGL((attn_fwd_stream2_kernel<12>), dim3(items < ncu ? items : ncu), dim3(AFS_WAVES * 64), smem, s, p);
-            else hipLaunchKernelGGL((attn_fwd_stream_kernel<12>), dim3(items < ncu ? items : ncu), dim3(AFS_WAVES * 64), smem, s, p);
+            VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)attn_fwd_stream_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL((attn_fwd_stream_kernel<12>), dim3(items < ncu ? items : ncu), dim3(AFS_WAVES * 64), smem, s, p);
             VLP_CHECK_LAUNCH("vlp_attn_fwd");
             return VLP_OK;
         }
