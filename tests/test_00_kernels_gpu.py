@@ -49,7 +49,11 @@ def drop_mult_ref(p, seed, stream, rows, cols, device=DEV):
 
 
 def rel(a, b):
-    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+    """max(max-normalised error, relative L2 error): the first bounds the worst element against the tensor's scale, the second is not
+    blind to errors spread over the many small elements (VERDICT r4 weak #3)."""
+    a, b = a.detach().double(), b.detach().double()
+    d = a - b
+    return max(float(d.abs().max() / (b.abs().max() + 1e-30)), float(d.norm() / (b.norm() + 1e-30)))
 
 
 def h16(*shape, scale=1.0, gen=None):
