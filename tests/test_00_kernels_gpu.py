@@ -655,6 +655,73 @@ def test_attention_dropout_exact_mask(gen):
     assert rel(dqkv.float(), q64.grad) < 5e-3
 
 
+@pytest.mark.parametrize("L,Nv", [(167, 100), (50, 30), (100, 36), (223, 100)])
+def test_attention_forward_dropout_decisions(L, Nv, gen):
+    """EVERY keep / drop decision of the forward, not a tolerance: V is one-hot over a window of 64 keys (zero elsewhere), so the context row
+    of a query IS its dropped, normalised probability row over that window -- an entry is exactly 0 iff it was dropped (attended
+    probabilities are >> the fp16 underflow).  Compared with the Python mirror of the hash (16-bit half < threshold = dropped)."""
+    B, heads, p, seed, stream = 3, 2, 0.25, 21, 5
+    H = heads * 64
+    gc = torch.Generator().manual_seed(8)
+    mask = _mask(B, L, Nv, gc).to(DEV)
+    Lp = (L + 31) // 32 * 32
+    mb = torch.empty(B, L, Lp, device=DEV, dtype=torch.uint8)
+    K.mask_pack(mask, mb, B, L, Lp)
+    keep_ref = drop_mult_ref(p, seed, stream, range(B * heads * L), range(L)).view(B, heads, L, L) > 0
+    qkv = h16(B * L, 3 * H, scale=0.25, gen=gen)               # small scores: attended probabilities stay near 1 / (attended keys)
+    checked = 0
+    for k0 in range(0, L, 64):
+        kw = min(64, L - k0)
+        v = torch.zeros(B, L, heads, 64, device=DEV, dtype=torch.half)
+        for j in range(kw):
+            v[:, k0 + j, :, j] = 1.0
+        qkv.view(B, L, 3, heads, 64)[:, :, 2] = v
+        ctx = torch.zeros(B * L, H, device=DEV, dtype=torch.half)
+        lse = torch.zeros(B, heads, L, device=DEV)
+        K.attn_fwd(qkv, mb, ctx, lse, B, L, heads, 0.125, dropout_p=p, seed=seed, rng_stream=stream)
+        got = ctx.view(B, L, heads, 64).permute(0, 2, 1, 3)[..., :kw] != 0            # [B, heads, q, key in window]
+        # attended keys carry a probability; a query row with NO attended key (padding rows) is uniform over all L keys, as in the reference
+        rowlive = (mask != 0).any(-1)                                                  # [B, L]
+        att = ((mask[:, :, k0:k0 + kw] != 0) | ~rowlive[:, :, None])[:, None].expand(B, heads, L, kw)
+        want = keep_ref[..., k0:k0 + kw] & att
+        assert torch.equal(got, want), "window at key %d: %d decisions differ" % (k0, int((got != want).sum()))       # (masked keys of a live row: exactly 0)
+        checked += int(att.sum())
+    assert checked > B * heads * L * 8
+
+
+@pytest.mark.parametrize("L,Nv", [(167, 100), (50, 30), (100, 36)])
+def test_attention_backward_dropout_decisions(L, Nv, gen):
+    """The backward recomputes the forward's dropout: with dO one-hot over a window of 64 queries, dV[key, j] = Pd[query q0 + j, key], so the
+    zero pattern of dV is the backward's keep / drop decision per (query, key) -- compared with the mirror of the hash, exactly."""
+    B, heads, p, seed, stream = 2, 2, 0.25, 33, 2
+    H = heads * 64
+    gc = torch.Generator().manual_seed(9)
+    mask = _mask(B, L, Nv, gc).to(DEV)
+    Lp = (L + 31) // 32 * 32
+    mb = torch.empty(B, L, Lp, device=DEV, dtype=torch.uint8)
+    mt = torch.empty(B, Lp, Lp, device=DEV, dtype=torch.uint8)
+    K.mask_pack(mask, mb, B, L, Lp, out_t=mt)
+    keep_ref = drop_mult_ref(p, seed, stream, range(B * heads * L), range(L)).view(B, heads, L, L) > 0
+    qkv = h16(B * L, 3 * H, scale=0.25, gen=gen)
+    ctx = torch.zeros(B * L, H, device=DEV, dtype=torch.half)
+    lse = torch.zeros(B, heads, L, device=DEV)
+    K.attn_fwd(qkv, mb, ctx, lse, B, L, heads, 0.125, dropout_p=p, seed=seed, rng_stream=stream)
+    rowlive = (mask != 0).any(-1)
+    carries = ((mask != 0) | ~rowlive[:, :, None])[:, None].expand(B, heads, L, L)      # (query, key) pairs with a non-zero probability
+    for q0 in range(0, L, 64):
+        qw = min(64, L - q0)
+        dctx = torch.zeros(B, L, heads, 64, device=DEV, dtype=torch.half)
+        for j in range(qw):
+            dctx[:, q0 + j, :, j] = 1.0
+        dqkv = torch.zeros(B * L, 3 * H, device=DEV, dtype=torch.half)
+        delta = torch.zeros(B, heads, L, device=DEV)
+        K.attn_bwd(qkv, mb, mt, ctx, dctx.view(B * L, H), lse, dqkv, delta, B, L, heads, 0.125, dropout_p=p, seed=seed, rng_stream=stream)
+        dv = dqkv.view(B, L, 3, heads, 64)[:, :, 2]                                      # [B, key, heads, j]
+        got = (dv != 0).permute(0, 2, 3, 1)[:, :, :qw]                                   # [B, heads, query q0 + j, key]
+        want = (keep_ref & carries)[:, :, q0:q0 + qw]
+        assert torch.equal(got, want), "query window at %d: %d decisions differ" % (q0, int((got != want).sum()))
+
+
 # =====================================================================================================
 # layernorm
 # =====================================================================================================
