@@ -45,7 +45,11 @@ DEVFN int swz_w(int r) { return (((r >> 4) & 3) << 1) | ((r >> 1) & 1); }
 //    paying one L2 round trip per k tile) the 128x128 ring (variant 17) is the latency-hiding kernel; the autotuner picks it there.
 // BM_T: rows of the block tile (128 -> 4 waves 2x2, 256 -> 8 waves 4x2); the wave tile is always 64x64.
 // NSR: stages of the VARIANT 3 ring (0 = default: 3 for 256-row tiles, 4 for 128x128).
-template <int VARIANT, int BM_T, int BN_T, bool SG, int NSR = 0>
+// EPI: 0 = the shared epilogue (every mode, run-time switches); 1 = "multiply by a stored tensor" only (the FFN-down dgrad: alpha * acc (+ bias)
+//      times mulsrc, nothing else; N % 16 == 0): the lane's eight multiplier vectors are requested TOGETHER before the first one is used.  In the
+//      shared epilogue each 8-wide vector sits behind its own run-time branches -- load, full vmcnt wait, multiply, store, eight times in a row per
+//      lane: the stored-derivative multiply cost 14 us on a 59 us GEMM (10 688 x 768 x 3072).  Same arithmetic, same bits.
+template <int VARIANT, int BM_T, int BN_T, bool SG, int NSR = 0, int EPI = 0>
 __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BN_T == 256 ? 4 : BM_T / 128) : ((VARIANT == 2 || BN_T == 256) ? 4 : 2))) void gemm_nt_kernel(GemmNtParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     f16* smem = reinterpret_cast<f16*>(smem_raw);
@@ -313,6 +317,34 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64, (VARIANT == 3 ? (BN
             for (int j = 0; j < 16; ++j) if (ncol0 + j < p.N) bias_v[j] = (float)p.bias[ncol0 + j];
         }
     }
+    if constexpr (EPI == 1) {
+        if (ncol0 >= p.N) return;
+        f16x8 mv[4][2];
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+            const int mc = min(m0 + wm * 64 + 16 * tm + li, p.M - 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) mv[tm][h] = ld8(p.mulsrc + (int64_t)mc * p.ldm + ncol0 + 8 * h);
+        }
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+            const int m = m0 + wm * 64 + 16 * tm + li;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = 8 * h + j;
+                    float vj = acc[tm][c >> 2][c & 3] * p.alpha + bias_v[c];
+                    vj *= (float)mv[tm][h][j];
+                    o[j] = (f16)vj;
+                }
+                ST8_OUT(p, p.Y + (int64_t)m * p.ldy + ncol0 + 8 * h, o);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm) {
         const int m = m0 + wm * 64 + 16 * tm + li;
@@ -455,7 +487,20 @@ extern "C" int vlp_gemm_nt(const vlp_gemm_nt_args* a, void* stream) {
             if ((variant & 48) == 48) { const int rc = vlp_gemm_nt_k32_launch(p, sg, s); if (rc != VLP_OK) return rc; }      /* 53 / 61: k tiles of 32, 4 stages */
             else
 #endif
-            if (variant & 16) LAUNCH_RING(256, 256, 2);
+            if (variant & 16) {
+                // the stored-tensor multiply alone (FFN-down dgrad): lean epilogue instantiation (VLP_NT_LEAN_EPI=0: the shared one, for A/B runs)
+                static const int lean_on = [] { const char* e = getenv("VLP_NT_LEAN_EPI"); return (e && e[0] == '0') ? 0 : 1; }();
+                const bool lean = lean_on && !sg && p.act == VLP_ACT_NONE && !p.preact && p.mulmode == VLP_MUL_PLAIN && !p.drop.thresh && !p.residual &&
+                                  p.N % 16 == 0 && p.ldm % 8 == 0 && ((uintptr_t)p.mulsrc & 15) == 0;
+                if (lean) {
+                    const size_t smem = (size_t)2 * (256 + 256) * BK * sizeof(f16);
+                    VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm_nt_kernel<3, 256, 256, false, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                    p.tiles_n = cdiv(a->N, 256);
+                    hipLaunchKernelGGL((gemm_nt_kernel<3, 256, 256, false, 2, 1>), dim3(cdiv(a->M, 256) * p.tiles_n), dim3(1024), smem, s, p);
+                } else {
+                    LAUNCH_RING(256, 256, 2);
+                }
+            }
             else LAUNCH_NT(1, 256, 256, 2);
             break;
         default: LAUNCH_NT(1, 128, 128, 2); break;
