@@ -165,6 +165,46 @@ def cpu_baseline(seconds_budget=20.0, hard_timeout=240.0):
         return {"value": None, "unit": "samples/s", "cores": threads, "kind": "port", "sample": "timed out after %ds" % hard_timeout}
 
 
+def parity_block(p32, model, batch, tasks, dev):
+    """Parity ON THE DRIVER'S RECORD (VERDICT r5 #6a): before anything is timed, the bench model itself -- full size, dropout off -- against the
+    oracle evaluated on the device (oracle/ = the CHECKER here, never the thing measured): max-rel error of the head logits vs the fp32 truth,
+    vs the reference's fp16 arithmetic, the reference-fp16's own error, and the distance between two reference-fp16 evaluations that differ only
+    in summation order (the noise floor of fp16 arithmetic on this network).  Same protocol and numbers as tests/test_20_fullsize_gpu.py."""
+    from oracle import vlp_oracle as O
+    from vlp_amd import synthetic as S
+    key = "vqa_logits" if tasks == "vqa2" else "mlm_logits"
+
+    def relmax(a, b):
+        return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+    def oracle(dtype, *flags):
+        pd = {k: v.to(dev).to(dtype) for k, v in p32.items()}
+        with torch.no_grad(), O.rounding(*flags):
+            return O.forward_pretraining_loss_mask(pd, S.batch_to(batch, dev), tasks=tasks)
+    was_training = model.training
+    model.eval()
+    b = S.batch_to(batch, dev, half=True)
+    with torch.no_grad():
+        losses = model(b.img, b.vis_pe, b.input_ids, b.segment_ids, b.input_mask, b.lm_label_ids, b.ans_labels, b.is_next, masked_pos=b.masked_pos,
+                       masked_weights=b.masked_weights, task_idx=b.task_idx, drop_worst_ratio=0.0)
+    torch.cuda.synchronize()
+    truth = oracle(torch.float32)
+    t = truth[key].float()
+    ours = (model.last_vqa_logits if tasks == "vqa2" else model.last_mlm_logits).float().reshape(t.shape)
+    r16 = oracle(torch.float16)[key].float().reshape(t.shape)
+    r16b = oracle(torch.float16, "sum_order")[key].float().reshape(t.shape)
+    model.train(was_training)
+    out = {"logits": key, "shape": list(t.shape), "metric": "max |a - b| / max |b|",
+           "hip_vs_fp32_oracle": round(relmax(ours, t), 6), "hip_vs_reference_fp16_oracle": round(relmax(ours, r16), 6),
+           "reference_fp16_vs_fp32_oracle": round(relmax(r16, t), 6), "reference_fp16_summation_order_spread": round(relmax(r16b, r16), 6),
+           "loss_hip": round(float((losses[0] + losses[1] + losses[2]).sum()), 5), "loss_fp32_oracle": round(float(truth["loss"].sum()), 5),
+           "north_star_tolerance": 1e-3,
+           "note": "full size (B x L x layers of this run), dropout off, the weights of the timed model; the literal 1e-3 is below the noise floor of fp16 "
+                   "arithmetic at this depth (the spread entry; DESIGN.md section 4): the tests bound hip_vs_fp32 by the reference-fp16's own error + 1e-3"}
+    out["hip_closer_to_fp32_than_reference_fp16"] = out["hip_vs_fp32_oracle"] <= out["reference_fp16_vs_fp32_oracle"]
+    return out
+
+
 def main():
     if len(sys.argv) >= 2 and sys.argv[1] == "--cpu-baseline-only":
         print(json.dumps(cpu_baseline_worker(float(sys.argv[2]), int(sys.argv[3]))))
@@ -183,6 +223,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-varlen", action="store_true", help="skip the second, padding-free (packed) leg reported under config.varlen")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity object (full-size logits vs the oracle on the device, before timing)")
+    ap.add_argument("--pool", type=int, default=8, help="device-resident synthetic batches cycled by the timed steps (config.batch_pool)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL + the DDP wrapper even for one rank (path check)")
     args = ap.parse_args()
 
@@ -218,8 +260,26 @@ def main():
     torch.manual_seed(0)
     cfg = BertConfig(28996, num_hidden_layers=args.layers, type_vocab_size=6, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
     model = BertForPreTrainingLossMask(cfg, num_labels=2, enable_butd=True, len_vis_input=100, tasks=args.tasks, allow_random_fc7=True)
+    p32, parity_err = None, None
+    if not args.no_parity:
+        # random-init weights of the architecture, drawn by the oracle's initialiser (init_bert_weights, N(0, 0.02): modeling.py:539-551) so that the
+        # parity block below can evaluate the SAME network in fp32 / reference-fp16; every rank loads the same values
+        try:
+            from oracle import vlp_oracle as O
+            p32 = O.init_params(vocab_size=28996, layers=args.layers, tasks=args.tasks, seed=0)
+            sd = dict(p32)
+            sd["cls.predictions.decoder.weight"] = p32["bert.embeddings.word_embeddings.weight"]
+            model.load_state_dict(sd, strict=True)
+        except Exception as e:      # noqa: BLE001
+            p32 = None
+            parity_err = "oracle unavailable: %r" % (e,)
     model.half().to(dev)
     eng = model.engine
+    # `value` is the DENSE step (BASELINE.json's workload: all L positions of every sample); the padding-free step is the second leg below.
+    # VLP_VARLEN=1 in the environment makes the FIRST leg packed (profiling runs) and the line says so.
+    env_varlen = eng.varlen is True
+    if not env_varlen:
+        eng.varlen = False
     if use_dist:
         model = DDP(model, device_ids=[dev_index], output_device=dev_index, find_unused_parameters=True)
     named = list(model.named_parameters())
@@ -232,8 +292,20 @@ def main():
     opt.pipeline_with_forward = os.environ.get("VLP_ADAM_PIPELINE", "0") == "1"
     model.train()
     pool = [S.batch_to(S.make_batch(args.batch, max_len_b=args.max_len_b, vocab_size=28996, max_pred=1 if args.tasks == "vqa2" else 3,
-                                    s2s_prob=args.s2s_prob, tasks=args.tasks, seed=1234 + 100 * rank + i), dev, half=True) for i in range(2)]
+                                    s2s_prob=args.s2s_prob, tasks=args.tasks, seed=1234 + 100 * rank + i), dev, half=True) for i in range(max(1, args.pool))]
     t_total = 100000
+    parity = None
+    if not args.no_parity and rank == 0 and world == 1:
+        if p32 is None:
+            parity = {"error": parity_err}
+        else:
+            try:
+                parity = parity_block(p32, model, S.make_batch(args.batch, max_len_b=args.max_len_b, vocab_size=28996, max_pred=1 if args.tasks == "vqa2" else 3,
+                                                               s2s_prob=args.s2s_prob, tasks=args.tasks, seed=1234), args.tasks, dev)
+            except Exception as e:      # noqa: BLE001
+                parity = {"error": repr(e)}
+            torch.cuda.empty_cache()
+    p32 = None
 
     def one(i):
         return train_step(model, opt, pool[i % len(pool)], 3e-5 * warmup_linear((i + 1) / t_total, 0.1))
@@ -295,7 +367,7 @@ def main():
     # ---- second leg: the padding-free (packed) step (Engine.varlen) on the SAME batches, timed the same way.  `value`
     # above stays the dense run; this leg is reported under config.varlen with its EXECUTED work (rows, flops) beside it.
     varlen = None
-    env_varlen = bool(eng.varlen)        # VLP_VARLEN=1 in the environment: the FIRST leg above already ran packed (profiling runs); say so below
+    imbalance = None
     if not args.no_varlen and not env_varlen:
         eng.varlen = True
         step0 = args.warmup + 2 * args.steps
@@ -326,6 +398,13 @@ def main():
             tt = torch.tensor([dtv], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dtv = float(tt)
+            # load imbalance of the packed step: every rank's GEMMs run over ITS sum of kept lengths, the all-reduce waits for the busiest rank
+            rr = torch.tensor([rows / max(args.steps, 1)], device=dev, dtype=torch.float64)
+            allr = [torch.zeros_like(rr) for _ in range(world)]
+            dist.all_gather(allr, rr)
+            per_rank = [float(v) for v in allr]
+            imbalance = {"max_over_mean_rows": round(max(per_rank) / (sum(per_rank) / world), 4), "rows_per_rank": [round(v, 1) for v in per_rank],
+                         "note": "synthetic pools are seeded per rank (no loader): vlp_amd.data.balanced_epoch_order brings this to <= 1.001 on real shards"}
         eng.varlen = False
         # executed dense-contraction work per sample, fwd + bwd = 3 x fwd (SURVEY.md 8d's accounting on the KEPT rows): per kept position and layer
         # 7 077 888 GEMM MACs + 2 n_b H attention MACs; region projections and the LM head do not depend on the caption length
@@ -339,7 +418,7 @@ def main():
         ex_gflop = sum(gf) / len(gf)
         sps = world * args.batch * args.steps / dtv
         varlen = {"value": round(sps, 2), "unit": "samples/s", "ms_per_step": round(dtv / args.steps * 1e3, 3),
-                  "real_rows_per_step": round(rows / args.steps, 1), "dense_rows_per_step": args.batch * (args.max_len_b + 103),
+                  "real_rows_per_step": round(rows / args.steps, 1), "dense_rows_per_step": args.batch * (args.max_len_b + 103), "rank_imbalance": imbalance,
                   "executed_gflop_per_sample": round(ex_gflop, 3), "dense_gflop_per_sample": FLOP_PER_SAMPLE / 1e9,
                   "step_mfma_frac_executed": round(sps / world * ex_gflop * 1e9 / (MFMA_PEAK_TFLOPS * 1e12), 4),
                   "final_loss": round(float((lt_v[0] + lt_v[1] + lt_v[2]).sum().detach()), 4),
@@ -384,6 +463,7 @@ def main():
                "config": {"workload": "%s: BERT-base %dL, 100 regions x 2048-d, seq_len %d (L=%d), bs %d/GPU, "
                                       "fwd+bwd+FP16 FusedAdam, dropout 0.1, dynamic loss scale" % (shape_name, args.layers, args.max_len_b, args.max_len_b + 103, args.batch),
                           "global_batch": world * args.batch, "parallelism": "dp%d" % world, "final_loss": round(loss, 4),
+                          "batch_pool": len(pool),       # distinct device-resident batches the steps cycle through (masks, lengths, cache contents repeat with this period)
                           "loss_scale": opt.cur_scale, "skipped_steps": opt.skipped_steps,
                           "rccl_ranks": dist.get_world_size() if use_dist else 1, "rank_param_checksums_equal": ranks_equal,
                           # "sharded" (VLP_DDP_MODE=sharded, N > 1): reduce-scatter, Adam on 1/N of the state per rank, parameter all-gather
@@ -397,7 +477,9 @@ def main():
                           "comm": comm,
                           "param_checksum": [float(eng.flat[k].float().sum()) for k in ("decay", "nodecay")] + [float(eng.flat["decay"].float().abs().sum())],
                           "varlen": varlen, "first_leg_packed": env_varlen},
-               "roofline": roof}
+               "roofline": roof, "parity": parity}
+        if comm is not None and imbalance is not None:
+            comm["imbalance"] = imbalance["max_over_mean_rows"]
         if os.environ.get("VLP_DEBUG_TUNE") == "1":  # noqa
             from vlp_amd.engine import Engine
             print("nt choices (M,N,K)->variant:", sorted(Engine._nt_choice.items()), file=sys.stderr)

@@ -11,7 +11,7 @@ if not torch.cuda.is_available():
     pytest.skip("needs a GPU", allow_module_level=True)
 
 from vlp_amd import synthetic as S                                # noqa: E402
-from vlp_amd.data import BatchPrefetcher, PackedRegionStore, TextPreprocessor, write_packed   # noqa: E402
+from vlp_amd.data import BatchPrefetcher, PackedRegionStore, TextPreprocessor, batch_seed, write_packed   # noqa: E402
 from vlp_amd.input_prep import MaskSpec, RawRegions                # noqa: E402
 from vlp_amd.modeling import BertConfig, BertForPreTrainingLossMask   # noqa: E402
 from vlp_amd.optimization_fp16 import FP16_Optimizer_State, FusedAdam   # noqa: E402
@@ -38,27 +38,26 @@ def procs(vocab=2048, max_len_b=20):
     return TextPreprocessor(mode="s2s", **kw), TextPreprocessor(mode="bi", **kw)
 
 
-def test_prefetcher_delivers_exact_batches(tmp_path):
+@pytest.mark.parametrize("num_workers", [1, 4])
+def test_prefetcher_delivers_exact_batches(tmp_path, num_workers):
     store, examples, feats, cls, box, ids = make_store(tmp_path)
     p_s2s, p_bi = procs()
     B, steps = 4, 5
-    random.seed(11)
-    pf = BatchPrefetcher(store, examples, B, p_s2s, p_bi, s2s_prob=0.5, device=DEV, steps=steps, seed=3)
+    pf = BatchPrefetcher(store, examples, B, p_s2s, p_bi, s2s_prob=0.5, device=DEV, steps=steps, seed=3, num_workers=num_workers)
     got = []
     for batch in pf:
         torch.cuda.synchronize()
         got.append([t.cpu() if torch.is_tensor(t) else type(t)(*(x.cpu() if torch.is_tensor(x) else x for x in t)) for t in batch])
     assert len(got) == steps
-    # replay the same sample stream synchronously
-    order = list(range(len(examples)))
-    random.Random(3).shuffle(order)
-    random.seed(11)
+    # replay the same sample stream synchronously: batch s draws from random.Random(batch_seed(seed, epoch, rank, s)) only
+    order = pf.epoch_order()
     row = {k: i for i, k in enumerate(ids)}
     for s in range(steps):
+        rng = random.Random(batch_seed(3, 0, 0, s))
         for j in range(B):
             img_id, toks = examples[order[(s * B + j) % len(order)]]
-            proc = random.choices([p_s2s, p_bi], weights=[0.5, 0.5])[0]
-            t = proc(toks)
+            proc = rng.choices([p_s2s, p_bi], weights=[0.5, 0.5])[0]
+            t = proc(toks, rng)
             g = got[s]
             assert g[0][j].tolist() == t["input_ids"] and g[1][j].tolist() == t["segment_ids"]
             assert g[3][j].tolist() == t["masked_ids"] and g[4][j].tolist() == t["masked_pos"] and g[5][j].tolist() == t["masked_weights"]
@@ -157,27 +156,27 @@ def test_repeated_prefetcher_batch_is_learned(tmp_path):
     assert sum(losses[-5:]) / 5 < 0.7 * sum(losses[:5]) / 5, losses
 
 
-def test_prefetcher_with_a_slow_consumer(tmp_path):
+@pytest.mark.parametrize("num_workers", [1, 3])
+def test_prefetcher_with_a_slow_consumer(tmp_path, num_workers):
     """a loader that is much faster than the training step must not overwrite a pinned host buffer whose H2D copy is
     still queued.  The consumer stream is stalled (device-side sleep) before every use and never synchronises the host, so the
     worker thread runs several batches ahead; every delivered batch must still hold exactly the bytes of its own samples."""
     store, examples, feats, cls, box, ids = make_store(tmp_path)
     p_s2s, p_bi = procs()
     B, steps = 4, 10
-    random.seed(21)
     got = []
-    for batch in BatchPrefetcher(store, examples, B, p_s2s, p_bi, s2s_prob=1.0, device=DEV, steps=steps, depth=2, seed=9):
+    pf = BatchPrefetcher(store, examples, B, p_s2s, p_bi, s2s_prob=1.0, device=DEV, steps=steps, depth=2, seed=9, num_workers=num_workers)
+    for batch in pf:
         torch.cuda._sleep(40_000_000)                       # ~20 ms of device time ahead of the consumer's reads
         got.append((batch[8].clone(), batch[10].cls_prob.clone(), batch[10].bbox.clone(), batch[0].clone()))
     torch.cuda.synchronize()
-    order = list(range(len(examples)))
-    random.Random(9).shuffle(order)
-    random.seed(21)
+    order = pf.epoch_order()
     row = {k: i for i, k in enumerate(ids)}
     for s in range(steps):
+        rng = random.Random(batch_seed(9, 0, 0, s))
         for j in range(B):
             img_id, toks = examples[order[(s * B + j) % len(order)]]
-            t = random.choices([p_s2s, p_bi], weights=[1.0, 0.0])[0](toks)      # same draws from `random` as the worker made
+            t = rng.choices([p_s2s, p_bi], weights=[1.0, 0.0])[0](toks, rng)      # same draws as the worker made for this batch
             r = row[img_id]
             assert np.array_equal(got[s][0][j].cpu().numpy(), feats[r]), (s, j)
             assert np.array_equal(got[s][1][j].cpu().numpy(), cls[r]) and np.array_equal(got[s][2][j].cpu().numpy(), box[r])

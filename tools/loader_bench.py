@@ -33,14 +33,21 @@ with tempfile.TemporaryDirectory(dir="/tmp") as d:
     kw = dict(max_pred=3, mask_prob=0.15, vocab_size=28996, cls_id=S.CLS_ID, sep_id=S.SEP_ID, mask_id=S.MASK_ID, unk_id=S.UNK_ID, max_len=167, max_len_b=64)
     p_s2s, p_bi = TextPreprocessor(mode="s2s", **kw), TextPreprocessor(mode="bi", **kw)
     out = {"batch": B, "images": N, "bytes_per_sample_h2d": 100 * 2048 * 2 + 100 * 1601 * 2 + 100 * 6 * 4 + 2 * 167 * 8 + 9 * 8 + 12 + 8}
-    random.seed(0)
-    # (a) loader alone
-    t0 = time.perf_counter()
-    n = 0
-    for batch in BatchPrefetcher(store, examples, B, p_s2s, p_bi, s2s_prob=0.75, device=dev, steps=STEPS, seed=0):
-        n += 1
-    torch.cuda.synchronize()
-    out["loader_only_samples_per_s"] = round(n * B / (time.perf_counter() - t0), 1)
+    # (a) loader alone, over worker-thread counts (WORKERS="1,2,4,8"); host cores of this process stated beside it
+    out["host_cpus"] = len(os.sched_getaffinity(0))
+    out["loader_only_samples_per_s"] = {}
+    for w in [int(x) for x in os.environ.get("WORKERS", "1,2,4,8").split(",")]:
+        pf = BatchPrefetcher(store, examples, B, p_s2s, p_bi, s2s_prob=0.75, device=dev, steps=STEPS, seed=0, num_workers=w)
+        for _ in pf:                # warm the page cache / pinned slots once
+            break
+        t0 = time.perf_counter()
+        n = 0
+        for batch in pf:
+            n += 1
+        torch.cuda.synchronize()
+        out["loader_only_samples_per_s"][str(w)] = round(n * B / (time.perf_counter() - t0), 1)
+    NW = int(os.environ.get("TRAIN_WORKERS", 4))
+    out["train_workers"] = NW
     # model
     cfg = BertConfig(28996, num_hidden_layers=12, type_vocab_size=6)
     model = BertForPreTrainingLossMask(cfg, enable_butd=True, len_vis_input=100, tasks="img2txt", allow_random_fc7=True).half().to(dev).train()

@@ -20,6 +20,7 @@ import math
 import os
 import weakref
 
+import numpy as np
 import torch
 
 from . import _lib as K
@@ -38,6 +39,10 @@ def _ru(x, m):
 
 def is_no_decay(name):
     return any(nd in name for nd in NO_DECAY)
+
+
+class VlpPerformanceWarning(UserWarning):
+    """A correct but avoidably slow way of driving the engine (issued once per engine)."""
 
 
 class _State(object):
@@ -73,7 +78,13 @@ class Engine(object):
     # as rows [row_off[b], row_off[b+1]) of every [M, *] activation and runs every row-wise kernel on M' = sum n_b rows; attention takes
     # row_off; dropout hashes keep the logical (b*L + l, col) element, so masks -- and with them losses, logits and gradients --
     # equal the dense run's up to the fp32 summation order of the weight-gradient / LayerNorm-parameter sums.
-    VARLEN = os.environ.get("VLP_VARLEN", "0") == "1"
+    # Round 6: ON BY DEFAULT where it costs nothing -- VLP_VARLEN unset = "auto": a batch whose kept lengths are known on the host (MaskSpec.lens_host:
+    # the loader's form) or remembered for this very mask tensor (a device-resident pool) runs packed; a FRESH dense int64 mask would need a
+    # device -> host read-back before the forward can be enqueued (a pipeline bubble per step), so in auto mode it runs dense after
+    # `varlen_readback_budget` read-backs (0 here; the entry script allows 8 so that a --synthetic pool warms up) and a one-time
+    # VlpPerformanceWarning says so.  VLP_VARLEN=1 / engine.varlen = True: always packed, read-backs accepted (warned about once);
+    # VLP_VARLEN=0 / False: never.
+    VARLEN = {"1": True, "0": False}.get(os.environ.get("VLP_VARLEN", ""), "auto")
     # (Round 5, measured and NOT kept -- the gradient norm in front of the optimizer step stays one vlp_sumsq pass over the buffer, 53 us:
     # one partial-sum launch per finished gradient slice on the side stream during backward LOSES, 9.738 / 9.722 vs 9.666 / 9.671 ms/step;
     # summing the 93 % of the buffer that is final when the side stream reaches the embedding tables, under the region-projection backward,
@@ -113,7 +124,11 @@ class Engine(object):
         self._side = None                 # second HIP stream for the layer wgrads (created on first use)
         self._side_busy = False           # True while backward may have work queued on it
         self._prof_ctr = 0
-        self.varlen = self.VARLEN         # padding-free (packed) training step, see VARLEN
+        self.varlen = self.VARLEN         # padding-free (packed) training step: True | False | "auto", see VARLEN
+        self.varlen_readback_budget = 0   # auto mode: how many fresh dense masks may still be reduced + read back (pool warm-up)
+        self._rb_streak = 0               # consecutive read-backs without a cache hit in between
+        self._rb_warned = False
+        self._pk_stage = None             # ring of pinned row_off staging buffers (+ events) for _packing
         self._pk_cache = {}               # kept-length tuple -> (row_off, row_map device tensors, M'): batches repeat in bench / epochs
         self._pk_lens = {}                # id(mask tensor) -> (weakref, version, ..., lens): lengths derived from a dense mask, once per tensor
         self.last_packed_rows = None      # M' of the latest packed forward (None: dense) -- bench.py / tests read it
@@ -298,6 +313,11 @@ class Engine(object):
         if z is None or z.device != device:
             z = self._zero1 = torch.zeros(1, device=device, dtype=torch.float32)
         return z
+
+    def is_zero_placeholder(self, t):
+        """True when `t` is the shared zero a forward hands out for a loss the task does not have (train loops skip it instead of
+        launching `+ 0`).  The placeholder is shared by every forward of this engine: do not modify it in place."""
+        return t is getattr(self, "_zero1", None)
 
     def zero_grad(self):
         """optimizer.zero_grad() of the train loop (run_img2txt_dist.py:585): no memset -- the next
@@ -565,7 +585,20 @@ class Engine(object):
         hit = self._pk_lens.get(key)
         if hit is not None and hit[0]() is attention_mask and hit[1] == attention_mask._version and \
                 (hit[2] is None) == (masked_pos is None) and (masked_pos is None or (hit[2]() is masked_pos and hit[4] == masked_pos._version)):
+            self._rb_streak = 0
             return hit[3]           # the SAME tensor objects, unmodified (weak references: a recycled id() cannot alias)
+        # a fresh dense mask: its lengths cost a reduction + a device -> host read-back in front of this forward
+        if self.varlen == "auto":
+            if self.varlen_readback_budget <= 0:
+                self._warn_readback("the padding-free step is OFF for this batch: its dense [B, L, L] attention mask is a new tensor, and deriving the kept "
+                                    "lengths from it would stall the launch queue once per step")
+                return None
+            self.varlen_readback_budget -= 1
+        else:
+            self._rb_streak += 1
+            if self._rb_streak > 8:
+                self._warn_readback("the padding-free step derives the kept lengths of a NEW dense [B, L, L] attention mask every step: one device -> host "
+                                    "read-back (a launch-queue stall) per step")
         cols = (attention_mask != 0).any(dim=1)                                            # [B, L]: key column attended by some query
         idx = torch.arange(1, L + 1, device=cols.device, dtype=torch.int32)
         n = (cols.to(torch.int32) * idx).amax(dim=1)
@@ -581,22 +614,42 @@ class Engine(object):
                               masked_pos._version if masked_pos is not None else 0)
         return lens
 
+    def _warn_readback(self, what):
+        if self._rb_warned:
+            return
+        self._rb_warned = True
+        import warnings
+        warnings.warn("vlp_amd: " + what + ".  Hand the engine vlp_amd.input_prep.MaskSpec (three int32 per sample + the lengths on the host: what "
+                      "vlp_amd.data.BatchPrefetcher delivers) in place of the dense mask, or keep the mask tensors resident and reuse them; "
+                      "VLP_VARLEN=0 silences this, VLP_VARLEN=1 accepts the read-back.", VlpPerformanceWarning, stacklevel=3)
+
+    PK_STAGE_SLOTS = 8
+
     def _packing(self, lens, B, L):
-        """(row_off int32 [B+1], row_map int32 [M'], M') on the device for the kept lengths `lens`."""
+        """(row_off int32 [B+1], row_map int32 [M'], M') on the device for the kept lengths `lens`.  Batches of a resident pool / an epoch
+        replay hit the cache; a real loader produces a new length tuple every step: its offsets go through a small RING of pinned staging
+        buffers (no hipHostMalloc per step, nothing pinned kept per cache entry -- ADVICE r5), one async H2D copy + one rowmap_build launch."""
         key = (L,) + tuple(lens)
         ent = self._pk_cache.get(key)
         if ent is None:
-            off = [0]
-            for n in lens:
-                off.append(off[-1] + n)
-            host = torch.tensor(off, dtype=torch.int32).pin_memory()
+            if self._pk_stage is None or self._pk_stage[0][0].numel() < B + 1:
+                self._pk_stage = [[torch.empty(max(B + 1, 257), dtype=torch.int32).pin_memory(), torch.cuda.Event()] for _ in range(self.PK_STAGE_SLOTS)]
+                self._pk_stage_i = 0
+            host, ev = self._pk_stage[self._pk_stage_i]
+            self._pk_stage_i = (self._pk_stage_i + 1) % self.PK_STAGE_SLOTS
+            ev.synchronize()                       # the copy issued from this buffer PK_STAGE_SLOTS misses ago (long done; never-recorded: returns at once)
+            off = np.zeros(B + 1, dtype=np.int32)
+            np.cumsum(np.asarray(lens, dtype=np.int32), out=off[1:])
+            host.numpy()[:B + 1] = off
             row_off = torch.empty(B + 1, dtype=torch.int32, device=self.device)
-            row_off.copy_(host, non_blocking=True)
-            row_map = torch.empty(off[-1], dtype=torch.int32, device=self.device)
+            row_off.copy_(host[:B + 1], non_blocking=True)
+            ev.record()
+            Mp = int(off[-1])
+            row_map = torch.empty(Mp, dtype=torch.int32, device=self.device)
             K.rowmap_build(row_off, B, L, row_map)
-            if len(self._pk_cache) >= 256:
+            if len(self._pk_cache) >= 64:
                 self._pk_cache.clear()
-            ent = self._pk_cache[key] = (row_off, row_map, off[-1], host)
+            ent = self._pk_cache[key] = (row_off, row_map, Mp)
         return ent[0], ent[1], ent[2]
 
     def forward(self, vis_feats, vis_pe, input_ids, token_type_ids, attention_mask, masked_pos, train, want_mlm, want_vqa,
@@ -1403,6 +1456,10 @@ class Engine(object):
                 (ws["d_vis_h"], ws["h1"], self.G("vis_embed.2.weight"), Mv, H, 2048, beta, self.G("vis_embed.2.bias")),
                 (ws["d_vispe_h"], ws["vpe_in"], ws["dwpe_pad"], Mv, H, PE_PAD, 0, None)])
         else:
+            if use_side and self._side_busy:
+                # these split-M launches use ws["tn_ws"] on the MAIN stream; the head wgrads deferred to the side stream use the same scratch and
+                # with <= 2 layers no per-layer wait orders the two: join first (small batches only -- Mv < 2048)
+                main.wait_stream(side)
             self._tn(ws["d_vispe_h"], ws["vpe_in"], ws["dwpe_pad"], Mv, H, PE_PAD, ws, 0)
             self._tn(ws["d_vis_h"], ws["h1"], self.G("vis_embed.2.weight"), Mv, H, 2048, ws, beta, bias=self.G("vis_embed.2.bias"))
             self._tn(ws["dz1v"], img, self.G("vis_embed.0.weight"), Mv, 2048, 2048, ws, beta, bias=self.G("vis_embed.0.bias"))

@@ -85,6 +85,7 @@ class BertAdam(Optimizer):
         super(BertAdam, self).__init__(params, defaults)
         self._flat = None
         self._step = 0
+        self.grad_scale = 1.0        # gradients arrive multiplied by this (a scaled fp16 backward); step() divides it out before the per-tensor clip
 
     def _engine(self):
         for g in self.param_groups:
@@ -195,6 +196,8 @@ class BertAdam(Optimizer):
                 act.append(1 if on else 0)
                 if on:
                     fg.g32[fg.offs[i]:fg.offs[i + 1]].copy_(p.grad.detach().reshape(-1))
+            if self.grad_scale != 1.0:
+                fg.g32.mul_(1.0 / self.grad_scale)
             fg.active.copy_(torch.tensor(act, dtype=torch.int32), non_blocking=True)
             if group["t_total"] != -1:
                 lr = group["lr"] * SCHEDULES[group["schedule"]](self._step / group["t_total"], group["warmup"])

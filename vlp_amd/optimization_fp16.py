@@ -178,6 +178,10 @@ class FP16_Optimizer_State(object):
         self.engine.wait_params()
         # d(loss * scale) = scale * d(loss): the device-resident scale goes in as the upstream gradient instead of being multiplied into the
         # loss first -- the same numbers without the multiply, its autograd twin and the ones() fill (three launches between forward and backward)
+        # NOTE: the upstream gradient below is a live VIEW of the optimizer's scale state -- _LossFn.backward hands its pointer to the
+        # backward kernels without a copy.  That is correct because every writer of _scale_state (vlp_loss_scale_update, last launch of a step) is
+        # ordered in front of this point: wait_params() above joins the optimizer stream, and the next update is only enqueued by step(), after
+        # this backward.  Anyone who moves loss_scale_update to another stream has to clone the element here instead.
         loss = loss.float()
         loss.backward(gradient=self._scale_state[0:1].reshape(loss.shape))
 

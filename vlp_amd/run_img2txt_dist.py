@@ -129,6 +129,17 @@ def build_parser():
                         "reference stack's FP16_Optimizer(FusedAdam) state_dict, loadable by the reference; both are accepted on resume")
     p.add_argument("--stop_after_epoch", type=int, default=0, help="stop after this epoch (schedule still spans --num_train_epochs); 0 = off")
     p.add_argument("--log_every", type=int, default=100, help="steps between loss read-backs (each read-back is a host sync)")
+    p.add_argument("--allow_fp16_compute", action="store_true",
+                   help="without --fp16 the reference trains in fp32 under BertAdam (run_img2txt_dist.py:421-426; its README's `--amp` commands do "
+                        "exactly that, because amp only engages together with --fp16, :305).  vlp_amd has no fp32 compute path: this switch runs "
+                        "that command line with fp16 storage / fp32 accumulate and BertAdam on fp32 master weights (static loss scale --loss_scale, "
+                        "default 1024)")
+    p.add_argument("--no_padding_free", action="store_true",
+                   help="compute all L positions of every sample like the reference does; by default positions past a sample's last token "
+                        "(attended by nothing, read by no loss) are not computed when the batch says where they start (DESIGN.md section 7)")
+    p.add_argument("--shard_order", default="balanced", choices=["balanced", "reference"],
+                   help="world_size > 1 with --packed_features: 'balanced' deals every global batch (DistributedSampler's sample set) to the ranks "
+                        "by caption length so that padding-free row counts per rank match; 'reference' is DistributedSampler's index order bit for bit")
     return p
 
 
@@ -179,8 +190,13 @@ def build_model(args, device):
     """run_img2txt_dist.py:310-377: construct (from scratch or from a checkpoint), .half(), .to(device)."""
     if args.relax_projection:
         raise NotImplementedError("--relax_projection is not supported by vlp_amd")
-    if not args.fp16:
-        raise NotImplementedError("vlp_amd implements the --fp16 path of the reference (fp16 storage, fp32 accumulate); add --fp16")
+    if not args.fp16 and not args.allow_fp16_compute:
+        raise NotImplementedError(
+            "vlp_amd implements the reference's --fp16 path (fp16 storage, fp32 accumulate, FusedAdam in FP16_Optimizer_State) and has no fp32 compute "
+            "path.  This command line has no --fp16%s.  Add --fp16 (the reference's fp16 recipe), or --allow_fp16_compute to keep the optimizer this "
+            "command line selects (BertAdam, run_img2txt_dist.py:421-426) on fp32 master weights with fp16 compute."
+            % (": the reference README's example commands pass --amp alone (README.md:112,131), and amp only engages together with --fp16 "
+               "(run_img2txt_dist.py:305), so the reference itself runs them in fp32" if args.amp else ""))
     config = model_config(args)
     state = None
     if args.model_recover_path:
@@ -207,6 +223,11 @@ def build_optimizer(args, model, t_total):
     no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
     groups = [{"params": [p for n, p in named if not any(nd in n for nd in no_decay)], "weight_decay": 0.01},
               {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": 0.0}]
+    if not args.fp16:        # --allow_fp16_compute: the reference's else-branch (:421-426) on fp32 masters of the fp16 parameters
+        from .optimization import BertAdam
+        opt = BertAdam(groups, lr=args.learning_rate, warmup=args.warmup_proportion, schedule=args.sche_mode, t_total=t_total)
+        opt.grad_scale = float(args.loss_scale) if args.loss_scale > 0 else 1024.0     # fp16 backward needs a scaled loss; step() divides it out
+        return opt
     inner = FusedAdam(groups, lr=args.learning_rate, bias_correction=False, max_grad_norm=1.0)
     if args.loss_scale == 0:
         return FP16_Optimizer_State(inner, dynamic_loss_scale=True)
@@ -226,17 +247,23 @@ def train_step(model, optimizer, batch, lr_this_step, mask_image_regions=False, 
     # :531 `loss = masked_lm_loss + pretext_loss + ans_loss`; the engine's shared zero placeholder (a loss this task does not have) is
     # recognised by identity and not added: no add launches for `+ 0`
     eng = getattr(model.module if hasattr(model, "module") else model, "engine", None)
-    zero = getattr(eng, "_zero1", None)
-    terms = [t for t in loss_tuple if t is not zero] or [masked_lm_loss]
+    terms = [t for t in loss_tuple if eng is None or not eng.is_zero_placeholder(t)]
+    if not terms:
+        raise RuntimeError("train_step: this batch has no live loss (no masked positions, no answer labels, no masked regions): nothing to back-propagate")
     loss = terms[0]
     for t in terms[1:]:
         loss = loss + t
     if accum_steps > 1:
         loss = loss / accum_steps                            # :567-568
-    optimizer.backward(loss)                                 # :571
+    if hasattr(optimizer, "backward"):
+        optimizer.backward(loss)                             # :571
+    else:                                                    # :573 `loss.backward()` (BertAdam; --allow_fp16_compute scales the fp16 backward)
+        gs = getattr(optimizer, "grad_scale", 1.0)
+        loss.float().backward(gradient=torch.full_like(loss, gs, dtype=torch.float32) if gs != 1.0 else None)
     if not accumulate:
-        for g in optimizer.param_groups:                     # :580-583
-            g["lr"] = lr_this_step
+        if hasattr(optimizer, "backward"):
+            for g in optimizer.param_groups:                 # :580-583 (fp16 only: BertAdam runs its own schedule)
+                g["lr"] = lr_this_step
         optimizer.step()
         optimizer.zero_grad()
     return loss_tuple
@@ -257,7 +284,8 @@ def build_packed_loader(args, device):
               always_truncate_tail=args.always_truncate_tail)
     return BatchPrefetcher(store, examples, args.train_batch_size, TextPreprocessor(mode="s2s", **kw), TextPreprocessor(mode="bi", **kw),
                            s2s_prob=args.s2s_prob, device=device, seed=args.seed, vis_mask_prob=args.vis_mask_prob,
-                           rank=max(args.global_rank, 0), world=max(args.world_size, 1))
+                           rank=max(args.global_rank, 0), world=max(args.world_size, 1), num_workers=args.num_workers,
+                           balance_lengths=(args.shard_order == "balanced" and not args.no_padding_free))
 
 
 def synthetic_batches(args, device, steps, rank):
@@ -313,6 +341,14 @@ def main(argv=None):
     if distributed:
         model = DDP(model, device_ids=[args.local_rank], output_device=args.local_rank, find_unused_parameters=True)
     optimizer = build_optimizer(args, model, t_total)
+    eng = (model.module if hasattr(model, "module") else model).engine
+    if args.no_padding_free:
+        eng.varlen = False
+    elif eng.varlen == "auto":
+        # padding-free by default: the packed loader's MaskSpec carries the lengths on the host; a --synthetic pool of dense
+        # masks is reduced + read back once per pooled tensor (budget), then remembered; anything else runs dense and says so once
+        eng.varlen_readback_budget = 8
+    logger.info("padding-free step: %s", eng.varlen)
     if hasattr(optimizer, "pipeline_with_forward"):
         # this loop touches parameters only through the engine, so the optimizer step MAY stream underneath the next forward
         # (VLP_ADAM_PIPELINE=1; bit-identical).  On one MI355X it is a wash (the HBM-bound update slows the concurrent GEMMs), so off.
@@ -331,7 +367,6 @@ def main(argv=None):
         t0 = time.time()
         losses = []
         if loader is not None:
-            loader.seed = args.seed + i_epoch                                                         # new shuffle every epoch
             loader.set_epoch(i_epoch - 1)                                                             # train_sampler.set_epoch(i_epoch-1), :455
         for step, batch in enumerate(loader if loader is not None else synthetic_batches(args, device, steps_per_epoch, args.global_rank)):
             acc = (step + 1) % args.gradient_accumulation_steps != 0
