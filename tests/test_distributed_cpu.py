@@ -66,11 +66,47 @@ def _worker(rank, world, init_file, q):
             assert summ["exposed_ms"] >= 0 and summ["overlapped_ms"] >= 0 and summ["collectives_ms"] >= 0
             assert abs(summ["collectives_ms"] - sum(b["ms"] for b in summ["per_bucket"])) <= 1e-2 + 1e-3 * summ["collectives_ms"]
             assert all(b["mb"] > 0 for b in summ["per_bucket"])
+        # the exchange-form rule, measured branch (forced: gloo / world 2 would take all-reduce unmeasured): both forms are timed on a scratch
+        # buffer, the ranks agree on ONE mode, and the reducer built on it reduces correctly
+        os.environ["VLP_DDP_CALIBRATE"] = "1"
+        try:
+            main4 = torch.randn(4096)
+            want4 = main4.clone()
+            dist.all_reduce(want4)
+            red4 = GradReducer(main4, [(0, 2048), (2048, 4096)], torch.zeros(8), None, bucket_cap_mb=0.008)
+        finally:
+            del os.environ["VLP_DDP_CALIBRATE"]
+        assert red4.mode in ("allreduce", "rs_ag") and red4.mode_calibration is not None and "measured at construction" in red4.mode_why
+        modes = [None, None]
+        dist.all_gather_object(modes, red4.mode)
+        assert modes[0] == modes[1]
+        red4.bucket_ready(0)
+        red4.bucket_ready(1)
+        red4.finish()
+        assert torch.allclose(main4, want4 / world, atol=1e-6)
         q.put((rank, "ok"))
     except Exception as e:   # pragma: no cover
         q.put((rank, repr(e)))
     finally:
         dist.destroy_process_group()
+
+
+def test_exchange_form_rule():
+    """VERDICT r5 #7b: the documented rule, without a process group.  Environment override first; all-reduce below four ranks / off RCCL /
+    when a bucket does not divide; from four RCCL ranks the measured times decide, reduce-scatter + all-gather winning ties (3 %)."""
+    from vlp_amd.distributed import choose_mode
+    never = lambda: (_ for _ in ()).throw(AssertionError("no measurement expected"))      # noqa: E731
+    assert choose_mode(8, "nccl", True, never, env="sharded")[0] == "sharded"
+    assert choose_mode(2, "nccl", True, never, env="")[0] == "allreduce"
+    assert choose_mode(8, "gloo", True, never, env="")[0] == "allreduce"
+    assert choose_mode(8, "nccl", False, never, env="")[0] == "allreduce"
+    assert choose_mode(8, "nccl", True, lambda: {"allreduce": 1.00, "rs_ag": 0.40, "mb": 50.0}, env="")[0] == "rs_ag"
+    assert choose_mode(4, "nccl", True, lambda: {"allreduce": 1.00, "rs_ag": 1.02, "mb": 50.0}, env="")[0] == "rs_ag"
+    mode, why = choose_mode(8, "nccl", True, lambda: {"allreduce": 0.50, "rs_ag": 0.80, "mb": 50.0}, env="")
+    assert mode == "allreduce" and "0.500" in why and "0.800" in why
+    assert choose_mode(8, "nccl", True, None, env="")[0] == "rs_ag"
+    with pytest.raises(ValueError):
+        choose_mode(8, "nccl", True, never, env="ring")
 
 
 def test_grad_reducer_world2_gloo():

@@ -56,25 +56,46 @@ with tempfile.TemporaryDirectory(dir="/tmp") as d:
     groups = [{"params": [p for n_, p in named if not any(x in n_ for x in nd)], "weight_decay": 0.01},
               {"params": [p for n_, p in named if any(x in n_ for x in nd)], "weight_decay": 0.0}]
     opt = FP16_Optimizer_State(FusedAdam(groups, lr=1e-4, bias_correction=False, max_grad_norm=1.0), dynamic_loss_scale=True)
+    eng = model.engine
     resident = S.batch_to(S.make_batch(B, max_len_b=64, vocab_size=28996, max_pred=3, seed=1), dev, half=True)
-    for _ in range(5):
-        train_step(model, opt, resident, 1e-4)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(STEPS):
-        train_step(model, opt, resident, 1e-4)
-    torch.cuda.synchronize()
-    out["train_resident_samples_per_s"] = round(STEPS * B / (time.perf_counter() - t0), 1)
-    # (c) fed by the prefetcher (first batches warm the MaskSpec / RawRegions paths)
-    it = iter(BatchPrefetcher(store, examples, B, p_s2s, p_bi, s2s_prob=0.75, device=dev, steps=STEPS + 5, seed=1))
-    for _ in range(5):
-        train_step(model, opt, next(it), 1e-4)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    k = 0
-    for batch in it:
-        train_step(model, opt, batch, 1e-4)
-        k += 1
-    torch.cuda.synchronize()
-    out["train_from_prefetcher_samples_per_s"] = round(k * B / (time.perf_counter() - t0), 1)
+
+    def timed(batches, n):
+        t0 = time.perf_counter()
+        k = 0
+        for b in batches:
+            train_step(model, opt, b, 1e-4)
+            k += 1
+            if k == n:
+                break
+        torch.cuda.synchronize()
+        return round(k * B / (time.perf_counter() - t0), 1)
+
+    def repeat(b):
+        while True:
+            yield b
+
+    # (b) resident batches: dense (the reference's [B, L, L] mask tensor, all L positions) and padding-free (a prefetcher batch kept resident:
+    #     MaskSpec carries the lengths, so the step packs)
+    eng.varlen = False
+    timed(repeat(resident), 5)
+    out["train_resident_dense_samples_per_s"] = timed(repeat(resident), STEPS)
+    eng.varlen = "auto"
+    # the SAME batches the prefetcher arm below will deliver (seed 1, its steps 5 .. 5 + STEPS), kept resident: equal rows, equal length tuples
+    keep = []
+    for i, b in enumerate(BatchPrefetcher(store, examples, B, p_s2s, p_bi, s2s_prob=0.75, device=dev, steps=STEPS + 5, seed=1, num_workers=NW)):
+        if i >= 5:
+            keep.append(tuple(t.clone() if torch.is_tensor(t) else type(t)(*(x.clone() if torch.is_tensor(x) else x for x in t)) for t in b))
+    timed(iter(keep), 5)
+    eng._pk_cache.clear()                 # every timed step builds its row map, as a real epoch does
+    out["train_resident_padding_free_samples_per_s"] = timed(iter(keep), STEPS)
+    out["padding_free_rows_mean"] = round(sum(sum(b[2].lens_host) for b in keep) / len(keep), 1)
+    del keep
+    # (c) fed by the prefetcher (NW loader threads), padding-free (the default for MaskSpec batches) and dense
+    for name, mode in (("padding_free", "auto"), ("dense", False)):
+        eng.varlen = mode
+        it = iter(BatchPrefetcher(store, examples, B, p_s2s, p_bi, s2s_prob=0.75, device=dev, steps=STEPS + 5, seed=1, num_workers=NW))
+        timed(it, 5)
+        out["train_from_prefetcher_%s_samples_per_s" % name] = timed(it, STEPS)
+        for _ in it:
+            pass
     print(json.dumps(out))

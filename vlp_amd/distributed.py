@@ -16,10 +16,14 @@ autograd graph, so the reducer lives here instead:
     unused-parameter bitmap exchange: their gradient slots stay zero;
   * reduction is the MEAN over ranks (torch DDP semantics) -- ReduceOp.AVG on RCCL; on
     backends without AVG (gloo, used by the CPU tests) SUM followed by a 1/world scale;
-  * `VLP_DDP_MODE=rs_ag` (opt-in) issues every bucket as reduce-scatter + all-gather instead of one all-reduce (SURVEY.md
-    section 5 / 8e: on point-to-point xGMI a direct reduce-scatter/all-gather uses all 7 links of a GPU, a ring is bound by one);
-    same result up to fp16 summation order.  No scaling curve has been measured yet (the driver owns the 8-GPU runs), so
-    all-reduce stays the default.
+  * exchange form: one all-reduce per bucket, or reduce-scatter + all-gather per bucket (`rs_ag`; SURVEY.md section 5 / 8e argues that on
+    point-to-point xGMI the direct reduce-scatter / all-gather uses all 7 links of a GPU while a ring is bound by one: 0.38 vs 2.65 ms for
+    231.9 MB); same result up to fp16 summation order.  THE RULE (round 6, `choose_mode`): `VLP_DDP_MODE` if set; otherwise all-reduce below
+    4 ranks (two or three GPUs: a ring over the direct link IS the direct exchange), and from 4 ranks on RCCL the form is MEASURED once at
+    construction -- both forms on a bucket-sized scratch buffer, three rounds each, the per-form times max-reduced over the ranks so that
+    every rank takes the same decision (`mode_calibration` on the reducer, quoted by bench.py under config.comm).  No 8-GPU run has been
+    available to the builder (the driver owns that node): the rule lets the first SCALE run pick the form the hardware prefers instead of
+    the one an estimate prefers; rs_ag wins ties (within 3 %) because it is the form the sharded optimizer step builds on.
   * `VLP_DDP_MODE=sharded` (opt-in, round 4): reduce-scatter ONLY -- rank r keeps the mean of chunk r of every bucket -- and the
     optimizer step is sharded over the ranks (`ShardPlan`, used by FP16_Optimizer_State): each rank runs the grad-norm partial and the
     fused Adam update on its 1/W of master / m / v (1.39 GB of state and 0.62 ms of HBM-bound update per step shrink by W), the clip
@@ -76,6 +80,26 @@ def coalesce_buckets(slices, cap):
     return buckets, fire_at
 
 
+def choose_mode(world, backend, divisible, calibrate=None, env=None):
+    """The exchange-form rule (module docstring): -> (mode, why).  `calibrate()` -> {"allreduce": ms, "rs_ag": ms} (already agreed over the
+    ranks) is only called when the rule needs a measurement.  Pure apart from that call: CPU-testable."""
+    env = os.environ.get("VLP_DDP_MODE") if env is None else env
+    if env:
+        if env not in ("allreduce", "rs_ag", "sharded"):
+            raise ValueError("VLP_DDP_MODE must be 'allreduce', 'rs_ag' or 'sharded', got %r" % env)
+        return env, "VLP_DDP_MODE"
+    force = os.environ.get("VLP_DDP_CALIBRATE") == "1"
+    if not divisible:
+        return "allreduce", "bucket sizes not divisible by the world size"
+    if not force and (world < 4 or backend != "nccl"):
+        return "allreduce", "fewer than 4 ranks or not RCCL: all-reduce"
+    if calibrate is None:
+        return "rs_ag", "4+ ranks on RCCL, no calibration available: the SURVEY 8e estimate"
+    t = calibrate()
+    mode = "rs_ag" if t["rs_ag"] <= 1.03 * t["allreduce"] else "allreduce"
+    return mode, "measured at construction: all-reduce %.3f ms, reduce-scatter + all-gather %.3f ms per %.0f MB" % (t["allreduce"], t["rs_ag"], t.get("mb", 0.0))
+
+
 class GradReducer(object):
     """Bucketed asynchronous all-reduce(mean) over slices of flat gradient buffers."""
 
@@ -84,13 +108,20 @@ class GradReducer(object):
         flat_tail: a small buffer reduced at the end (biases / LayerNorm parameters);
         mode: "allreduce" (default) | "rs_ag" (env VLP_DDP_MODE)."""
         self.flat_main, self.flat_tail, self.pg = flat_main, flat_tail, process_group
-        self.mode = mode or os.environ.get("VLP_DDP_MODE", "allreduce")
-        if self.mode not in ("allreduce", "rs_ag", "sharded"):
-            raise ValueError("VLP_DDP_MODE must be 'allreduce', 'rs_ag' or 'sharded', got %r" % self.mode)
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
         cap = int(bucket_cap_mb * 1024 * 1024 / flat_main.element_size())
         self.buckets, self.fire_at = coalesce_buckets(slices, cap)
+        self._avg = dist.get_backend(process_group) == "nccl"
+        self._work = []
+        self.mode_calibration = None
+        if mode is not None:
+            if mode not in ("allreduce", "rs_ag", "sharded"):
+                raise ValueError("mode must be 'allreduce', 'rs_ag' or 'sharded', got %r" % mode)
+            self.mode, self.mode_why = mode, "constructor argument"
+        else:
+            sizes0 = [hi - lo for lo, hi in self.buckets] + ([flat_tail.numel()] if flat_tail is not None else [])
+            self.mode, self.mode_why = choose_mode(self.world, dist.get_backend(process_group), all(n % self.world == 0 for n in sizes0), self._calibrate)
         if self.mode != "allreduce":
             # every bucket (and the tail) is cut into `world` equal chunks: checked HERE, not discovered per step (the engine lays
             # parameters out on 64-element boundaries, so any power-of-two world up to 64 divides)
@@ -98,8 +129,6 @@ class GradReducer(object):
             bad = [n for n in sizes if n % self.world]
             if bad:
                 raise ValueError("VLP_DDP_MODE=%s: bucket sizes %r are not divisible by the world size %d" % (self.mode, bad, self.world))
-        self._avg = dist.get_backend(process_group) == "nccl"
-        self._work = []
         # comm profile (bench.py --gpus N, second un-timed pass): per collective the moment its slice was ready (stamp on the issuing
         # stream) and the moment it completed (stamp on an OBSERVER stream that waits for that collective only), plus the end of
         # backward's compute on the main stream -- so a scaling result can be read as exposed vs overlapped communication
@@ -107,6 +136,42 @@ class GradReducer(object):
         self._obs = None
         self._stamps = []          # [(label, numel, ready, done)] of the current step
         self.comm_steps = []       # one summary dict per profiled step (comm_summary())
+
+    def _calibrate(self, rounds=3):
+        """Both exchange forms on a scratch buffer of the largest bucket's size (values irrelevant), `rounds` timed rounds each after one
+        warm-up; per-form time = the slowest rank's mean (one MAX all-reduce), so all ranks agree.  ~10-30 ms once per process."""
+        n = max(hi - lo for lo, hi in self.buckets)
+        n -= n % self.world
+        buf = torch.zeros(n, device=self.flat_main.device, dtype=self.flat_main.dtype)
+        cuda = buf.is_cuda
+        saved, out = self.mode if hasattr(self, "mode") else None, {}
+        for form in ("allreduce", "rs_ag"):
+            self.mode = form
+            ts = []
+            for i in range(rounds + 1):
+                if cuda:
+                    torch.cuda.synchronize()
+                dist.barrier(group=self.pg)
+                t0 = time.perf_counter()
+                self._reduce_impl(buf)
+                for work, t in self._work:
+                    if work is not None:
+                        work.wait()
+                self._work = []
+                if cuda:
+                    torch.cuda.synchronize()
+                if i:
+                    ts.append((time.perf_counter() - t0) * 1e3)
+            out[form] = sum(ts) / len(ts)
+        if saved is not None:
+            self.mode = saved
+        else:
+            del self.mode
+        tt = torch.tensor([out["allreduce"], out["rs_ag"]], device=buf.device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=self.pg)
+        out = {"allreduce": float(tt[0]), "rs_ag": float(tt[1]), "mb": n * buf.element_size() / 2.0 ** 20}
+        self.mode_calibration = {k: round(v, 4) for k, v in out.items()}
+        return out
 
     def _observe(self, n_before, label, t, ready):
         """Profile hook: the collectives appended to self._work since n_before belong to one bucket; their completion is stamped on the
@@ -219,6 +284,8 @@ class GradReducer(object):
                               "done_after_backward_ms": round(sum(s["per_bucket"][i]["done_after_backward_ms"] for s in self.comm_steps) / n, 4)}
                              for i, b in enumerate(first)]
         out["steps"] = n
+        out["mode_rule"] = self.mode_why
+        out["mode_calibration_ms"] = self.mode_calibration
         return out
 
 
