@@ -384,6 +384,44 @@ int vlp_mask_pack_rect(const int64_t* mask, int64_t batch_stride, int64_t row_st
 int vlp_kv_append(const void* qkv_new, int64_t ld, void* cache, int32_t Lcap, int32_t B, int32_t T, int32_t start, int32_t H, void* stream);
 int vlp_argmax_rows(const void* logits, int64_t ld, int32_t rows, int32_t V, int64_t* ids, int64_t ids_stride, float* vals, int64_t vals_stride,
                     void* stream);
+/* Token-step kernels of the incremental decoder (round 6; csrc/decode.hip).  One token step of BertForSeq2SeqDecoder.forward
+ * (modeling.py:1189-1253) runs BertLayer (:360-372) on M = sequences x T rows (T = 1-2 new positions): launch- and latency-bound, so a
+ * Linear is ONE load burst per workgroup instead of a k loop, and the split-K reduce IS the LayerNorm launch.
+ *   vlp_dec_gemm: Y[M, N] = act(X[M, K] . W[N, K]^T + bias)   (the Linears of :270-272, :314, :341, :354 on the new rows), M any, N any,
+ *       K % (64 * splits) == 0, K / splits <= 768.
+ *       splits == 1, slab == NULL: fp16 result.  If kv_cache != NULL, output columns >= kv_col0 (the K | V part of a packed QKV projection,
+ *       kv_col0 % 32 == 0) are written to kv_cache[(m / kv_T) * kv_Lcap + kv_start + m % kv_T][n - kv_col0] (row pitch kv_ld) instead of Y:
+ *       the K/V append of vlp_kv_append fused into the projection (a TRUE K/V cache in place of the hidden-state history of :273-277, 386-394).
+ *       splits > 1 (or slab != NULL): raw fp32 partial sums of k slice s to slab[s][m][n] (pitch ldslab, ldslab % 8 == 0); bias / act / Y unused.
+ *   vlp_dec_reduce_ln: Y[m, :] = LayerNorm( fp16( sum_s slab[s][m, :] + bias + residual[m, :] ) ) * gamma + beta  (:315-316, :355-356: dense
+ *       output + bias, dropout p = 0, residual add, BertLayerNorm :188-192 with fp32 statistics); slabs summed in index order (deterministic).
+ *       H in {256, 512, 768, 1024}. */
+typedef struct {
+    const void* X; int64_t ldx;          /* f16 [M, K] */
+    const void* W; int64_t ldw;          /* f16 [N, K] */
+    const void* bias;                    /* f16 [N] or NULL (splits == 1 only) */
+    void* Y; int64_t ldy;                /* f16 [M, N] (splits == 1) */
+    float* slab; int64_t ldslab;         /* f32 [splits][M][ldslab] (split form) or NULL */
+    void* kv_cache; int64_t kv_ld;       /* f16 [sequences][kv_Lcap][kv_ld] or NULL */
+    int32_t kv_col0, kv_Lcap, kv_T, kv_start;
+    int32_t M, N, K, splits;
+    int32_t act;                         /* VLP_ACT_NONE | VLP_ACT_GELU (splits == 1 only) */
+} vlp_dec_gemm_args;
+int vlp_dec_gemm(const vlp_dec_gemm_args* a, void* stream);
+typedef struct {
+    const float* slab; int64_t ldslab; int32_t splits;
+    const void* bias;                    /* f16 [H] or NULL */
+    const void* residual; int64_t ldr;   /* f16 [M, H] or NULL */
+    const void* gamma; const void* beta; /* f16 [H] */
+    float eps;
+    void* Y; int64_t ldy;                /* f16 [M, H] */
+    int32_t M, H;
+} vlp_dec_reduce_ln_args;
+int vlp_dec_reduce_ln(const vlp_dec_reduce_ln_args* a, void* stream);
+/* vlp_argmax_rows2: vlp_argmax_rows with the index written to TWO destinations (the output column and the next step's input token,
+ * :1228, 1248-1250; ids_b may be NULL) by one launch: 1024 threads per row, 16-byte loads (ld % 8 == 0, logits 16-byte aligned). */
+int vlp_argmax_rows2(const void* logits, int64_t ld, int32_t rows, int32_t V, int64_t* ids_a, int64_t ids_a_stride, int64_t* ids_b, int64_t ids_b_stride,
+                     float* vals, int64_t vals_stride, void* stream);
 /* On-device input preparation (replaces per-sample CPU work of vlp/seq2seq_loader.py):
  *   vlp_mask_build: the packed attention masks (format of vlp_mask_pack, incl. the optional key-major copy) straight from the per-sample
  *       lengths, seq2seq_loader.py:292-301:  second_st = len(tokens_a)+2, second_end = len(tokens_a)+len(tokens_b)+3;

@@ -78,6 +78,122 @@ def test_argmax_rows(rows, V):
     assert int(ids[:, 0].abs().sum()) == 0 and int(ids[:, 2].abs().sum()) == 0
 
 
+# ---- round 6: the burst kernels of a token step (csrc/decode.hip) against plain torch fp32 ----------------------------------------------
+def _rand16(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).half().to(DEV)
+
+
+@pytest.mark.parametrize("M,N,Kd,act", [(128, 2304, 768, 0), (128, 3072, 768, 2), (70, 96, 128, 0), (384, 768, 768, 2), (64, 1000, 192, 0), (1, 32, 64, 0), (70, 100, 128, 0), (64, 28996, 768, 0)])
+def test_dec_gemm_plain_and_gelu(M, N, Kd, act):
+    """Y = act(X W^T + b): fp32 torch reference on the same fp16 operands; ragged M (not a multiple of 64) and N (not a multiple of 8 / 32);
+    rows / columns outside the problem are not written."""
+    x, w, b = _rand16(M, Kd, seed=1), _rand16(N, Kd, scale=0.05, seed=2), _rand16(N, seed=3)
+    ldy = (N + 7) // 8 * 8 + 8
+    y = torch.full((M + 3, ldy), 7.0, device=DEV, dtype=torch.float16)
+    K.dec_gemm(x, w, M, N, Kd, y=y, bias=b, act=K.ACT_GELU if act else K.ACT_NONE)
+    torch.cuda.synchronize()
+    ref = x.float() @ w.float().t() + b.float()
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    got = y[:M, :N].float()
+    assert float((got - ref).abs().max()) <= 2e-3 * max(1.0, float(ref.abs().max())) + 2e-3
+    n8 = (N + 7) // 8 * 8
+    assert torch.all(y[M:] == 7.0) and torch.all(y[:M, n8:] == 7.0)                 # nothing outside [M, roundup8(N)] is touched
+    assert torch.all(y[:M, N:n8] == 0)                                              # the pad columns of the last vector are written as zero
+
+
+def test_dec_gemm_qkv_writes_the_kv_cache():
+    """The QKV form: columns < H land in Y, columns >= H in the K | V cache row of (sequence, absolute position) -- what a plain GEMM
+    followed by vlp_kv_append produces, bit for bit."""
+    R, T, H, Lcap, st = 6, 2, 256, 40, 17
+    M = R * T
+    x, w, b = _rand16(M, H, seed=4), _rand16(3 * H, H, scale=0.05, seed=5), _rand16(3 * H, seed=6)
+    y = torch.zeros(M, 3 * H, device=DEV, dtype=torch.float16)
+    cache = torch.full((R, Lcap, 2 * H), 3.0, device=DEV, dtype=torch.float16)
+    K.dec_gemm(x, w, M, 3 * H, H, y=y, bias=b, kv_cache=cache, kv_col0=H, kv_Lcap=Lcap, kv_T=T, kv_start=st)
+    full = torch.zeros(M, 3 * H, device=DEV, dtype=torch.float16)
+    K.dec_gemm(x, w, M, 3 * H, H, y=full, bias=b)
+    cache2 = torch.full((R, Lcap, 2 * H), 3.0, device=DEV, dtype=torch.float16)
+    K.kv_append(full, 3 * H, cache2, Lcap, R, T, st, H)
+    torch.cuda.synchronize()
+    assert torch.equal(y[:, :H], full[:, :H]) and torch.all(y[:, H:] == 0)
+    assert torch.equal(cache, cache2)
+    ref = (x.float() @ w.float().t() + b.float())
+    assert float((full.float() - ref).abs().max()) <= 3e-3 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("M,H,Kd,S", [(128, 768, 3072, 4), (128, 768, 768, 4), (37, 256, 512, 2), (192, 512, 128, 1)])
+def test_dec_split_gemm_plus_reduce_layernorm(M, H, Kd, S):
+    """Split form + vlp_dec_reduce_ln = LayerNorm(fp16(X W^T + bias + residual)): against torch in fp32 with the same fp16 rounding of the
+    pre-LayerNorm sum; deterministic (two runs are bit-identical)."""
+    x, w = _rand16(M, Kd, seed=7), _rand16(H, Kd, scale=0.03, seed=8)
+    b, res, ga, be = _rand16(H, seed=9), _rand16(M, H, seed=10), (1 + 0.1 * _rand16(H, seed=11).float()).half(), _rand16(H, scale=0.1, seed=12)
+    outs = []
+    for _ in range(2):
+        slab = torch.full((S, M, H), float("nan"), device=DEV, dtype=torch.float32)
+        y = torch.empty(M, H, device=DEV, dtype=torch.float16)
+        K.dec_gemm(x, w, M, H, Kd, slab=slab, splits=S)
+        K.dec_reduce_ln(slab, S, b, res, ga, be, y, M, H, eps=1e-5)
+        torch.cuda.synchronize()
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    pre = (x.float() @ w.float().t() + b.float() + res.float()).half().float()
+    ref = torch.nn.functional.layer_norm(pre, (H,), ga.float(), be.float(), 1e-5)
+    # a pre-LayerNorm element that sits on an fp16 rounding boundary may round the other way under another summation order: compare with
+    # the LayerNorm of OUR fp16 pre-activation's neighbourhood -> tolerance of one fp16 ulp of the pre-activation, amplified by rstd
+    err = float((outs[0].float() - ref).abs().max())
+    assert err <= 6e-3, err
+    assert float((outs[0].float() - ref).abs().mean()) <= 4e-4
+
+
+@pytest.mark.parametrize("rows,V", [(64, 28996), (3, 1000), (5, 7), (2, 29056)])
+def test_argmax_rows2(rows, V):
+    g = torch.Generator().manual_seed(rows * 131 + V)
+    ld = (V + 63) // 64 * 64
+    x = torch.randn(rows, ld, generator=g).half()
+    x[0, V // 3] = 9.0
+    if V > 10:
+        x[0, V // 3 + 5] = 9.0                                   # a tie: the FIRST maximum wins (torch.argmax on CPU, modeling.py:1228)
+    x[:, V:] = 100.0                                             # pad columns must be ignored
+    xd = x.to(DEV)
+    a, b_, v = torch.zeros(rows, 3, dtype=torch.long, device=DEV), torch.zeros(rows, 2, dtype=torch.long, device=DEV), torch.zeros(rows, device=DEV)
+    K.argmax_rows2(xd, ld, rows, V, a[:, 1], b_[:, 0], v)
+    torch.cuda.synchronize()
+    ref_v, ref_i = x[:, :V].float().max(dim=1)
+    first = torch.tensor([int((x[r, :V].float() == ref_v[r]).nonzero()[0]) for r in range(rows)])
+    assert torch.equal(a[:, 1].cpu(), first) and torch.equal(b_[:, 0].cpu(), first) and torch.equal(v.cpu(), ref_v)
+    assert torch.all(a[:, 0] == 0) and torch.all(a[:, 2] == 0) and torch.all(b_[:, 1] == 0)
+
+
+def test_greedy_decode_fused_token_steps_equal_the_unfused_path():
+    """The same decoder with the token steps on the round-6 burst kernels and on the round-2 split-K path: identical token ids wherever the
+    top-1 / top-2 margin exceeds the fp16 noise, scores to SCORE_TOL (the two differ in fp32 summation order only)."""
+    from vlp_amd.engine import Engine
+    mk = dict(vocab_size=1536, layers=3, tasks="img2txt", seed=31, std=0.05)
+    p = O.init_params(vocab_size=mk["vocab_size"], layers=mk["layers"], tasks=mk["tasks"], seed=mk["seed"], std=mk["std"])
+    inp = [t.to(DEV) for t in decode_inputs(6, 8, 55)]
+    outs = {}
+    old = Engine.DECODE_FUSED
+    try:
+        for fused in (True, False):
+            Engine.DECODE_FUSED = fused
+            m = build_decoder(p, mk)
+            for _ in range(3):                                  # plain call, graph capture, replay
+                ids, vals = m(inp[0].half(), inp[1].half(), *inp[2:])
+            torch.cuda.synchronize()
+            outs[fused] = (ids.cpu(), vals.cpu())
+    finally:
+        Engine.DECODE_FUSED = old
+    ids_f, vals_f = outs[True]
+    ids_u, vals_u = outs[False]
+    same = ids_f == ids_u
+    assert float(same.float().mean()) >= 0.95, same
+    first_diff = [(int((~same[b]).nonzero()[0]) if (~same[b]).any() else ids_f.shape[1]) for b in range(ids_f.shape[0])]
+    for b, n in enumerate(first_diff):                           # up to the first differing token the inputs were identical
+        assert torch.allclose(vals_f[b, :n], vals_u[b, :n], rtol=SCORE_TOL, atol=SCORE_TOL)
+
+
 @pytest.mark.parametrize("B,Lq,Lk,Lcap,heads", [(2, 103, 103, 122, 12), (3, 2, 110, 122, 12), (2, 2, 33, 64, 2), (1, 64, 200, 256, 4)])
 def test_attn_decode_vs_torch(B, Lq, Lk, Lcap, heads):
     H = heads * 64

@@ -39,7 +39,8 @@ def test_ctypes_structs_match_c_layout(tmp_path):
                "vlp_mlm_loss_fwd_args": _lib.MlmLossFwdArgs, "vlp_mlm_loss_bwd_args": _lib.MlmLossBwdArgs,
                "vlp_fused_adam_args": _lib.FusedAdamArgs, "vlp_bert_adam_args": _lib.BertAdamArgs,
                "vlp_transpose_desc": _lib.TransposeDesc, "vlp_attn_decode_args": _lib.AttnDecodeArgs, "vlp_beam_select_args": _lib.BeamSelectArgs, "vlp_vis_pe_prep_args": _lib.VisPePrepArgs,
-               "vlp_pretext_fwd_args": _lib.PretextFwdArgs, "vlp_pretext_bwd_args": _lib.PretextBwdArgs}
+               "vlp_pretext_fwd_args": _lib.PretextFwdArgs, "vlp_pretext_bwd_args": _lib.PretextBwdArgs,
+               "vlp_dec_gemm_args": _lib.DecGemmArgs, "vlp_dec_reduce_ln_args": _lib.DecReduceLnArgs}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vlp_hip.h"', "int main(void) {"]
     for cname, st in structs.items():
         lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))

@@ -41,6 +41,34 @@ for name, kw in MODES:
     dt = (time.perf_counter() - t0) / n
     out[name] = {"ms_per_batch": round(dt * 1e3, 2), "captions_per_s": round(B / dt, 1), "ms_per_token_step": round(dt * 1e3 / T, 3),
                  "host_enqueue_ms": round(t_enq * 1e3, 2)}
+    if name == "greedy":
+        # roofline of a TOKEN step (HBM-bound: every step streams the encoder + head weights and the K/V history once): algorithmic bytes =
+        # fp16 weights of the 12 layers + head transform + tied vocabulary matrix, + K | V rows of every position decoded so far (B x Lk x 2H
+        # fp16 per layer, Lk averaged over the steps), + the logits written and read back by the argmax; against 8 TB/s (6.29 achievable)
+        H, NL, V = cfg.hidden_size, cfg.num_hidden_layers, cfg.vocab_size
+        w_bytes = 2 * (sum(p.numel() for n, p in m.named_parameters() if n.startswith("bert.encoder.")) + H * H + V * H)
+        lk_avg = sum(in_len + s + 1 for s in range(1, T)) / max(T - 1, 1)
+        kv_bytes = B * lk_avg * 2 * H * 2 * NL
+        logit_bytes = 2 * B * V * 2
+        step_bytes = w_bytes + kv_bytes + logit_bytes
+        # the first step (whole prefix, 102 rows per sequence) is a different regime: time it alone and subtract
+        first_args = (img, vis_pe, input_ids[:, :in_len], token_type[:, :in_len + 1].contiguous(), pos[:, :in_len + 1].contiguous(),
+                      am[:, :in_len + 1, :in_len + 1].contiguous())
+        for _ in range(2):
+            m(*first_args)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n):
+            m(*first_args)
+        torch.cuda.synchronize()
+        first_ms = (time.perf_counter() - t1) / n * 1e3
+        tok_ms = max(dt * 1e3 - first_ms, 0.0) / max(T - 1, 1)
+        out[name].update({"first_step_ms": round(first_ms, 3), "ms_per_token_step_excl_first": round(tok_ms, 4)})
+        out["roofline"] = {"bound": "hbm", "kernel": "one greedy token step (all launches of the step; B = %d, history %.0f positions)" % (B, lk_avg),
+                           "achieved": round(step_bytes / (tok_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                           "frac": round(step_bytes / (tok_ms * 1e-3) / 8e12, 4), "traffic": None,
+                           "algorithmic_mb": {"weights": round(w_bytes / 1e6, 1), "kv_history": round(kv_bytes / 1e6, 1), "logits": round(logit_bytes / 1e6, 1)},
+                           "floor_ms_at_6.29_TBps": round(step_bytes / 6.29e12 * 1e3, 4)}
     del m
 print(json.dumps(out))
 if os.environ.get("VLP_DEBUG_TUNE") == "1":

@@ -79,6 +79,17 @@ class AttnDecodeArgs(C.Structure):
                 ("k_prefix", vp), ("v_prefix", vp), ("prefix_rows_per_batch", i64), ("n_prefix", i32), ("beams", i32)]
 
 
+class DecGemmArgs(C.Structure):
+    _fields_ = [("X", vp), ("ldx", i64), ("W", vp), ("ldw", i64), ("bias", vp), ("Y", vp), ("ldy", i64), ("slab", vp), ("ldslab", i64),
+                ("kv_cache", vp), ("kv_ld", i64), ("kv_col0", i32), ("kv_Lcap", i32), ("kv_T", i32), ("kv_start", i32),
+                ("M", i32), ("N", i32), ("K", i32), ("splits", i32), ("act", i32)]
+
+
+class DecReduceLnArgs(C.Structure):
+    _fields_ = [("slab", vp), ("ldslab", i64), ("splits", i32), ("bias", vp), ("residual", vp), ("ldr", i64), ("gamma", vp), ("beta", vp),
+                ("eps", f32), ("Y", vp), ("ldy", i64), ("M", i32), ("H", i32)]
+
+
 class VisPePrepArgs(C.Structure):
     _fields_ = [("bbox", vp), ("cls", vp), ("ld_cls", i64), ("out", vp), ("ld_out", i64), ("B", i32), ("Nv", i32), ("n_cls", i32),
                 ("pad_to", i32), ("cls_is_f32", i32), ("eps", f32)]
@@ -155,6 +166,9 @@ SYMBOLS = {
     "vlp_attn_decode": (C.c_int, [C.POINTER(AttnDecodeArgs), vp]),
     "vlp_mask_pack_rect": (C.c_int, [vp, i64, i64, vp, i32, i32, i32, i32, vp]),
     "vlp_kv_append": (C.c_int, [vp, i64, vp, i32, i32, i32, i32, i32, vp]),
+    "vlp_dec_gemm": (C.c_int, [C.POINTER(DecGemmArgs), vp]),
+    "vlp_dec_reduce_ln": (C.c_int, [C.POINTER(DecReduceLnArgs), vp]),
+    "vlp_argmax_rows2": (C.c_int, [vp, i64, i32, i32, vp, i64, vp, i64, vp, i64, vp]),
     "vlp_logsoftmax_topk": (C.c_int, [vp, i64, i32, i32, i32, vp, i32, i32, vp, vp, vp]),
     "vlp_beam_select": (C.c_int, [C.POINTER(BeamSelectArgs), vp]),
     "vlp_kv_gather": (C.c_int, [vp, i64, vp, i64, vp, i32, i32, i32, i32, vp]),
@@ -394,6 +408,29 @@ def attn_decode(q, ld_q, q_rows, k, v, ld_kv, kv_rows, mask, ctx, B, Lq, Lk, hea
     a = AttnDecodeArgs(ptr(q), ld_q, q_rows, ptr(k), ptr(v), ld_kv, kv_rows, ptr(mask), ptr(ctx), ctx.stride(0), B, Lq, Lk, heads, scale,
                        ptr(k_prefix), ptr(v_prefix), prefix_rows, n_prefix, beams)
     _check(load().vlp_attn_decode(C.byref(a), stream_ptr()))
+
+
+def dec_gemm(x, w, M, N, Kd, y=None, bias=None, act=0, slab=None, splits=1, kv_cache=None, kv_col0=0, kv_Lcap=0, kv_T=1, kv_start=0):
+    """Token-step Linear (csrc/decode.hip): y [M, N] fp16 (optionally K | V columns >= kv_col0 into kv_cache [seq, kv_Lcap, ld]) or, with
+    `slab` (fp32 [splits, M, ldslab]), raw split-K partial sums for dec_reduce_ln."""
+    _req_cuda(x, w, y, bias, slab, kv_cache)
+    a = DecGemmArgs(ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), y.stride(0) if y is not None else 0,
+                    ptr(slab), slab.stride(1) if slab is not None else 0, ptr(kv_cache), kv_cache.stride(1) if kv_cache is not None else 0,
+                    kv_col0, kv_Lcap, kv_T, kv_start, M, N, Kd, splits, act)
+    _check(load().vlp_dec_gemm(C.byref(a), stream_ptr()))
+
+
+def dec_reduce_ln(slab, splits, bias, residual, gamma, beta, y, M, H, eps=1e-5):
+    _req_cuda(slab, bias, residual, gamma, beta, y)
+    a = DecReduceLnArgs(ptr(slab), slab.stride(1), splits, ptr(bias), ptr(residual), residual.stride(0) if residual is not None else 0,
+                        ptr(gamma), ptr(beta), eps, ptr(y), y.stride(0), M, H)
+    _check(load().vlp_dec_reduce_ln(C.byref(a), stream_ptr()))
+
+
+def argmax_rows2(logits, ld, rows, V, ids_a, ids_b, vals):
+    _req_cuda(logits, ids_a, ids_b, vals)
+    _check(load().vlp_argmax_rows2(ptr(logits), ld, rows, V, ptr(ids_a), ids_a.stride(0), ptr(ids_b), ids_b.stride(0) if ids_b is not None else 0,
+                                   ptr(vals), vals.stride(0), stream_ptr()))
 
 
 def mask_pack_rect(mask_view, out_u8, B, Lq, Lk, Lkp):

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 BUILD = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libvlp_hip.so")
-SOURCES = ["api.cpp", "gemm_nt.hip", "gemm_nt_wp.hip", "gemm_nt_ps.hip", "gemm_nt_splitk.hip", "gemm_tn.hip", "attention.hip", "layernorm.hip", "elementwise.hip", "loss.hip", "adam.hip", "pretext.hip"]
+SOURCES = ["api.cpp", "gemm_nt.hip", "gemm_nt_wp.hip", "gemm_nt_ps.hip", "gemm_nt_splitk.hip", "gemm_tn.hip", "attention.hip", "layernorm.hip", "elementwise.hip", "loss.hip", "adam.hip", "pretext.hip", "decode.hip"]
 # investigation variants (phased / k32 NT kernels, further wave-pipelined configurations, two-kernel attention backward, stream-K grouped
 # wgrad): `python -m vlp_amd.build --lab` -> vlp_amd/libvlp_hip_lab.so (-DVLP_LAB_BUILD), selected with VLP_HIP_LIB=...; never the product library
 LAB_SOURCES = ["gemm_nt_ph.hip", "gemm_nt_k32.hip"]

@@ -1423,11 +1423,114 @@ extern "C" int vlp_attn_fwd(const vlp_attn_fwd_args* a, void* stream) {
     return launch_attn_fwd(p, (hipStream_t)stream);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Token-step attention of the incremental decoder (round 6): Lq <= 2 new queries per sequence against Lk <= 128 cached keys.  The general
+// forward kernel above stages K and V of the head in LDS behind two workgroup barriers and walks 16-query tiles -- 10.2 us per layer for
+// 2 x 110 scores per (sequence, head).  Here ONE WAVE owns a (sequence, head) and nothing goes through LDS: the K and V rows are requested
+// up front as whole 128-byte lines (8 lanes per row, 16 rows-of-8 groups: lane l holds 16-byte chunk l & 7 of rows 8 i + (l >> 3)), a score
+// is 4 v_dot2_f32_f16 per lane + a 3-step DPP reduction over the row's 8 lanes, the softmax statistics and P.V reduce over the 8 row groups of
+// a wave (row rotate + v_permlane16/32_swap; the ds_bpermute form of __shfl_xor cost ~100 dependent cycles per exchange: 9 us per launch).  (A first form with one WHOLE row per lane -- 16 loads of 16 bytes at a 3 KB stride per lane -- measured 12.1 us:
+// every load instruction touched 64 cache lines.)  Same arithmetic as the forward tile: scores in the log2 domain with the additive -10000
+// mask term, P~ = exp2(s - max) rounded to fp16 for P.V, the fp32 sum of the UNROUNDED P~ as the normaliser, one rounding of the context.
+// ---------------------------------------------------------------------------------------------
+template <int LQ>
+__global__ __launch_bounds__(256) void attn_decode_small_kernel(AttnParams p) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= p.B * p.heads) return;
+    const int b = item / p.heads, h = item - b * p.heads;
+    const int Lk = p.Lk;
+    const int rg = lane >> 3, c = lane & 7;                 // row inside a group of 8, 16-byte chunk of the 128-byte head row
+    constexpr int NG = 16;                                  // 16 groups x 8 rows = 128 keys
+    const int ng = (Lk + 7) >> 3;                           // groups that hold a real key (wave-uniform)
+    f16x8 kr[NG], vr[NG];
+    const int64_t own_base = (int64_t)b * p.bs_kv, pre_base = (int64_t)(b / p.beams) * p.bs_kv2;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        if (i < ng) {
+            // branch-free source select (a divergent branch per group made the compiler wait for every group's loads before the next
+            // group's branch: 16 serialized round trips, 13.5 us)
+            const int kc = min(8 * i + rg, Lk - 1);
+            const bool pre = kc < p.n_prefix;
+            const int64_t off = ((pre ? pre_base : own_base) + kc) * p.ld_kv + h * HD + 8 * c;
+            kr[i] = ld8((pre ? p.k2 : p.k) + off);
+            vr[i] = ld8((pre ? p.v2 : p.v) + off);
+        }
+    }
+    f16x8 qr[LQ];
+    uint8_t mb[LQ][NG];                                     // mask bytes of this lane's rows: requested with everything else (a load inside the score loop is a round trip per group)
+#pragma unroll
+    for (int q = 0; q < LQ; ++q) {
+        const int qq = min(q, p.Lq - 1);
+        qr[q] = ld8(p.q + ((int64_t)b * p.bs_q + qq) * p.ld_q + h * HD + 8 * c);
+        const uint8_t* mrow = p.mask + ((int64_t)b * p.Lq + qq) * p.Lp;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) mb[q][i] = (i < ng) ? mrow[min(8 * i + rg, p.Lp - 1)] : (uint8_t)2;
+    }
+    const float sc2 = p.scale * LOG2E_F;
+#pragma unroll
+    for (int q = 0; q < LQ; ++q) {
+        if (q >= p.Lq) break;
+        float s2[NG];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            s2[i] = -INFINITY;
+            if (i < ng) {
+                const int key = 8 * i + rg;
+                const uint32_t mbyte = mb[q][i];
+                float acc = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc = __builtin_amdgcn_fdot2((f16x2){kr[i][2 * e], kr[i][2 * e + 1]}, (f16x2){qr[q][2 * e], qr[q][2 * e + 1]}, acc, false);
+                acc = sum8(acc);                            // all 8 lanes of the row hold its score (DPP: no LDS round trip)
+                const float term = (key >= Lk || mbyte >= 2u) ? -INFINITY : (mbyte == 1u ? 0.f : -MASK_C1);
+                s2[i] = fmaf(acc, sc2, term);
+                mx = fmaxf(mx, s2[i]);
+            }
+        }
+        mx = max_over_groups8(mx);
+        float sum = 0.f;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            if (i < ng) {
+                const float pr = __builtin_amdgcn_exp2f(s2[i] - mx);
+                sum += pr;
+                const float ph = (float)(f16)pr;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = fmaf(ph, (float)vr[i][e], o[e]);
+            }
+        }
+        sum = sum_over_groups8(sum);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = sum_over_groups8(o[e]);
+        if (rg == 0) {
+            const float inv = 1.f / sum;
+            f16x8 ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = (f16)(o[e] * inv);
+            st8(p.ctx + ((int64_t)b * p.Lq + q) * p.ld_ctx + h * HD + 8 * c, ov);
+        }
+    }
+}
+
+static int launch_attn_decode_small(AttnParams& p, hipStream_t s) {
+    const dim3 grid(cdiv(p.B * p.heads, 4));
+    if (p.Lq == 1) hipLaunchKernelGGL(attn_decode_small_kernel<1>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(attn_decode_small_kernel<2>, grid, dim3(256), 0, s, p);
+    VLP_CHECK_LAUNCH("vlp_attn_decode");
+    return VLP_OK;
+}
+
 extern "C" int vlp_attn_decode(const vlp_attn_decode_args* a, void* stream) {
     VLP_CHECK_ARG(a != nullptr && a->q && a->k && a->v && a->mask && a->ctx, "vlp_attn_decode: null operand");
     VLP_ENTER(a->q, "vlp_attn_decode");
     VLP_CHECK_ARG(a->B > 0 && a->heads > 0 && a->Lq > 0 && a->Lk > 0 && a->Lk <= 256, "vlp_attn_decode: bad shape (Lk <= 256)");
     VLP_CHECK_ARG(a->ld_q % 8 == 0 && a->ld_kv % 8 == 0 && a->ld_ctx % 4 == 0, "vlp_attn_decode: leading dims");
+    const bool ctx16 = a->ld_ctx % 8 == 0 && (uintptr_t)a->ctx % 16 == 0;
     VLP_CHECK_ARG(((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) % 16 == 0 && (uintptr_t)a->ctx % 8 == 0 && (uintptr_t)a->mask % 4 == 0,
                   "vlp_attn_decode: alignment");
     VLP_CHECK_ARG(a->kv_rows_per_batch >= a->Lk && a->q_rows_per_batch >= a->Lq, "vlp_attn_decode: batch strides");
@@ -1448,6 +1551,10 @@ extern "C" int vlp_attn_decode(const vlp_attn_decode_args* a, void* stream) {
         p.k2 = (const f16*)a->k_prefix; p.v2 = (const f16*)a->v_prefix; p.bs_kv2 = a->prefix_rows_per_batch;
         p.n_prefix = a->n_prefix; p.beams = a->beams;
     }
+    if (p.beams < 1) p.beams = 1;
+    // token steps (1-2 new rows per sequence, history <= 128): the wave-per-(sequence, head) kernel; VLP_ATTN_DECODE_SMALL=0: the general kernel
+    static const int small_on = [] { const char* e = getenv("VLP_ATTN_DECODE_SMALL"); return (e && e[0] == '0') ? 0 : 1; }();
+    if (small_on && ctx16 && a->Lq <= 2 && a->Lk <= 128) return launch_attn_decode_small(p, (hipStream_t)stream);
     return launch_attn_fwd(p, (hipStream_t)stream);
 }
 

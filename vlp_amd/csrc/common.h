@@ -170,6 +170,41 @@ DEVFN void gelu_and_grad_f(float x, float& gl, float& gp) {
     gp = fmaf(x * 0.39894228040143267794f, e, cdf);
 }
 
+// Cross-lane exchanges that stay in the VALU (no LDS round trip: a ds_bpermute-based __shfl_xor costs ~100 cycles of dependent latency each):
+//   lanes ^1, ^2 inside a quad and the mirror inside 8 lanes by DPP, ^8 by a rotate inside the row of 16, ^16 / ^32 by the gfx950
+//   v_permlane16_swap / v_permlane32_swap (with both operands the same value the two results are "mine" and "the partner's").
+#define VLP_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
+DEVFN float lane_xor1(float v) { return VLP_DPP(v, 0xB1); }          // quad_perm [1,0,3,2]
+DEVFN float lane_xor2(float v) { return VLP_DPP(v, 0x4E); }          // quad_perm [2,3,0,1]
+DEVFN float lane_mirror8(float v) { return VLP_DPP(v, 0x141); }      // row_half_mirror: lane i <-> 7 - i inside every 8 lanes
+DEVFN float lane_xor8(float v) { return VLP_DPP(v, 0x128); }         // row_ror:8 inside every 16 lanes
+// (inline asm, not __builtin_amdgcn_permlane{16,32}_swap: with the builtin hipcc / ROCm 7.2 folded op(r[0], r[1]) to r[0] -- the v_max / v_add
+// behind the swap was missing from the ISA of attn_decode_small_kernel, also with the second operand made opaque.  The two v_nop are the
+// wait states the "VALU write -> v_permlane read" hazard needs, cdna_hip_programming.md T21.)
+DEVFN void lane_pair16(float v, float& a, float& b) {                // a + b / max(a, b) = the ^16 combination, whichever of the two is "mine"
+    unsigned x = __builtin_bit_cast(unsigned, v), y = x;
+    asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    a = __builtin_bit_cast(float, x); b = __builtin_bit_cast(float, y);
+}
+DEVFN void lane_pair32(float v, float& a, float& b) {
+    unsigned x = __builtin_bit_cast(unsigned, v), y = x;
+    asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    a = __builtin_bit_cast(float, x); b = __builtin_bit_cast(float, y);
+}
+DEVFN float sum8(float v) { v += lane_xor1(v); v += lane_xor2(v); return v + lane_mirror8(v); }     // all 8 lanes of a group end with the group's sum
+DEVFN float sum_over_groups8(float v) {                              // lanes with equal (lane & 7): sum over the 8 groups of a wave
+    v += lane_xor8(v);
+    float a, b;
+    lane_pair16(v, a, b); v = a + b;
+    lane_pair32(v, a, b); return a + b;
+}
+DEVFN float max_over_groups8(float v) {
+    v = fmaxf(v, lane_xor8(v));
+    float a, b;
+    lane_pair16(v, a, b); v = fmaxf(a, b);
+    lane_pair32(v, a, b); return fmaxf(a, b);
+}
+
 DEVFN float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -912,6 +912,7 @@ class Engine(object):
                   # static copies of the caller's per-position inputs, so that the launches of a token step have call-invariant arguments
                   mask_static=i64(R, Lcap, Lcap), tt_steps=i64(Lcap, R, 2), pid_steps=i64(Lcap, R, 2),
                   out_ids=i64(B, Lcap), out_val=f(B, Lcap), plans={}, calls=0, plan_stream=None,
+                  slab=f(self.DEC_SPLITS, R * 2, H),      # fp32 split-K partial sums of the token-step out-projection / FFN-down (vlp_dec_gemm -> vlp_dec_reduce_ln)
                   sk_ws=torch.empty(K.gemm_nt_splitk_workspace_bytes(min(M, 1024), max(I, 3 * H), max(self.SKINNY_SPLITS)), device=dev,
                                     dtype=torch.uint8))
         if Kb > 1:
@@ -956,6 +957,44 @@ class Engine(object):
         self._nt(ws["h1"], self.P("vis_embed.2.weight"), ws["vis_h"], Mv, H, 2048, bias=self.P("vis_embed.2.bias"), act=K.ACT_RELU)
         self._nt(ws["vpe_in"], ws["wpe_pad"], ws["vispe_h"], Mv, H, PE_PAD, bias=self.P("vis_pe_embed.0.bias"), act=K.ACT_RELU)
 
+    # Token steps on the burst kernels of csrc/decode.hip (round 6): 7 launches per layer instead of 12 (vlp_dec_gemm QKV with the K/V append
+    # fused, attention, out-projection as 4 k slices, slab reduce + bias + residual + LayerNorm in one launch, FFN-up + GeLU, FFN-down as 4 k
+    # slices, reduce + LayerNorm).  VLP_DECODE_FUSED=0: the round-2 path (split-K skinny GEMMs, separate reduces / kv_append / LayerNorms).
+    DECODE_FUSED = os.environ.get("VLP_DECODE_FUSED", "1") == "1"
+    DEC_SPLITS = 4
+    DEC_VOCAB = os.environ.get("VLP_DECODE_VOCAB_BURST", "1") == "1"      # the tied vocabulary projection of a token step on vlp_dec_gemm too
+
+    def _decode_layers_fused(self, ws, caches, Lcap, x, alt, maskb, R, T, st, prefix):
+        """The 12 BertLayers of a token step (M = R * T <= a few hundred rows) on vlp_dec_gemm / vlp_dec_reduce_ln.  Same arithmetic and
+        rounding points as the unfused path (fp16 GEMM outputs, fp16 pre-LayerNorm sums, fp32 LayerNorm statistics); only the fp32
+        summation order of the contractions differs."""
+        model = self._model()
+        cfg = model.config
+        H, I, A, NL = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers
+        scale = 1.0 / math.sqrt(H // A)
+        Lk, M, S = st + T, R * T, self.DEC_SPLITS
+        slab = ws["slab"].view(-1)[:S * M * H].view(S, M, H)        # slab s holds rows [s * M, (s + 1) * M)
+        for i in range(NL):
+            Ln = "bert.encoder.layer.%d." % i
+            kv = caches[i]
+            K.dec_gemm(x, self.P(Ln + "attention.self.query.weight"), M, 3 * H, H, y=ws["qkv"], bias=self.P(Ln + "attention.self.query.bias"),
+                       kv_cache=kv, kv_col0=H, kv_Lcap=Lcap, kv_T=T, kv_start=st)
+            if prefix is None:
+                K.attn_decode(ws["qkv"], 3 * H, T, kv, kv[:, :, H:], 2 * H, Lcap, maskb, ws["ctx"], R, T, Lk, A, scale)
+            else:
+                pk = prefix[0][i]
+                K.attn_decode(ws["qkv"], 3 * H, T, kv, kv[:, :, H:], 2 * H, Lcap, maskb, ws["ctx"], R, T, Lk, A, scale, k_prefix=pk,
+                              v_prefix=pk[:, :, H:], prefix_rows=Lcap, n_prefix=prefix[1], beams=prefix[2])
+            K.dec_gemm(ws["ctx"], self.P(Ln + "attention.output.dense.weight"), M, H, H, slab=slab, splits=S)
+            K.dec_reduce_ln(slab, S, self.P(Ln + "attention.output.dense.bias"), x, self.P(Ln + "attention.output.LayerNorm.weight"),
+                            self.P(Ln + "attention.output.LayerNorm.bias"), ws["x1"], M, H)
+            K.dec_gemm(ws["x1"], self.P(Ln + "intermediate.dense.weight"), M, I, H, y=ws["g"], bias=self.P(Ln + "intermediate.dense.bias"), act=K.ACT_GELU)
+            K.dec_gemm(ws["g"], self.P(Ln + "output.dense.weight"), M, H, I, slab=slab, splits=S)
+            K.dec_reduce_ln(slab, S, self.P(Ln + "output.dense.bias"), ws["x1"], self.P(Ln + "output.LayerNorm.weight"),
+                            self.P(Ln + "output.LayerNorm.bias"), alt, M, H)
+            x, alt = alt, x
+        return x
+
     def _decode_model_step(self, ws, caches, Lcap, xids, tt, pid, mask_view, R, T, st, first, prefix=None):
         """One incremental forward of R sequences x T new tokens at absolute positions st..st+T-1: Q/K/V projection of the new
         tokens, K|V appended to the per-layer caches, attention over positions 0..st+T-1, LM head on the last ([MASK]) slot.
@@ -979,7 +1018,11 @@ class Engine(object):
         K.layernorm_fwd(ws["emb_pre"], self.P(E + "LayerNorm.weight"), self.P(E + "LayerNorm.bias"), x, M, H)
         def same_in_all_layers(suffix):
             return lambda: [self.P("bert.encoder.layer.%d.%s" % (j, suffix)) for j in range(NL)]
-        for i in range(NL):
+        fused = (self.DECODE_FUSED and not first and M <= 1024 and H % 256 == 0 and H <= 768 and I % (64 * self.DEC_SPLITS) == 0 and
+                 I // self.DEC_SPLITS <= 768 and H % (64 * self.DEC_SPLITS) == 0)
+        if fused:
+            x = self._decode_layers_fused(ws, caches, Lcap, x, alt, maskb, R, T, st, prefix)
+        for i in range(0 if not fused else NL, NL):
             Ln = "bert.encoder.layer.%d." % i
             kv = caches[i]
             self._nt_skinny(x, self.P(Ln + "attention.self.query.weight"), ws["qkv"], M, 3 * H, H, ws["sk_ws"], tune_ws=same_in_all_layers("attention.self.query.weight"), bias=self.P(Ln + "attention.self.query.bias"))
@@ -1000,10 +1043,18 @@ class Engine(object):
             K.layernorm_fwd(ws["pre"], self.P(Ln + "output.LayerNorm.weight"), self.P(Ln + "output.LayerNorm.bias"), alt, M, H)
             x, alt = alt, x
         # ---- LM head on the [MASK] slot (:1226-1228 / :1293-1296) ----------------------------------
-        K.gather_rows(x, H, ws["last_first"] if first else ws["last_step"], ws["sel"], H, R, 1, T, H)
-        self._nt(ws["sel"], self.P(C + "transform.dense.weight"), ws["tg"], R, H, H, bias=self.P(C + "transform.dense.bias"), act=K.ACT_GELU)
+        if fused:
+            # the [MASK] slot is the LAST of the T new rows of every sequence: a strided view of x (row pitch T * H), no gather launch
+            sel = x.view(-1)[:R * T * H].view(R, T * H)[:, (T - 1) * H:]
+            K.dec_gemm(sel, self.P(C + "transform.dense.weight"), R, H, H, y=ws["tg"], bias=self.P(C + "transform.dense.bias"), act=K.ACT_GELU)
+        else:
+            K.gather_rows(x, H, ws["last_first"] if first else ws["last_step"], ws["sel"], H, R, 1, T, H)
+            self._nt(ws["sel"], self.P(C + "transform.dense.weight"), ws["tg"], R, H, H, bias=self.P(C + "transform.dense.bias"), act=K.ACT_GELU)
         K.layernorm_fwd(ws["tg"], self.P(C + "transform.LayerNorm.weight"), self.P(C + "transform.LayerNorm.bias"), ws["tln"], R, H)
-        self._nt(ws["tln"], self.P("bert.embeddings.word_embeddings.weight"), ws["logits"], R, V, H, bias=self.P(C + "bias"), ldy=ws["Vp"])
+        if fused and self.DEC_VOCAB:
+            K.dec_gemm(ws["tln"], self.P("bert.embeddings.word_embeddings.weight"), R, V, H, y=ws["logits"], bias=self.P(C + "bias"))
+        else:
+            self._nt(ws["tln"], self.P("bert.embeddings.word_embeddings.weight"), ws["logits"], R, V, H, bias=self.P(C + "bias"), ldy=ws["Vp"])
 
     def _decode_static_inputs(self, ws, token_type_ids, position_ids, attention_mask, in_len, out_len, rep):
         """Copies the caller's per-position inputs of the token steps s >= 1 into workspace buffers (one torch op each), so that the
@@ -1080,8 +1131,7 @@ class Engine(object):
                 for dst in (out_ids[:, s], ws["xids"][:, 0]):                   # same (seed, stream) -> same draw; 2nd = next input token
                     K.sample_rows(ws["logits"], ws["Vp"], B, V, self.base_seed + self.step_seed, 7001, dst, out_val[:, s])
             else:
-                K.argmax_rows(ws["logits"], ws["Vp"], B, V, out_ids[:, s], out_val[:, s])
-                K.argmax_rows(ws["logits"], ws["Vp"], B, V, ws["xids"][:, 0], out_val[:, s])      # next step's first input token
+                K.argmax_rows2(ws["logits"], ws["Vp"], B, V, out_ids[:, s], ws["xids"][:, 0], out_val[:, s])      # + next step's first input token
 
         # step 0: the whole prefix + [MASK]
         self._decode_model_step(ws, ws["kv"], out_len, x_first, token_type_ids[:, :T0].contiguous(), position_ids[:, :T0].contiguous(),

@@ -1,9 +1,10 @@
 """Kernel-variant selection for the GEMM entry points -- deterministic by default.
 
-Every variant of vlp_gemm_nt / vlp_gemm_tn computes the same contraction, but tile shape and split factor change the
-fp32 summation order, i.e. the low-order bits of the fp16 results.  Round 1 chose variants by timing candidates on first
-use, which made numerics (and HBM traffic) depend on the box and on timer noise.  Now the choice is a pure function of
-the problem shape:
+Every variant of vlp_gemm_nt computes the same contraction with every output element's fp32 chain walked in ascending k: the NT variants
+are BIT-IDENTICAL to one another (measured in round 4 on the step's shapes, tests/test_00_kernels_gpu.py::test_gemm_nt_variant_identity,
+profiles/r04_nt_variant_identity.json); they differ in speed only.  vlp_gemm_tn's split-M factor does change the fp32 summation order of a
+weight gradient (low-order bits).  Round 1 chose variants by timing candidates on first use, which made speed, HBM traffic and -- for the
+wgrads -- the low-order bits depend on the box and on timer noise.  Now the choice is a pure function of the problem shape:
 
   1. `VLP_NT_VARIANT` / `VLP_TN_CHOICE` environment overrides (A/B runs);
   2. the committed table `vlp_amd/tuned_gfx950.json` (measured once on an MI355X with `python -m vlp_amd.tuning --tune`,
