@@ -194,7 +194,9 @@ def test_greedy_decode_fused_token_steps_equal_the_unfused_path():
         assert torch.allclose(vals_f[b, :n], vals_u[b, :n], rtol=SCORE_TOL, atol=SCORE_TOL)
 
 
-@pytest.mark.parametrize("B,Lq,Lk,Lcap,heads", [(2, 103, 103, 122, 12), (3, 2, 110, 122, 12), (2, 2, 33, 64, 2), (1, 64, 200, 256, 4)])
+# (Lq <= 2, Lk <= 128: the wave-per-(sequence, head) token-step kernel of round 6 -- every group count 1 .. 16 of its 8-row groups is hit below)
+@pytest.mark.parametrize("B,Lq,Lk,Lcap,heads", [(2, 103, 103, 122, 12), (3, 2, 110, 122, 12), (2, 2, 33, 64, 2), (1, 64, 200, 256, 4)] +
+                         [(2, 1 + (lk % 2), lk, 128, 3) for lk in (1, 7, 8, 9, 16, 23, 31, 40, 47, 50, 63, 64, 65, 72, 81, 95, 104, 111, 113, 120, 127, 128)])
 def test_attn_decode_vs_torch(B, Lq, Lk, Lcap, heads):
     H = heads * 64
     g = torch.Generator().manual_seed(Lk * 7 + Lq)

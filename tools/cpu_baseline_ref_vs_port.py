@@ -4,7 +4,7 @@
 optimization.py BertAdam, loaded by oracle/ref_loader.py) and the port run the same training step -- the loop body of
 vlp/run_img2txt_dist.py:462-586 on a synthetic COCO-shape batch: forward, backward, BertAdam.step -- side by side on the same threads.
 B = 16, L = 167 (100 regions + 64 tokens + 3), 12 layers, vocab 28 996, fp32 (BASELINE.md section 3 protocol).
-Writes profiles/r03_cpu_baseline_reference_vs_port.json; bench.py quotes the ratio in cpu_baseline.sample.
+Writes profiles/r06_cpu_baseline_reference_vs_port.json; bench.py quotes the ratio in cpu_baseline.sample.
 usage: python tools/cpu_baseline_ref_vs_port.py [steps] [threads]"""
 import json
 import os

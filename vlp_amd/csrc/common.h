@@ -173,24 +173,57 @@ DEVFN void gelu_and_grad_f(float x, float& gl, float& gp) {
 // Cross-lane exchanges that stay in the VALU (no LDS round trip: a ds_bpermute-based __shfl_xor costs ~100 cycles of dependent latency each):
 //   lanes ^1, ^2 inside a quad and the mirror inside 8 lanes by DPP, ^8 by a rotate inside the row of 16, ^16 / ^32 by the gfx950
 //   v_permlane16_swap / v_permlane32_swap (with both operands the same value the two results are "mine" and "the partner's").
+#ifdef VLP_SHFL_BPERMUTE      // A/B builds (tools/build_variant_lib.sh <out.so> -DVLP_SHFL_BPERMUTE): every exchange as the ds_bpermute __shfl_xor of rounds 1-5
+DEVFN float lane_xor1(float v) { return __shfl_xor(v, 1, 64); }
+DEVFN float lane_xor2(float v) { return __shfl_xor(v, 2, 64); }
+DEVFN float lane_mirror8(float v) { return __shfl_xor(v, 4, 64); }   // (equal to the mirror wherever the quads are uniform: every use below)
+DEVFN float lane_xor8(float v) { return __shfl_xor(v, 8, 64); }
+#else
 #define VLP_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
 DEVFN float lane_xor1(float v) { return VLP_DPP(v, 0xB1); }          // quad_perm [1,0,3,2]
 DEVFN float lane_xor2(float v) { return VLP_DPP(v, 0x4E); }          // quad_perm [2,3,0,1]
 DEVFN float lane_mirror8(float v) { return VLP_DPP(v, 0x141); }      // row_half_mirror: lane i <-> 7 - i inside every 8 lanes
 DEVFN float lane_xor8(float v) { return VLP_DPP(v, 0x128); }         // row_ror:8 inside every 16 lanes
+#endif
 // (inline asm, not __builtin_amdgcn_permlane{16,32}_swap: with the builtin hipcc / ROCm 7.2 folded op(r[0], r[1]) to r[0] -- the v_max / v_add
 // behind the swap was missing from the ISA of attn_decode_small_kernel, also with the second operand made opaque.  The two v_nop are the
 // wait states the "VALU write -> v_permlane read" hazard needs, cdna_hip_programming.md T21.)
-DEVFN void lane_pair16(float v, float& a, float& b) {                // a + b / max(a, b) = the ^16 combination, whichever of the two is "mine"
-    unsigned x = __builtin_bit_cast(unsigned, v), y = x;
-    asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+#if defined(VLP_SHFL_BPERMUTE) || defined(VLP_PAIR_BPERMUTE)
+DEVFN void lane_pair16_u(unsigned v, unsigned& a, unsigned& b) { a = v; b = (unsigned)__shfl_xor((int)v, 16, 64); }
+DEVFN void lane_pair32_u(unsigned v, unsigned& a, unsigned& b) { a = v; b = (unsigned)__shfl_xor((int)v, 32, 64); }
+#else
+#ifdef VLP_PAIR_PAD
+#define VLP_PL_PRE "s_nop 7\n\t"
+#define VLP_PL_POST "\n\ts_nop 7"
+#else
+#define VLP_PL_PRE "v_nop\n\tv_nop\n\t"
+#define VLP_PL_POST ""
+#endif
+DEVFN void lane_pair16_u(unsigned v, unsigned& a, unsigned& b) {     // op(a, b) = the ^16 combination of v, whichever of the two is "mine"
+    a = v; b = v;
+    asm volatile(VLP_PL_PRE "v_permlane16_swap_b32 %0, %1" VLP_PL_POST : "+v"(a), "+v"(b));
+}
+DEVFN void lane_pair32_u(unsigned v, unsigned& a, unsigned& b) {
+    a = v; b = v;
+    asm volatile(VLP_PL_PRE "v_permlane32_swap_b32 %0, %1" VLP_PL_POST : "+v"(a), "+v"(b));
+}
+#endif
+DEVFN void lane_pair16(float v, float& a, float& b) {
+    unsigned x, y;
+    lane_pair16_u(__builtin_bit_cast(unsigned, v), x, y);
     a = __builtin_bit_cast(float, x); b = __builtin_bit_cast(float, y);
 }
 DEVFN void lane_pair32(float v, float& a, float& b) {
-    unsigned x = __builtin_bit_cast(unsigned, v), y = x;
-    asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    unsigned x, y;
+    lane_pair32_u(__builtin_bit_cast(unsigned, v), x, y);
     a = __builtin_bit_cast(float, x); b = __builtin_bit_cast(float, y);
 }
+DEVFN float add_xor16(float v) { float a, b; lane_pair16(v, a, b); return a + b; }       // v + (v of lane ^ 16): bitwise the __shfl_xor form (a + b commutes)
+DEVFN float add_xor32(float v) { float a, b; lane_pair32(v, a, b); return a + b; }
+DEVFN float max_xor16(float v) { float a, b; lane_pair16(v, a, b); return fmaxf(a, b); }
+DEVFN float max_xor32(float v) { float a, b; lane_pair32(v, a, b); return fmaxf(a, b); }
+DEVFN unsigned or_xor16(unsigned v) { unsigned a, b; lane_pair16_u(v, a, b); return a | b; }
+DEVFN unsigned or_xor32(unsigned v) { unsigned a, b; lane_pair32_u(v, a, b); return a | b; }
 DEVFN float sum8(float v) { v += lane_xor1(v); v += lane_xor2(v); return v + lane_mirror8(v); }     // all 8 lanes of a group end with the group's sum
 DEVFN float sum_over_groups8(float v) {                              // lanes with equal (lane & 7): sum over the 8 groups of a wave
     v += lane_xor8(v);
@@ -205,6 +238,13 @@ DEVFN float max_over_groups8(float v) {
     lane_pair32(v, a, b); return fmaxf(a, b);
 }
 
+// Whole-wave reductions: the ds_bpermute butterflies of rounds 1-5 (hipcc lowers __shfl_xor to ds_bpermute_b32).  Round 6 measured the VALU
+// forms above in their place (every reduction of LayerNorm / attention / the loss kernels; profiles/r06_instep_ab_lane_exchanges.txt):
+// LayerNorm forward 10.0 -> 9.7 us, backward 15.1 -> 14.7 us in the lab, 9.105 / 9.140 vs 9.163 / 9.123 ms per step in the same-box A/B -- inside
+// the noise (the chains hide behind the other resident waves) -- AND the asm v_permlane16/32_swap form made attn_fwd_kernel<16, 8> with dropout
+// draw wrong keep decisions for one hash word of key tile 8 (tests/test_00_kernels_gpu.py::test_attention_forward_dropout_decisions[223-100];
+// deterministic, not cured by wait states, not root-caused).  The training kernels therefore keep the proven form; the VALU exchanges are
+// used by attn_decode_small_kernel only (its own tests cover them), where they are worth 2.5 us of a 12.8 us launch.
 DEVFN float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
