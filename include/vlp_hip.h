@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VLP_ABI_VERSION 4
+#define VLP_ABI_VERSION 5      /* 5 (round 6): + vlp_dec_gemm, vlp_dec_reduce_ln, vlp_argmax_rows2 (no existing struct changed) */
 
 typedef enum {
     VLP_OK = 0,

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libvlp_hip.so does not export %s" % name
     assert declared == set(_lib.SYMBOLS.keys()), declared ^ set(_lib.SYMBOLS.keys())
-    assert lib.vlp_version() == 4
+    assert lib.vlp_version() == 5
     # exported symbols visible to a plain dynamic loader (what a cgo/JNI/ctypes binding would see)
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (vlp_[a-z0-9_]+)", out))

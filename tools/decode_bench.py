@@ -70,6 +70,7 @@ for name, kw in MODES:
                            "algorithmic_mb": {"weights": round(w_bytes / 1e6, 1), "kv_history": round(kv_bytes / 1e6, 1), "logits": round(logit_bytes / 1e6, 1)},
                            "floor_ms_at_6.29_TBps": round(step_bytes / 6.29e12 * 1e3, 4)}
     del m
+    torch.cuda.empty_cache()          # (workspaces + captured graphs of one mode otherwise fragment the next mode's allocations: beam 5 after greedy + beam 3 measured 90 ms instead of 34)
 print(json.dumps(out))
 if os.environ.get("VLP_DEBUG_TUNE") == "1":
     from vlp_amd.engine import Engine

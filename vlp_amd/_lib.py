@@ -277,7 +277,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.vlp_version() != 4:      # include/vlp_hip.h VLP_ABI_VERSION
+    if lib.vlp_version() != 5:      # include/vlp_hip.h VLP_ABI_VERSION
         raise RuntimeError("libvlp_hip.so ABI version mismatch")
     _lib = lib
     return lib
