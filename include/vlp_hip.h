@@ -406,6 +406,11 @@ typedef struct {
     int32_t kv_col0, kv_Lcap, kv_T, kv_start;
     int32_t M, N, K, splits;
     int32_t act;                         /* VLP_ACT_NONE | VLP_ACT_GELU (splits == 1 only) */
+    const void* residual; int64_t ldr;   /* f16 [M, N] or NULL (splits == 1): Y = act(X W^T + bias + residual), one rounding (modeling.py:315-316) */
+    /* LayerNorm prologue (splits == 1, K <= 768): X holds PRE-LayerNorm rows; the kernel computes X' = LayerNorm(X) * gamma + beta (fp32 statistics,
+     * one rounding, modeling.py:188-192) in LDS and multiplies X'.  ln_out (optional): X' [M, K] is also written there (the next residual). */
+    const void* ln_gamma; const void* ln_beta; float ln_eps;
+    void* ln_out; int64_t ld_ln_out;
 } vlp_dec_gemm_args;
 int vlp_dec_gemm(const vlp_dec_gemm_args* a, void* stream);
 typedef struct {

@@ -147,6 +147,37 @@ def test_dec_split_gemm_plus_reduce_layernorm(M, H, Kd, S):
     assert float((outs[0].float() - ref).abs().mean()) <= 4e-4
 
 
+@pytest.mark.parametrize("M,N,Kd,act", [(128, 3072, 768, 2), (70, 96, 256, 0), (192, 768, 512, 0), (5, 40, 64, 2)])
+def test_dec_gemm_layernorm_prologue_and_residual(M, N, Kd, act):
+    """(a) residual epilogue: Y = fp16(X W^T + b + R) in one rounding; (b) LayerNorm prologue: Y = act(LayerNorm(P) W^T + b) with the normalised rows also
+    written to ln_out -- against torch fp32 on the fp16 operands, and against the two-launch form (layernorm_fwd, then the plain kernel) which
+    rounds at the same points."""
+    x, w, b = _rand16(M, Kd, seed=21), _rand16(N, Kd, scale=0.05, seed=22), _rand16(N, seed=23)
+    res = _rand16(M, N, seed=24)
+    y = torch.empty(M, N, device=DEV, dtype=torch.float16)
+    K.dec_gemm(x, w, M, N, Kd, y=y, bias=b, residual=res)
+    ref = x.float() @ w.float().t() + b.float() + res.float()
+    assert float((y.float() - ref).abs().max()) <= 3e-3 * max(1.0, float(ref.abs().max()))
+    # prologue
+    pre = _rand16(M, Kd, scale=2.0, seed=25) + 0.5
+    ga, be = (1 + 0.1 * _rand16(Kd, seed=26).float()).half(), _rand16(Kd, scale=0.1, seed=27)
+    y1 = torch.empty(M, N, device=DEV, dtype=torch.float16)
+    xn = torch.full((M + 2, Kd), 9.0, device=DEV, dtype=torch.float16)
+    K.dec_gemm(pre, w, M, N, Kd, y=y1, bias=b, act=K.ACT_GELU if act else K.ACT_NONE, ln_gamma=ga, ln_beta=be, ln_eps=1e-5, ln_out=xn)
+    xr = torch.empty(M, Kd, device=DEV, dtype=torch.float16)
+    if Kd % 256 == 0:
+        K.layernorm_fwd(pre, ga, be, xr, M, Kd)
+    else:
+        xr = torch.nn.functional.layer_norm(pre.float(), (Kd,), ga.float(), be.float(), 1e-5).half()
+    y2 = torch.empty(M, N, device=DEV, dtype=torch.float16)
+    K.dec_gemm(xr, w, M, N, Kd, y=y2, bias=b, act=K.ACT_GELU if act else K.ACT_NONE)
+    torch.cuda.synchronize()
+    refn = torch.nn.functional.layer_norm(pre.float(), (Kd,), ga.float(), be.float(), 1e-5)
+    assert float((xn[:M].float() - refn).abs().max()) <= 4e-3 and torch.all(xn[M:] == 9.0)
+    assert float((xn[:M].float() - xr.float()).abs().max()) <= 2e-3                  # an fp16 ulp at most where the statistics' summation order flips a rounding
+    assert float((y1.float() - y2.float()).abs().max()) <= 4e-3 * max(1.0, float(y2.float().abs().max()))
+
+
 @pytest.mark.parametrize("rows,V", [(64, 28996), (3, 1000), (5, 7), (2, 29056)])
 def test_argmax_rows2(rows, V):
     g = torch.Generator().manual_seed(rows * 131 + V)

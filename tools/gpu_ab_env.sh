@@ -5,7 +5,7 @@ export PYTHONUNBUFFERED=1
 for spec in "$@"; do
   name="${spec%%:*}"; envs="${spec#*:}"
   ( IFS='|'; for kv in $envs; do [ -n "$kv" ] && export "$kv"; done
-    timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -n 1 | python -c "
+    timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity 2>/dev/null | tail -n 1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
 v=d['config'].get('varlen') or {}

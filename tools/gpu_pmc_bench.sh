@@ -2,7 +2,7 @@
 # HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) and SQ counters of the kernels of the bench step -> gpurun_out/pmc_traffic.json, pmc_sq.json
 mkdir -p gpurun_out; export TMPDIR=/tmp PYTHONUNBUFFERED=1 VLP_WGRAD_SIDE_STREAM=0; cd $GRAFT_REPO_ROOT
 rm -rf /tmp/pf /tmp/pw /tmp/ps1 /tmp/ps2
-B="python bench.py --steps 6 --warmup 4 --no-cpu-baseline --no-kernel-events --no-varlen"
+B="python bench.py --steps 6 --warmup 4 --no-cpu-baseline --no-parity --no-kernel-events --no-varlen"
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -o p -- $B > /dev/null 2>gpurun_out/pmcf.err; echo "fetch pass $?"
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -o p -- $B > /dev/null 2>gpurun_out/pmcw.err; echo "write pass $?"
 timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 --kernel-trace --output-format csv -d /tmp/ps1 -o p -- $B > /dev/null 2>gpurun_out/pmcs1.err; echo "sq pass 1 $?"

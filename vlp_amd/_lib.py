@@ -82,7 +82,8 @@ class AttnDecodeArgs(C.Structure):
 class DecGemmArgs(C.Structure):
     _fields_ = [("X", vp), ("ldx", i64), ("W", vp), ("ldw", i64), ("bias", vp), ("Y", vp), ("ldy", i64), ("slab", vp), ("ldslab", i64),
                 ("kv_cache", vp), ("kv_ld", i64), ("kv_col0", i32), ("kv_Lcap", i32), ("kv_T", i32), ("kv_start", i32),
-                ("M", i32), ("N", i32), ("K", i32), ("splits", i32), ("act", i32)]
+                ("M", i32), ("N", i32), ("K", i32), ("splits", i32), ("act", i32),
+                ("residual", vp), ("ldr", i64), ("ln_gamma", vp), ("ln_beta", vp), ("ln_eps", f32), ("ln_out", vp), ("ld_ln_out", i64)]
 
 
 class DecReduceLnArgs(C.Structure):
@@ -410,13 +411,16 @@ def attn_decode(q, ld_q, q_rows, k, v, ld_kv, kv_rows, mask, ctx, B, Lq, Lk, hea
     _check(load().vlp_attn_decode(C.byref(a), stream_ptr()))
 
 
-def dec_gemm(x, w, M, N, Kd, y=None, bias=None, act=0, slab=None, splits=1, kv_cache=None, kv_col0=0, kv_Lcap=0, kv_T=1, kv_start=0):
+def dec_gemm(x, w, M, N, Kd, y=None, bias=None, act=0, slab=None, splits=1, kv_cache=None, kv_col0=0, kv_Lcap=0, kv_T=1, kv_start=0,
+             residual=None, ln_gamma=None, ln_beta=None, ln_eps=1e-5, ln_out=None):
     """Token-step Linear (csrc/decode.hip): y [M, N] fp16 (optionally K | V columns >= kv_col0 into kv_cache [seq, kv_Lcap, ld]) or, with
     `slab` (fp32 [splits, M, ldslab]), raw split-K partial sums for dec_reduce_ln."""
-    _req_cuda(x, w, y, bias, slab, kv_cache)
+    _req_cuda(x, w, y, bias, slab, kv_cache, residual, ln_gamma, ln_beta, ln_out)
     a = DecGemmArgs(ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), y.stride(0) if y is not None else 0,
                     ptr(slab), slab.stride(1) if slab is not None else 0, ptr(kv_cache), kv_cache.stride(1) if kv_cache is not None else 0,
-                    kv_col0, kv_Lcap, kv_T, kv_start, M, N, Kd, splits, act)
+                    kv_col0, kv_Lcap, kv_T, kv_start, M, N, Kd, splits, act,
+                    ptr(residual), residual.stride(0) if residual is not None else 0, ptr(ln_gamma), ptr(ln_beta), ln_eps,
+                    ptr(ln_out), ln_out.stride(0) if ln_out is not None else 0)
     _check(load().vlp_dec_gemm(C.byref(a), stream_ptr()))
 
 

@@ -11,7 +11,9 @@
 //                      trips -- and consumed in three groups behind counted vmcnt waits.  grid = (N / 32, M / 64, splits): 144 - 192
 //                      workgroups for every Linear of BERT-base.  Epilogues: bias (+ erf-GeLU) -> fp16; the QKV form writes the K | V
 //                      columns straight into the layer's K/V cache at the rows' absolute positions (no kv_append launch); splits > 1
-//                      (out-projection, FFN-down) writes fp32 partial tiles to a slab.
+//                      (FFN-down) writes fp32 partial tiles to a slab.  `residual`: + residual before the one rounding (BertSelfOutput).  LayerNorm
+//                      PROLOGUE (`ln_gamma`): X holds pre-LayerNorm rows; every workgroup normalises its 64 rows in LDS right after the burst lands
+//                      (a wave needs only its own vmcnt for the rows it staged) -- the LayerNorm launch between out-projection and FFN-up is gone.
 //   vlp_dec_reduce_ln  sums the slabs in a fixed order (deterministic: no atomics), adds bias + residual, rounds to fp16 exactly where the
 //                      unfused path rounds (its GEMM epilogue's fp16 output), and applies LayerNorm (TF style, fp32 statistics,
 //                      modeling.py:188-192): one wave per row, the slab reduce the split-K needed anyway IS the LayerNorm launch.
@@ -35,10 +37,13 @@ struct DecGemmParams {
     f16* Y; int64_t ldy;
     float* slab; int64_t ldslab;
     f16* kv; int64_t kv_ld; int kv_col0, kv_Lcap, kv_T, kv_start;
+    const f16* residual; int64_t ldr;                       // EPI 0: + residual[m][n] before the one rounding (BertSelfOutput's dense + residual)
+    const f16* ln_gamma; const f16* ln_beta; float ln_eps;  // LNP: X holds PRE-LayerNorm rows; the workgroup normalises its 64 rows in LDS first
+    f16* ln_out; int64_t ld_ln_out;                         //      and the workgroups of column tile 0 write the normalised rows here
     int M, N, K, nkt, act;
 };
 
-template <int EPI>      // 0: bias (+ GeLU) -> fp16 Y / K|V cache    1: fp32 partial tile -> slab[blockIdx.z]
+template <int EPI, bool LNP = false>      // EPI 0: bias (+ residual) (+ GeLU) -> fp16 Y / K|V cache    1: fp32 partial tile -> slab[blockIdx.z];  LNP: LayerNorm prologue
 __global__ __launch_bounds__(256, 1) void dec_gemm_kernel(DecGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     f16* smem = reinterpret_cast<f16*>(smem_raw);
@@ -87,9 +92,65 @@ __global__ __launch_bounds__(256, 1) void dec_gemm_kernel(DecGemmParams p) {
             acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1, xf, acc[1], 0, 0, 0);
         }
     };
+    if constexpr (LNP) {
+        // ---- LayerNorm prologue (BertLayerNorm, modeling.py:188-192; fp32 statistics, one rounding -- the arithmetic of layernorm_fwd / dec_reduce_ln):
+        // X holds the fp16 pre-LayerNorm rows (dense + bias + residual of the previous Linear).  A wave normalises the 16 rows IT staged (its own
+        // vmcnt covers them: no barrier), in place in LDS: 4 lanes per row (row 16 w + li, lane quarter g takes k tiles g, g + 4, g + 8), so the
+        // LayerNorm launch between the two Linears -- and the round trip of the normalised rows through HBM -- disappears.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // lane l <-> (row 8 j + (l >> 3) of the wave's 16, physical 16-byte chunk l & 7): one ds_read_b128 covers 8 whole 128-byte rows of a k tile =
+        // 1 KB contiguous in LDS (conflict-free: the DMA's own image); a row's sum is the lane's 12 chunks + a 3-step DPP reduction over its 8 lanes.
+        // (First form: 4 lanes per row, each reading 3 k tiles x 8 chunks -- 8-way bank conflicts and 48 parameter loads per lane: +9 us per launch.)
+        const int rb = lane >> 3, pc = lane & 7;
+        f16x8 raw[2][DG_MAXKT];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kt = 0; kt < DG_MAXKT; ++kt)
+                raw[j][kt] = (kt < nkt) ? ld8(xs + kt * XT + (16 * w + 8 * j + rb) * DG_BK + (pc << 3)) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        const float invK = 1.f / (float)p.K;
+        float mu[2], rs[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < DG_MAXKT; ++kt)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum += (float)raw[j][kt][e];
+            mu[j] = sum8(sum) * invK;
+            float sq = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < DG_MAXKT; ++kt)
+                if (kt < nkt) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float d = (float)raw[j][kt][e] - mu[j]; sq += d * d; }
+                }
+            rs[j] = 1.f / sqrtf(sum8(sq) * invK + p.ln_eps);
+        }
+        // the row's LOGICAL chunk at physical slot pc is pc ^ (row & 7) (the DMA swizzle): that is the column block gamma / beta are read at
+#pragma unroll
+        for (int kt = 0; kt < DG_MAXKT; ++kt) {
+            if (kt < nkt) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int r = 16 * w + 8 * j + rb;
+                    const int c = (int)k0 + kt * DG_BK + ((pc ^ (r & 7)) << 3);
+                    const f16x8 gv = ld8(p.ln_gamma + c), bv = ld8(p.ln_beta + c);
+                    f16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (f16)((float)gv[e] * (((float)raw[j][kt][e] - mu[j]) * rs[j]) + (float)bv[e]);
+                    st8(xs + kt * XT + r * DG_BK + (pc << 3), o);
+                    const int m_ln = m0 + r;
+                    if (p.ln_out && blockIdx.x == 0 && m_ln < p.M) st8(p.ln_out + (int64_t)m_ln * p.ld_ln_out + c, o);
+                }
+            }
+        }
+        __syncthreads();                                     // every wave's normalised rows + everybody's W pieces (their vmcnt(0) above) are in LDS
+        for (int kt = 0; kt < nkt; ++kt) compute(kt);
+    }
     // groups of DG_GROUP k tiles: the in-order vmcnt of this wave says its own pieces of the group have landed, the barrier says
     // everybody's have (every wave issued the same number of DMAs per k tile: 3)
-    const int ngroups = (nkt + DG_GROUP - 1) / DG_GROUP;
+    const int ngroups = LNP ? 0 : (nkt + DG_GROUP - 1) / DG_GROUP;
     for (int gi = 0; gi < ngroups; ++gi) {
         const int left = max(nkt - (gi + 1) * DG_GROUP, 0) * 3;       // DMAs of later groups that may stay in flight
         if (left >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
@@ -122,6 +183,16 @@ __global__ __launch_bounds__(256, 1) void dec_gemm_kernel(DecGemmParams p) {
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) if (nc + j < p.N) v[j] += (float)p.bias[nc + j];
+            }
+        }
+        if (p.residual) {
+            if (full) {
+                const f16x8 rr = ld8(p.residual + (int64_t)m * p.ldr + nc);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)rr[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (nc + j < p.N) v[j] += (float)p.residual[(int64_t)m * p.ldr + nc + j];
             }
         }
         if (p.act == VLP_ACT_GELU) {
@@ -157,6 +228,9 @@ extern "C" int vlp_dec_gemm(const vlp_dec_gemm_args* a, void* stream) {
     p.Y = (f16*)a->Y; p.ldy = a->ldy;
     p.slab = (float*)a->slab; p.ldslab = a->ldslab;
     p.kv = (f16*)a->kv_cache; p.kv_ld = a->kv_ld; p.kv_col0 = a->kv_col0; p.kv_Lcap = a->kv_Lcap; p.kv_T = a->kv_T; p.kv_start = a->kv_start;
+    p.residual = (const f16*)a->residual; p.ldr = a->ldr;
+    p.ln_gamma = (const f16*)a->ln_gamma; p.ln_beta = (const f16*)a->ln_beta; p.ln_eps = a->ln_eps;
+    p.ln_out = (f16*)a->ln_out; p.ld_ln_out = a->ld_ln_out;
     p.M = a->M; p.N = a->N; p.K = a->K; p.nkt = a->K / (DG_BK * a->splits); p.act = a->act;
     const dim3 grid(cdiv(a->N, DG_BN), cdiv(a->M, DG_BM), a->splits);
     const size_t smem = (size_t)DG_MAXKT * (DG_BM + DG_BN) * DG_BK * sizeof(f16);
@@ -164,9 +238,10 @@ extern "C" int vlp_dec_gemm(const vlp_dec_gemm_args* a, void* stream) {
     if (a->splits > 1 || a->slab) {
         VLP_CHECK_ARG(a->slab && a->ldslab % 8 == 0 && a->ldslab >= (a->N + 7) / 8 * 8 && (uintptr_t)a->slab % 16 == 0,
                       "vlp_dec_gemm: the split form needs an fp32 slab [splits][M][ldslab], ldslab %% 8 == 0, 16-byte aligned");
-        VLP_CHECK_ARG(a->act == VLP_ACT_NONE && !a->kv_cache, "vlp_dec_gemm: the split form stores raw partial sums (bias / activation belong to vlp_dec_reduce_ln)");
-        VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)dec_gemm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(dec_gemm_kernel<1>, grid, dim3(256), smem, s, p);
+        VLP_CHECK_ARG(a->act == VLP_ACT_NONE && !a->kv_cache && !a->residual && !a->ln_gamma,
+                      "vlp_dec_gemm: the split form stores raw partial sums (bias / residual / activation / LayerNorm belong to vlp_dec_reduce_ln)");
+        VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)dec_gemm_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((dec_gemm_kernel<1, false>), grid, dim3(256), smem, s, p);
     } else {
         VLP_CHECK_ARG(a->Y && a->ldy % 8 == 0 && (uintptr_t)a->Y % 16 == 0, "vlp_dec_gemm: bad Y layout");
         VLP_CHECK_ARG(!a->bias || (uintptr_t)a->bias % 16 == 0, "vlp_dec_gemm: bias must be 16-byte aligned");
@@ -174,8 +249,16 @@ extern "C" int vlp_dec_gemm(const vlp_dec_gemm_args* a, void* stream) {
             VLP_CHECK_ARG(a->kv_col0 % DG_BN == 0 && a->kv_col0 <= a->N && a->kv_ld % 8 == 0 && a->kv_T > 0 && a->kv_start >= 0 &&
                           a->kv_start + a->kv_T <= a->kv_Lcap && (uintptr_t)a->kv_cache % 16 == 0 && a->N % 8 == 0,
                           "vlp_dec_gemm: bad K/V cache arguments");
-        VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)dec_gemm_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(dec_gemm_kernel<0>, grid, dim3(256), smem, s, p);
+        if (a->residual) VLP_CHECK_ARG(a->ldr % 8 == 0 && (uintptr_t)a->residual % 16 == 0, "vlp_dec_gemm: bad residual layout");
+        if (a->ln_gamma) {
+            VLP_CHECK_ARG(a->ln_beta && ((uintptr_t)a->ln_gamma | (uintptr_t)a->ln_beta) % 16 == 0 && (!a->ln_out || (a->ld_ln_out % 8 == 0 && (uintptr_t)a->ln_out % 16 == 0)),
+                          "vlp_dec_gemm: bad LayerNorm-prologue arguments");
+            VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)dec_gemm_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL((dec_gemm_kernel<0, true>), grid, dim3(256), smem, s, p);
+        } else {
+            VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)dec_gemm_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL((dec_gemm_kernel<0, false>), grid, dim3(256), smem, s, p);
+        }
     }
     VLP_CHECK_LAUNCH("vlp_dec_gemm");
     return VLP_OK;

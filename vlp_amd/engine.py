@@ -962,6 +962,11 @@ class Engine(object):
     # slices, reduce + LayerNorm).  VLP_DECODE_FUSED=0: the round-2 path (split-K skinny GEMMs, separate reduces / kv_append / LayerNorms).
     DECODE_FUSED = os.environ.get("VLP_DECODE_FUSED", "1") == "1"
     DEC_SPLITS = 4
+    # VLP_DECODE_LN_PROLOGUE=1: the attention-output LayerNorm as a PROLOGUE of the FFN-up launch (6 launches per layer).  Built, tested and measured in
+    # round 6, NOT the default: every one of the 192 workgroups of the FFN-up grid normalises its 64 rows itself (16 rows per wave, ~25 VALU ops per
+    # element on one wave per SIMD): the launch goes 6.4 -> 15.5 us, more than the 4.8 us LayerNorm launch + boundary it removes
+    # (0.645 vs 0.559 ms per token step, profiles/r06_decode_ln_prologue_ab.txt).
+    DEC_LN_PROLOGUE = os.environ.get("VLP_DECODE_LN_PROLOGUE", "0") == "1"
     DEC_VOCAB = os.environ.get("VLP_DECODE_VOCAB_BURST", "1") == "1"      # the tied vocabulary projection of a token step on vlp_dec_gemm too
 
     def _decode_layers_fused(self, ws, caches, Lcap, x, alt, maskb, R, T, st, prefix):
@@ -985,10 +990,16 @@ class Engine(object):
                 pk = prefix[0][i]
                 K.attn_decode(ws["qkv"], 3 * H, T, kv, kv[:, :, H:], 2 * H, Lcap, maskb, ws["ctx"], R, T, Lk, A, scale, k_prefix=pk,
                               v_prefix=pk[:, :, H:], prefix_rows=Lcap, n_prefix=prefix[1], beams=prefix[2])
-            K.dec_gemm(ws["ctx"], self.P(Ln + "attention.output.dense.weight"), M, H, H, slab=slab, splits=S)
-            K.dec_reduce_ln(slab, S, self.P(Ln + "attention.output.dense.bias"), x, self.P(Ln + "attention.output.LayerNorm.weight"),
-                            self.P(Ln + "attention.output.LayerNorm.bias"), ws["x1"], M, H)
-            K.dec_gemm(ws["x1"], self.P(Ln + "intermediate.dense.weight"), M, I, H, y=ws["g"], bias=self.P(Ln + "intermediate.dense.bias"), act=K.ACT_GELU)
+            if self.DEC_LN_PROLOGUE:
+                # out-projection + bias + residual -> fp16 pre-LayerNorm rows; FFN-up normalises them in its prologue (and writes x1 for the next residual)
+                K.dec_gemm(ws["ctx"], self.P(Ln + "attention.output.dense.weight"), M, H, H, y=ws["pre"], bias=self.P(Ln + "attention.output.dense.bias"), residual=x)
+                K.dec_gemm(ws["pre"], self.P(Ln + "intermediate.dense.weight"), M, I, H, y=ws["g"], bias=self.P(Ln + "intermediate.dense.bias"), act=K.ACT_GELU,
+                           ln_gamma=self.P(Ln + "attention.output.LayerNorm.weight"), ln_beta=self.P(Ln + "attention.output.LayerNorm.bias"), ln_out=ws["x1"])
+            else:
+                K.dec_gemm(ws["ctx"], self.P(Ln + "attention.output.dense.weight"), M, H, H, slab=slab, splits=S)
+                K.dec_reduce_ln(slab, S, self.P(Ln + "attention.output.dense.bias"), x, self.P(Ln + "attention.output.LayerNorm.weight"),
+                                self.P(Ln + "attention.output.LayerNorm.bias"), ws["x1"], M, H)
+                K.dec_gemm(ws["x1"], self.P(Ln + "intermediate.dense.weight"), M, I, H, y=ws["g"], bias=self.P(Ln + "intermediate.dense.bias"), act=K.ACT_GELU)
             K.dec_gemm(ws["g"], self.P(Ln + "output.dense.weight"), M, H, I, slab=slab, splits=S)
             K.dec_reduce_ln(slab, S, self.P(Ln + "output.dense.bias"), ws["x1"], self.P(Ln + "output.LayerNorm.weight"),
                             self.P(Ln + "output.LayerNorm.bias"), alt, M, H)
