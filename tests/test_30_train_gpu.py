@@ -353,6 +353,28 @@ def test_entry_script_synthetic(tmp_path):
     assert os.path.exists(os.path.join(out2, "model.1.bin"))
 
 
+def test_entry_script_reference_readme_command_line(tmp_path):
+    """The reference README's example commands pass --amp WITHOUT --fp16 (README.md:112,131): in the reference that is the fp32 BertAdam path
+    (amp engages only with --fp16, run_img2txt_dist.py:305; optimizer :421-426).  Here the command line stops with a message that says so and
+    names both ways on; with --allow_fp16_compute it trains under BertAdam (own warm-up schedule, fp32 master weights, fp16 compute, static
+    loss scale on the backward): finite weights that moved, a loss that falls on a repeated synthetic pool."""
+    from vlp_amd import run_img2txt_dist as R
+    base = ["--do_train", "--new_segment_ids", "--always_truncate_tail", "--amp", "--enable_butd", "--s2s_prob", "1", "--bi_prob", "0", "--from_scratch",
+            "--max_len_b", "20", "--train_batch_size", "4", "--num_hidden_layers", "2", "--len_vis_input", "100", "--learning_rate", "1e-4", "--log_every", "1"]
+    with pytest.raises(NotImplementedError) as e:
+        R.main(["--output_dir", os.path.join(tmp_path, "refuse"), "--num_train_epochs", "1", "--synthetic", "2"] + base)
+    msg = str(e.value)
+    assert "README" in msg and "--fp16" in msg and "--allow_fp16_compute" in msg and "BertAdam" in msg
+    out = os.path.join(tmp_path, "run")
+    R.main(["--output_dir", out, "--num_train_epochs", "3", "--synthetic", "4", "--allow_fp16_compute"] + base)
+    sd = torch.load(os.path.join(out, "model.3.bin"))
+    assert all(torch.isfinite(v.float()).all() for v in sd.values())
+    osd = torch.load(os.path.join(out, "optim.3.bin"))
+    assert "vlp_master_fp32" in osd and osd["param_groups"][0]["schedule"] == "warmup_linear"          # BertAdam's state, not FP16_Optimizer_State's
+    losses = [float(l.rsplit("Loss", 1)[1]) for l in open(os.path.join(out, "training.log")) if "Iter" in l and "Loss" in l]
+    assert len(losses) == 12 and all(x == x for x in losses) and sum(losses[-4:]) < sum(losses[:4]), losses          # the same 4 pooled batches, three passes
+
+
 @pytest.mark.parametrize("mode", ["allreduce", "rs_ag", "sharded"])
 def test_bench_through_torchrun_and_rccl_world1(mode):
     """The launch line the driver uses for N > 1, with N = 1: RCCL process group, parameter broadcast, bucketed

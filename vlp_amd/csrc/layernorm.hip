@@ -309,6 +309,114 @@ __global__ __launch_bounds__(LNB_THREADS, NP <= 3 ? LNB_MINW : (NP == 4 ? 3 : 2)
     }
 }
 
+// Round 6: the SAME arithmetic for H == 256 NP (every LayerNorm of the model: 768) with a loop body the compiler can count.  In the kernel above
+// the next row's loads sit under lane-dependent (c < H) and row-dependent (row + nwaves < M, row_map != 0, dxd != 0) branches, so hipcc's waitcnt pass
+// cannot know how many requests are in flight at the join and puts `s_waitcnt vmcnt(0)` in front of the current row's arithmetic (seen in the ISA:
+// three of them per iteration): the "prefetch" was waited for in the iteration that issued it -- one row in flight per wave, not two.  Here every
+// iteration issues exactly the same loads (the next row is clamped to M - 1 instead of skipped; the optional operands are template switches), so the
+// waits are counted and a wave really keeps two rows of HBM traffic in flight.
+template <int NP, bool HAS_DXD, bool HAS_MAP>
+__global__ __launch_bounds__(LNB_THREADS, LNB_MINW) void layernorm_bwd_full_kernel(
+    const f16* __restrict__ dy, int64_t lddy, const f16* __restrict__ x, int64_t ldx, const f16* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ rstd, f16* __restrict__ dx, int64_t lddx,
+    f16* __restrict__ dxd, int64_t lddxd, float* __restrict__ part, int M, DropCtx dyd, DropCtx outd, const int32_t* __restrict__ row_map) {
+    constexpr int H = 256 * NP;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * LNB_WAVES + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * LNB_WAVES;
+    constexpr float invH = 1.f / (float)H;
+    float g[NP][4], dg[NP][4], db[NP][4];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const f16x4 gv = ld4(gamma + 256 * k + 4 * lane);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { g[k][e] = (float)gv[e]; dg[k][e] = 0.f; db[k][e] = 0.f; }
+    }
+    f16x4 xc[NP], dc[NP], xn[NP], dn[NP];
+    float mu_c, rs_c, mu_n, rs_n;
+    int map_c = 0, map_n = 0;
+    auto fetch = [&](int row, f16x4 (&X)[NP], f16x4 (&D)[NP], float& m_, float& r_, int& mp_) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            X[k] = ld4(x + (int64_t)row * ldx + 256 * k + 4 * lane);
+            D[k] = ld4(dy + (int64_t)row * lddy + 256 * k + 4 * lane);
+        }
+        m_ = mean[row];
+        r_ = rstd[row];
+        if constexpr (HAS_MAP) mp_ = row_map[row];
+    };
+    if (wave >= M) {                       // (no rows: only the zero partials below)
+        mu_c = rs_c = 0.f;
+    } else {
+        fetch(wave, xc, dc, mu_c, rs_c, map_c);
+    }
+    for (int row = wave; row < M; row += nwaves) {
+        fetch(min(row + nwaves, M - 1), xn, dn, mu_n, rs_n, map_n);        // ALWAYS (the tail re-reads row M - 1): a countable loop body
+        const float mu = mu_c, rs = rs_c;
+        const uint64_t drow = HAS_MAP ? (uint64_t)(uint32_t)map_c : (uint64_t)row;
+        const uint32_t rk_dy = dyd.thresh ? drop_rowkey(dyd, drow) : 0u;
+        const uint32_t rk_out = outd.thresh ? drop_rowkey(outd, drow) : 0u;
+        float xh[NP][4], d[NP][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int c = 256 * k + 4 * lane;
+            float m4[4] = {1.f, 1.f, 1.f, 1.f};
+            if (dyd.thresh) drop_mult4(dyd, rk_dy, (uint32_t)c, m4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dd = (float)dc[k][e] * m4[e];
+                xh[k][e] = ((float)xc[k][e] - mu) * rs;
+                dg[k][e] += dd * xh[k][e];
+                db[k][e] += dd;
+                d[k][e] = dd * g[k][e];
+                s1 += d[k][e];
+                s2 += d[k][e] * xh[k][e];
+            }
+        }
+        s1 = wave_sum(s1) * invH;
+        s2 = wave_sum(s2) * invH;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int c = 256 * k + 4 * lane;
+            f16x4 o, od;
+            float m4[4] = {1.f, 1.f, 1.f, 1.f};
+            if (HAS_DXD) drop_mult4(outd, rk_out, (uint32_t)c, m4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = rs * (d[k][e] - s1 - xh[k][e] * s2);
+                o[e] = (f16)t;
+                od[e] = (f16)(t * m4[e]);
+            }
+            st4_out<VLP_SS_LN>(dx + (int64_t)row * lddx + c, o);
+            if (HAS_DXD) st4_out<VLP_SS_LN>(dxd + (int64_t)row * lddxd + c, od);
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) { xc[k] = xn[k]; dc[k] = dn[k]; }
+        mu_c = mu_n;
+        rs_c = rs_n;
+        map_c = map_n;
+    }
+    extern __shared__ float lnb_sh[];      // [LNB_WAVES][2H]
+    {
+        float* sg = lnb_sh + (threadIdx.x >> 6) * 2 * H;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int c = 256 * k + 4 * lane;
+            *reinterpret_cast<f32x4*>(sg + c) = (f32x4){dg[k][0], dg[k][1], dg[k][2], dg[k][3]};
+            *reinterpret_cast<f32x4*>(sg + H + c) = (f32x4){db[k][0], db[k][1], db[k][2], db[k][3]};
+        }
+    }
+    __syncthreads();
+    float* dst = part + (int64_t)blockIdx.x * 2 * H;
+    for (int i = threadIdx.x; i < 2 * H; i += LNB_THREADS) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < LNB_WAVES; ++w) t += lnb_sh[w * 2 * H + i];
+        dst[i] = t;
+    }
+}
+
 // out[0..H) = dgamma, out[H..2H) = dbeta from part[nparts][2H].  Block = 64 columns x 16 partial-groups.
 __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nparts, int H, f16* dgamma, f16* dbeta, int beta) {
     __shared__ float sh[16][64];
@@ -369,7 +477,19 @@ extern "C" int vlp_layernorm_bwd(const vlp_layernorm_bwd_args* a, void* stream) 
         (void)hipFuncSetAttribute((const void*)layernorm_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * 1024 * 4);
         (void)hipFuncSetAttribute((const void*)layernorm_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * 2048 * 4);
     });
-    if (a->H <= 768)
+    // H = 768: the countable-loop form (VLP_LNB_FULL=0: the general kernel, A/B runs)
+    static const int full_on = [] { const char* e = getenv("VLP_LNB_FULL"); return (e && e[0] == '0') ? 0 : 1; }();
+    if (full_on && a->H == 768) {
+        const bool hd = a->dx_drop != nullptr, hm = a->row_map != nullptr && (dyd.thresh || outd.thresh);
+#define LAUNCH_LNB_FULL(HD_, HM_)                                                                                                                       \
+    do {                                                                                                                                                \
+        VLP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)layernorm_bwd_full_kernel<3, HD_, HM_>, hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * 768 * 4)); \
+        hipLaunchKernelGGL((layernorm_bwd_full_kernel<3, HD_, HM_>), dim3(blocks), dim3(LNB_THREADS), lnb_smem, s, (const f16*)a->dy, a->lddy, (const f16*)a->x,       \
+                           a->ldx, (const f16*)a->gamma, a->mean, a->rstd, (f16*)a->dx, a->lddx, (f16*)a->dx_drop, a->lddxd, part, a->M, dyd, outd, a->row_map);          \
+    } while (0)
+        if (hd && hm) LAUNCH_LNB_FULL(true, true); else if (hd) LAUNCH_LNB_FULL(true, false); else if (hm) LAUNCH_LNB_FULL(false, true); else LAUNCH_LNB_FULL(false, false);
+#undef LAUNCH_LNB_FULL
+    } else if (a->H <= 768)
         hipLaunchKernelGGL(layernorm_bwd_kernel<3>, dim3(blocks), dim3(LNB_THREADS), lnb_smem, s, (const f16*)a->dy, a->lddy, (const f16*)a->x, a->ldx,
                            (const f16*)a->gamma, a->mean, a->rstd, (f16*)a->dx, a->lddx, (f16*)a->dx_drop, a->lddxd, part, a->M, a->H, dyd, outd, a->row_map);
     else if (a->H <= 1024)

@@ -289,8 +289,14 @@ def build_packed_loader(args, device):
 
 
 def synthetic_batches(args, device, steps, rank):
-    """Device-resident synthetic batches (a small rotating pool, seeded per rank like a DistributedSampler shard)."""
-    pool = []
+    """Device-resident synthetic batches (a small rotating pool, seeded per rank like a DistributedSampler shard).  The pool is built once per
+    run and reused by every epoch: the same tensor objects come back, so the padding-free step derives their kept lengths once."""
+    pool = getattr(args, "_synthetic_pool", None)
+    if pool is not None:
+        for s in range(steps):
+            yield pool[s % len(pool)]
+        return
+    pool = args._synthetic_pool = []
     for i in range(min(4, steps)):
         b = synthetic.make_batch(args.train_batch_size, max_len_b=args.max_len_b, len_vis_input=args.len_vis_input,
                                  vocab_size=KNOWN_VOCABS.get(args.bert_model, 28996), max_pred=args.max_pred, mask_prob=args.mask_prob,
@@ -306,7 +312,8 @@ def main(argv=None):
     os.makedirs(args.output_dir, exist_ok=True)
     json.dump(args.__dict__, open(os.path.join(args.output_dir, "opt.json"), "w"), sort_keys=True, indent=2)
     logging.basicConfig(filename=os.path.join(args.output_dir, args.log_file), filemode="w",
-                        format="%(asctime)s - %(levelname)s - %(name)s -   %(message)s", datefmt="%m/%d/%Y %H:%M:%S", level=logging.INFO)
+                        format="%(asctime)s - %(levelname)s - %(name)s -   %(message)s", datefmt="%m/%d/%Y %H:%M:%S", level=logging.INFO,
+                        force=True)      # (a second main() in one process logs to ITS output_dir, not to the first one's file)
     logger = logging.getLogger(__name__)
     if args.no_cuda or not torch.cuda.is_available():
         raise RuntimeError("vlp_amd has no CPU path: an MI355X is required (the reference's --no_cuda mode is not provided)")
