@@ -41,6 +41,10 @@ for name, kw in MODES:
     dt = (time.perf_counter() - t0) / n
     out[name] = {"ms_per_batch": round(dt * 1e3, 2), "captions_per_s": round(B / dt, 1), "ms_per_token_step": round(dt * 1e3 / T, 3),
                  "host_enqueue_ms": round(t_enq * 1e3, 2)}
+    if name != "greedy":
+        # beam_search() returns the best sequences, which needs one device -> host copy of the frames: the call itself waits for the GPU, so the
+        # "enqueue" figure equals the wall time; the device work is enqueued in ~2 ms (Engine.decode_beam, hipGraph replays) -- decoding is not host-bound
+        out[name]["host_enqueue_includes_final_device_to_host_copy"] = True
     if name == "greedy":
         # roofline of a TOKEN step (HBM-bound: every step streams the encoder + head weights and the K/V history once): algorithmic bytes =
         # fp16 weights of the 12 layers + head transform + tied vocabulary matrix, + K | V rows of every position decoded so far (B x Lk x 2H

@@ -1108,9 +1108,12 @@ class Engine(object):
                 g.replay()
                 ws["plans"][key] = g
                 return
-            except Exception:                    # capture not possible here: fall back to the ctypes plan
+            except Exception as e:               # capture not possible here: fall back to the ctypes plan (host-bound: say so, once)
                 torch.cuda.synchronize()
                 Engine.DECODE_GRAPHS = False
+                import warnings
+                warnings.warn("vlp_amd: hipGraph capture of a decoder token step failed (%r); token steps fall back to replayed ctypes launch plans, "
+                              "which are bound by host launch overhead" % (e,), VlpPerformanceWarning)
         with K.record() as plan:
             fn()
         ws["plans"][key] = plan

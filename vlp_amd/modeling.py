@@ -660,15 +660,40 @@ class BertForSeq2SeqDecoder(PreTrainedBertModel):
         tot, wids, ptrs = self.engine.decode_beam(vis_feats, vis_pe, input_ids, token_type_ids, position_ids, attention_mask, self.mask_word_id,
                                                   K, self.eos_id, min_len=self.min_len, forbid_fn=forbid_fn)
         frames = tot.shape[0]
-        tot_l, wid_l, ptr_l = tot.tolist(), wids.tolist(), ptrs.tolist()           # one device -> host copy each
         dev = input_ids.device
-        traces = {"pred_seq": torch.zeros(B, out_len, dtype=torch.long), "scores": torch.zeros(B, out_len, K, dtype=torch.float32),
-                  "wids": torch.zeros(B, out_len, K, dtype=torch.long), "ptrs": torch.zeros(B, out_len, K, dtype=torch.long)}
-        for b in range(B):
-            sc, ww, pp = [tot_l[f][b] for f in range(frames)], [wid_l[f][b] for f in range(frames)], [ptr_l[f][b] for f in range(frames)]
-            seq = self._backtrack(sc, ww, pp)
-            traces["pred_seq"][b, :len(seq)] = torch.tensor(seq, dtype=torch.long)
-            traces["scores"][b, :frames] = torch.tensor(sc, dtype=torch.float32)
-            traces["wids"][b, :frames] = torch.tensor(ww, dtype=torch.long)
-            traces["ptrs"][b, :frames] = torch.tensor(pp, dtype=torch.long)
-        return {k: v.to(dev) for k, v in traces.items()}
+        # frames stay on the device: [frames, B, K] -> [B, out_len, K], zero padded (three small launches; no per-sample host loop)
+        scores = torch.zeros(B, out_len, K, dtype=torch.float32, device=dev)
+        wid_o = torch.zeros(B, out_len, K, dtype=torch.long, device=dev)
+        ptr_o = torch.zeros(B, out_len, K, dtype=torch.long, device=dev)
+        scores[:, :frames] = tot.permute(1, 0, 2)
+        wid_o[:, :frames] = wids.permute(1, 0, 2)
+        ptr_o[:, :frames] = ptrs.permute(1, 0, 2)
+        # best hypothesis of every sample (:1446-1474), vectorised over the batch on the host: ONE device -> host copy of the three frame tensors
+        pred = self._backtrack_batch(tot.cpu().numpy(), wids.cpu().numpy(), ptrs.cpu().numpy(), out_len)
+        return {"pred_seq": torch.from_numpy(pred).to(dev), "scores": scores, "wids": wid_o, "ptrs": ptr_o}
+
+    def _backtrack_batch(self, scores, words, back, out_len):
+        """_backtrack for all samples at once (numpy; arrays [frames, B, K]) -> int64 [B, out_len], 0 padded.  Same rules: candidates are the
+        hypotheses that emitted eos, or any hypothesis of the last valid frame (the first frame whose K words are all eos, else the final one);
+        rank by cumulative log-probability + length_penalty * (frame + 1), first maximum in (frame, beam) order; follow the back pointers."""
+        import numpy as np
+        F, B, K = scores.shape
+        eos, lp = self.eos_id, self.length_penalty
+        all_eos = (words == eos).all(axis=2)                                   # [F, B]
+        last = np.where(all_eos.any(axis=0), all_eos.argmax(axis=0), F - 1)    # [B]
+        f_idx = np.arange(F)[:, None, None]
+        cand = (f_idx <= last[None, :, None]) & ((words == eos) | (f_idx == last[None, :, None]))
+        val = np.where(cand, scores.astype(np.float64) + lp * (f_idx + 1), -np.inf)      # [F, B, K]
+        flat = val.transpose(1, 0, 2).reshape(B, F * K)
+        best = flat.argmax(axis=1)                                             # first maximum in (frame, beam) order, as the reference's strict `>` scan
+        ok = np.isfinite(flat[np.arange(B), best])
+        bf, bk = best // K, best % K
+        out = np.zeros((B, out_len), dtype=np.int64)
+        rows = np.arange(B)
+        k = bk.copy()
+        for t in range(F - 1, -1, -1):
+            live = ok & (t <= bf)
+            out[live, t] = words[t, rows, k][live]
+            if t > 0:
+                k = np.where(live, back[t, rows, k], k)
+        return out
