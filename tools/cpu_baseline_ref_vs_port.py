@@ -82,6 +82,6 @@ out = {"what": "one training step (forward + backward + BertAdam.step), B=16, L=
        "reference_over_port": round(t_port / t_ref, 3),
        "note": "reference = /root/reference pytorch_pretrained_bert (unmodified, dropout 0.1, train mode) + optimization.BertAdam; port = oracle/vlp_oracle.py "
                "(dropout-free functional restatement + bert_adam_step): bench.py's cpu_baseline times the port on the GPU box's host cores"}
-path = os.path.join(ROOT, "profiles", "r03_cpu_baseline_reference_vs_port.json")
+path = os.path.join(ROOT, "profiles", "r06_cpu_baseline_reference_vs_port.json")
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(out, indent=1))
