@@ -375,6 +375,25 @@ def test_entry_script_reference_readme_command_line(tmp_path):
     assert len(losses) == 12 and all(x == x for x in losses) and sum(losses[-4:]) < sum(losses[:4]), losses          # the same 4 pooled batches, three passes
 
 
+def test_entry_script_baseline_config0_shape(tmp_path):
+    """BASELINE.json configs[0] through the entry script: 2 layers, 8 regions, seq_len 32, bs 4, world_size 1 (--local_rank -1), the reference's
+    fp32 command line (no --fp16: BertAdam, run_img2txt_dist.py:421-426).  The reference runs it on the CPU; here the same command line plus
+    --allow_fp16_compute runs it on the GPU under BertAdam with fp32 master weights (there is no CPU product path): checkpoints
+    in the reference's key names, finite weights, a loss that falls over three passes of the same four pooled batches."""
+    from vlp_amd import run_img2txt_dist as R
+    out = os.path.join(tmp_path, "cfg0")
+    R.main(["--output_dir", out, "--do_train", "--new_segment_ids", "--enable_butd", "--from_scratch", "--local_rank", "-1", "--len_vis_input", "8",
+            "--max_len_b", "21", "--train_batch_size", "4", "--num_hidden_layers", "2", "--num_train_epochs", "3", "--synthetic", "4",
+            "--learning_rate", "1e-4", "--log_every", "1", "--allow_fp16_compute"])
+    sd = torch.load(os.path.join(out, "model.3.bin"))
+    assert "bert.encoder.layer.1.output.LayerNorm.bias" in sd and "bert.encoder.layer.2.output.LayerNorm.bias" not in sd
+    assert all(torch.isfinite(v.float()).all() for v in sd.values())
+    osd = torch.load(os.path.join(out, "optim.3.bin"))
+    assert "vlp_master_fp32" in osd
+    losses = [float(l.rsplit("Loss", 1)[1]) for l in open(os.path.join(out, "training.log")) if "Iter" in l and "Loss" in l]
+    assert len(losses) == 12 and all(x == x for x in losses) and sum(losses[-4:]) < sum(losses[:4]), losses
+
+
 @pytest.mark.parametrize("mode", ["allreduce", "rs_ag", "sharded"])
 def test_bench_through_torchrun_and_rccl_world1(mode):
     """The launch line the driver uses for N > 1, with N = 1: RCCL process group, parameter broadcast, bucketed

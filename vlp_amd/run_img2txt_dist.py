@@ -384,7 +384,7 @@ def main(argv=None):
             if not acc:
                 global_step += 1
             if step % args.log_every == 0:        # the only host read-back; the reference does 4 per step (:535-538)
-                losses.append(float(lt[0] + lt[1] + lt[2]))
+                losses.append(float((lt[0] + lt[1] + lt[2]).detach()))
                 logger.info("Epoch %d, Iter %d, Loss %.3f", i_epoch, step, losses[-1])
         torch.cuda.synchronize()
         dt = time.time() - t0
